@@ -1,0 +1,209 @@
+/*
+ * pvc3.h — C ABI of the MI355X-native project_alignments hot path (libpvc3_hip.so).
+ *
+ * Drop-in boundary for PanVC 3's libpanvc3 alignment_projector: everything the reference's
+ * project_task::process() computes per record between reading a BAM record and writing it back
+ * (project-alignments/project_alignments.cc:721-732 and :897-901) is computed here for a whole batch
+ * of records on one GPU.  Plain pointers and sizes only; no exceptions cross the boundary; every
+ * function returns PVC3_OK (0) or a negative PVC3_E_* code (pvc3_last_error() gives the message).
+ *
+ * Reference interface replaced by each entry point (paths relative to the reference tree):
+ *   pvc3_index_add_aligned / _add_bits   msa_index::sequence_entry(seq_id, bit_vector) include/panvc3/msa_index.hh:58-65,
+ *                                        make_sequence_entry_pair :214-236, index-msa/index_vector_builder.cc:29-52
+ *   pvc3_index_set_reference             the dst contig buffer handed to project_alignment (ref_seq),
+ *                                        project_alignments.cc:575-594, :726
+ *   pvc3_project_positions               msa_index::sequence_entry::project_position include/panvc3/msa_index.hh:253-258
+ *                                        (call sites project_alignments.cc:900, convert-bed-positions/main.cc:60-73)
+ *   pvc3_batch_project / pvc3_dbatch_*   alignment_projector::project_alignment include/panvc3/alignment_projector.hh:58-68
+ *                                        + accessors :70-74 (alignment(), realigned_reference_ranges(),
+ *                                        realigned_query_ranges()), libpanvc3/alignment_projector.cc:30-154
+ *
+ * Threading: a pvc3_context is used by one host thread at a time; a finalized pvc3_index is read-only and
+ * may be shared by several contexts (one per GPU).  There is no CPU fallback: without a GPU
+ * pvc3_context_create() fails with PVC3_E_NO_DEVICE.
+ */
+#ifndef PVC3_H
+#define PVC3_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVC3_API __attribute__((visibility("default")))
+
+#define PVC3_VERSION 100	/* 0.1.0 */
+
+/* Return codes. */
+enum
+{
+	PVC3_OK = 0,
+	PVC3_E_INVALID = -1,		/* bad argument */
+	PVC3_E_NOMEM = -2,			/* host or device allocation failed */
+	PVC3_E_HIP = -3,			/* HIP runtime error */
+	PVC3_E_NO_DEVICE = -4,		/* no usable GPU */
+	PVC3_E_CAPACITY = -5,		/* caller-provided output buffer too small (needed sizes are reported) */
+	PVC3_E_STATE = -6			/* call sequence error (e.g. index not uploaded) */
+};
+
+/* Per-record status (pvc3_batch_out.status).  A record with a non-zero status has empty outputs. */
+enum
+{
+	PVC3_ST_OK = 0,
+	PVC3_ST_SRC_RANGE = 1,		/* src_pos (+ reference-consuming length) beyond the source sequence */
+	PVC3_ST_CIGAR_OP = 2,		/* CIGAR operation code > 8 (rewrite_cigar.hh:149-151 libbio_fail) */
+	PVC3_ST_QUERY_RANGE = 3,	/* CIGAR consumes more query bases than l_seq (rewrite_cigar.hh:102 assert) */
+	PVC3_ST_REF_RANGE = 4		/* dst text missing or too short (rewrite_cigar.hh:103 assert) */
+};
+
+/* BAM CIGAR encoding: (count << 4) | op, op codes "MIDNSHP=X" = 0..8. */
+enum { PVC3_CIGAR_M = 0, PVC3_CIGAR_I, PVC3_CIGAR_D, PVC3_CIGAR_N, PVC3_CIGAR_S, PVC3_CIGAR_H, PVC3_CIGAR_P, PVC3_CIGAR_EQ, PVC3_CIGAR_X };
+
+/* Record flags. */
+enum
+{
+	PVC3_FLAG_HAS_QUAL = 1u,	/* base qualities present => Malde base-quality scoring (alignment_projector.cc:76, :97-137) */
+	PVC3_FLAG_HAS_MATE = 2u		/* mate_* fields valid => mate_dst_pos is computed (project_alignments.cc:880-905) */
+};
+
+#define PVC3_NO_MATE 0xFFFFFFFFu
+
+/* Realignment score type (seqan3 is not part of the reference snapshot). */
+enum
+{
+	PVC3_SCORE_FP64 = 0,		/* Malde scores as doubles (base_quality_scorer::score_type, align.hh:26) */
+	PVC3_SCORE_INT32_TRUNC = 1	/* each substitution score truncated to int32 (upstream seqan3's default score type) */
+};
+
+typedef struct pvc3_index pvc3_index;
+typedef struct pvc3_context pvc3_context;
+typedef struct pvc3_dbatch pvc3_dbatch;
+
+typedef struct pvc3_params
+{
+	int32_t gap_open;			/* --gap-opening-cost, seqan3 open_score (cmdline.ggo:43; default 0) */
+	int32_t gap_ext;			/* --gap-extension-cost, seqan3 extension_score (cmdline.ggo:44; default -1) */
+	int32_t score_mode;			/* PVC3_SCORE_* */
+	int32_t tiebreak_mode;		/* 0 = restated seqan3 order: diagonal > up ('I') > left ('D'), extension > opening */
+} pvc3_params;
+
+/* One realigned indel run (alignment_projector.cc:69-73). */
+typedef struct pvc3_run
+{
+	uint32_t query_location;	/* realigned_query_ranges(): [location, location + length), soft-clipped bases included */
+	uint32_t query_length;
+	uint32_t ref_position;		/* realigned_reference_ranges().location: indel_run_checker::reference_position() at
+								   report time, i.e. the position AFTER the run-terminating operation (quirk Q7) */
+	uint32_t ref_length;
+} pvc3_run;
+
+/* Input batch, structure of arrays.  All pointers are host pointers for pvc3_batch_project / pvc3_dbatch_create. */
+typedef struct pvc3_batch_in
+{
+	uint64_t n;						/* number of records */
+	uint32_t const *src_pos;		/* [n] 0-based position in the unaligned source sequence (BAM POS) */
+	uint32_t const *src_entry;		/* [n] index entry of the source sequence (the record's RNAME, chr<sep>seq) */
+	uint32_t const *dst_entry;		/* [n] index entry of the destination row (--reference-msa-id of the same chromosome) */
+	uint32_t const *flags;			/* [n] PVC3_FLAG_* */
+	uint64_t const *cigar_off;		/* [n + 1] offsets into cigar */
+	uint32_t const *cigar;			/* BAM-encoded operations */
+	uint64_t const *seq_off;		/* [n + 1] byte offsets into seq4 (each record starts on a byte boundary, as in BAM) */
+	uint32_t const *l_seq;			/* [n] number of bases */
+	uint8_t const *seq4;			/* BAM 4-bit bases "=ACMGRSVTWYHKDBN", high nibble first */
+	uint64_t const *qual_off;		/* [n + 1] offsets into qual; may be NULL if no record has PVC3_FLAG_HAS_QUAL */
+	uint8_t const *qual;			/* raw phred values (BAM QUAL); values > 41 saturate (seqan3::phred42) */
+	uint32_t const *mate_src_entry;	/* [n] index entry of the mate's source sequence (RNEXT); may be NULL */
+	uint32_t const *mate_dst_entry;	/* [n] destination row of the mate's chromosome; may be NULL */
+	uint32_t const *mate_pos;		/* [n] 0-based mate position (PNEXT); may be NULL */
+} pvc3_batch_in;
+
+/* Output batch.  Caller-allocated host buffers; variable-length outputs are packed in record order. */
+typedef struct pvc3_batch_out
+{
+	uint32_t *dst_pos;				/* [n] return value of project_alignment(): new 0-based POS */
+	uint32_t *mate_dst_pos;			/* [n] projected mate position, PVC3_NO_MATE if the record has no mate */
+	int32_t *status;				/* [n] PVC3_ST_* */
+	uint64_t *out_cigar_off;		/* [n + 1] */
+	uint32_t *out_cigar;			/* alignment(): rewritten + realigned + collapsed CIGAR, BAM-encoded */
+	uint64_t out_cigar_cap;			/* capacity of out_cigar in operations */
+	uint64_t *run_off;				/* [n + 1] */
+	pvc3_run *runs;					/* realigned ranges */
+	uint64_t run_cap;
+} pvc3_batch_out;
+
+typedef struct pvc3_batch_stats
+{
+	uint64_t n_records;
+	uint64_t n_failed;				/* records with status != 0 */
+	uint64_t n_realigned_records;	/* records with at least one indel run */
+	uint64_t n_runs;				/* total realigned indel runs */
+	uint64_t out_cigar_total;		/* total output CIGAR operations (required out_cigar_cap) */
+	uint64_t algorithmic_bytes;		/* SURVEY.md §8(d) bytes of this batch (reads + writes), see DESIGN.md */
+	float ms_project;				/* last launch durations (hipEvent), 0 if timing is disabled */
+	float ms_mate;
+	float ms_realign;
+	float ms_pack;
+	uint32_t attempts;				/* 1 unless a workspace had to grow */
+	uint32_t reserved;
+} pvc3_batch_stats;
+
+/* ---- library ---------------------------------------------------------------------------------------------------- */
+PVC3_API int pvc3_version(void);
+PVC3_API char const *pvc3_strerror(int code);
+PVC3_API char const *pvc3_last_error(void);				/* thread-local message of the last failing call */
+PVC3_API int pvc3_device_count(int *count);
+
+/* ---- index (host side; msa_index.hh) ---------------------------------------------------------------------------- */
+PVC3_API int pvc3_index_create(pvc3_index **idx);
+PVC3_API void pvc3_index_destroy(pvc3_index *idx);
+/* Column i is a gap iff aligned[i] == '-'.  Returns the new entry id in *entry. */
+PVC3_API int pvc3_index_add_aligned(pvc3_index *idx, char const *aligned, uint64_t n_cols, uint32_t *entry);
+/* Bit (i & 63) of gap_words[i >> 6] is 1 iff column i is a gap. */
+PVC3_API int pvc3_index_add_bits(pvc3_index *idx, uint64_t const *gap_words, uint64_t n_cols, uint32_t *entry);
+/* Unaligned text (raw FASTA bytes, case preserved) of an entry used as a destination; len >= number of non-gap columns.
+ * The bytes are copied. */
+PVC3_API int pvc3_index_set_reference(pvc3_index *idx, uint32_t entry, char const *text, uint64_t len);
+PVC3_API int pvc3_index_entry_count(pvc3_index const *idx, uint32_t *count);
+PVC3_API int pvc3_index_entry_info(pvc3_index const *idx, uint32_t entry, uint64_t *n_cols, uint64_t *n_non_gap);
+/* Host view of the HBM layout of one entry (for inspection and host-logic tests):
+ * blocks = n_blocks x 8 uint64 {non-gap columns before the block, 7 x 64 gap bits}; sel[j] = column of non-gap #(64 j). */
+PVC3_API int pvc3_index_entry_layout(pvc3_index const *idx, uint32_t entry, uint64_t const **blocks, uint64_t *n_blocks, uint32_t const **sel, uint64_t *n_sel);
+
+/* ---- device context ------------------------------------------------------------------------------------------------ */
+PVC3_API int pvc3_context_create(int device, pvc3_context **ctx);
+PVC3_API void pvc3_context_destroy(pvc3_context *ctx);
+/* Launch on a caller-owned hipStream_t (NULL restores the context's own stream). */
+PVC3_API int pvc3_context_set_stream(pvc3_context *ctx, void *hip_stream);
+PVC3_API int pvc3_context_set_timing(pvc3_context *ctx, int enabled);	/* hipEvent pairs around each kernel group */
+PVC3_API int pvc3_context_synchronize(pvc3_context *ctx);
+/* Tuning / test knobs: "realign_waves", "realign_lds_bytes", "scratch_per_wave", "arena_initial", "runs_initial". */
+PVC3_API int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value);
+/* Replicates the index (bit-vector blocks, select samples, reference texts) into this context's HBM. */
+PVC3_API int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx);
+PVC3_API int pvc3_context_hbm_bytes(pvc3_context const *ctx, uint64_t *index_bytes, uint64_t *workspace_bytes);
+
+/* ---- hot path ------------------------------------------------------------------------------------------------------ */
+/* Host buffers in, host buffers out: upload, project + realign, pack, download.  On PVC3_E_CAPACITY the required
+ * capacities are stored in out->out_cigar_off[n] and out->run_off[n]. */
+PVC3_API int pvc3_batch_project(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_batch_out *out, pvc3_params const *params, pvc3_batch_stats *stats);
+
+/* Device-resident form: inputs are uploaded once, pvc3_dbatch_project() only enqueues kernels on the context's stream
+ * (inputs and outputs stay in HBM), pvc3_dbatch_finish() waits and reports, pvc3_dbatch_download() copies results out. */
+PVC3_API int pvc3_dbatch_create(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_dbatch **batch);
+PVC3_API void pvc3_dbatch_destroy(pvc3_dbatch *batch);
+PVC3_API int pvc3_dbatch_project(pvc3_context *ctx, pvc3_dbatch *batch, pvc3_params const *params);
+PVC3_API int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *batch, pvc3_batch_stats *stats);
+PVC3_API int pvc3_dbatch_download(pvc3_context *ctx, pvc3_dbatch *batch, pvc3_batch_out *out);
+/* 64-bit checksum of all outputs, computed on the device: the wrapping sum over records of a hash of (first_record + i,
+ * dst_pos, mate_dst_pos, status, CIGAR, runs).  Additive, so the checksums of shards add up to that of the whole. */
+PVC3_API int pvc3_dbatch_checksum(pvc3_context *ctx, pvc3_dbatch *batch, uint64_t first_record, uint64_t *checksum);
+
+/* project_position for n independent positions: out[i] = rank0_dst(select0_src(1 + pos[i])); PVC3_NO_MATE if out of range. */
+PVC3_API int pvc3_project_positions(pvc3_context *ctx, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,110 @@
+"""Loads libpvc3_hip.so (the HIP kernels + C ABI).  There is no fallback: if the library is missing, loading fails."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpvc3_hip.so")
+
+_lib = None
+
+
+class Error(RuntimeError):
+	def __init__(self, code, message):
+		super().__init__("pvc3 error %d: %s" % (code, message))
+		self.code = code
+
+
+class Run(C.Structure):
+	_fields_ = [("query_location", C.c_uint32), ("query_length", C.c_uint32), ("ref_position", C.c_uint32), ("ref_length", C.c_uint32)]
+
+
+class Params(C.Structure):
+	_fields_ = [("gap_open", C.c_int32), ("gap_ext", C.c_int32), ("score_mode", C.c_int32), ("tiebreak_mode", C.c_int32)]
+
+
+class BatchIn(C.Structure):
+	_fields_ = [
+		("n", C.c_uint64),
+		("src_pos", C.c_void_p), ("src_entry", C.c_void_p), ("dst_entry", C.c_void_p), ("flags", C.c_void_p),
+		("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+		("seq_off", C.c_void_p), ("l_seq", C.c_void_p), ("seq4", C.c_void_p),
+		("qual_off", C.c_void_p), ("qual", C.c_void_p),
+		("mate_src_entry", C.c_void_p), ("mate_dst_entry", C.c_void_p), ("mate_pos", C.c_void_p),
+	]
+
+
+class BatchOut(C.Structure):
+	_fields_ = [
+		("dst_pos", C.c_void_p), ("mate_dst_pos", C.c_void_p), ("status", C.c_void_p),
+		("out_cigar_off", C.c_void_p), ("out_cigar", C.c_void_p), ("out_cigar_cap", C.c_uint64),
+		("run_off", C.c_void_p), ("runs", C.c_void_p), ("run_cap", C.c_uint64),
+	]
+
+
+class BatchStats(C.Structure):
+	_fields_ = [
+		("n_records", C.c_uint64), ("n_failed", C.c_uint64), ("n_realigned_records", C.c_uint64), ("n_runs", C.c_uint64),
+		("out_cigar_total", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+		("ms_project", C.c_float), ("ms_mate", C.c_float), ("ms_realign", C.c_float), ("ms_pack", C.c_float),
+		("attempts", C.c_uint32), ("reserved", C.c_uint32),
+	]
+
+
+def lib():
+	"""The loaded library (raises OSError if it has not been built: there is no CPU fallback)."""
+	global _lib
+	if _lib is not None:
+		return _lib
+	if not os.path.exists(LIB_PATH):
+		raise OSError("%s is missing: build it with `python -m panvc3_amd.build` (hipcc, gfx950)" % LIB_PATH)
+	# PyTorch-ROCm wheels bundle their own libamdhip64.so.  Loading torch first makes our library bind to that same
+	# runtime (same SONAME), so a process never ends up with two HIP runtimes.
+	try:
+		import torch  # noqa: F401
+	except ImportError:
+		pass
+	L = C.CDLL(LIB_PATH)
+	vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+	P = C.POINTER
+	sig = {
+		"pvc3_version": ([], i32),
+		"pvc3_strerror": ([i32], C.c_char_p),
+		"pvc3_last_error": ([], C.c_char_p),
+		"pvc3_device_count": ([P(i32)], i32),
+		"pvc3_index_create": ([P(vp)], i32),
+		"pvc3_index_destroy": ([vp], None),
+		"pvc3_index_add_aligned": ([vp, C.c_char_p, u64, P(u32)], i32),
+		"pvc3_index_add_bits": ([vp, vp, u64, P(u32)], i32),
+		"pvc3_index_set_reference": ([vp, u32, vp, u64], i32),
+		"pvc3_index_entry_count": ([vp, P(u32)], i32),
+		"pvc3_index_entry_info": ([vp, u32, P(u64), P(u64)], i32),
+		"pvc3_index_entry_layout": ([vp, u32, P(vp), P(u64), P(vp), P(u64)], i32),
+		"pvc3_context_create": ([i32, P(vp)], i32),
+		"pvc3_context_destroy": ([vp], None),
+		"pvc3_context_set_stream": ([vp, vp], i32),
+		"pvc3_context_set_timing": ([vp, i32], i32),
+		"pvc3_context_set_option": ([vp, C.c_char_p, C.c_int64], i32),
+		"pvc3_context_synchronize": ([vp], i32),
+		"pvc3_context_upload_index": ([vp, vp], i32),
+		"pvc3_context_hbm_bytes": ([vp, P(u64), P(u64)], i32),
+		"pvc3_batch_project": ([vp, P(BatchIn), P(BatchOut), P(Params), P(BatchStats)], i32),
+		"pvc3_dbatch_create": ([vp, P(BatchIn), P(vp)], i32),
+		"pvc3_dbatch_destroy": ([vp], None),
+		"pvc3_dbatch_project": ([vp, vp, P(Params)], i32),
+		"pvc3_dbatch_finish": ([vp, vp, P(BatchStats)], i32),
+		"pvc3_dbatch_download": ([vp, vp, P(BatchOut)], i32),
+		"pvc3_dbatch_checksum": ([vp, vp, u64, P(u64)], i32),
+		"pvc3_project_positions": ([vp, u64, vp, vp, vp, vp], i32),
+	}
+	for name, (argtypes, restype) in sig.items():
+		f = getattr(L, name)
+		f.argtypes = argtypes
+		f.restype = restype
+	L._pvc3_signatures = sig
+	_lib = L
+	return L
+
+
+def check(rc):
+	if rc != 0:
+		raise Error(rc, lib().pvc3_last_error().decode(errors="replace"))

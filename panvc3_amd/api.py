@@ -1,0 +1,312 @@
+"""Host-side Python mirror of the C ABI (include/pvc3.h) and of the reference's alignment_projector interface.
+
+`AlignmentProjector.project_alignment()` takes the arguments of panvc3::alignment_projector::project_alignment
+(include/panvc3/alignment_projector.hh:58-68) and exposes alignment(), realigned_reference_ranges() and
+realigned_query_ranges() (:70-74), so that parity tests read like tests/alignment_projector.cc.  Everything is computed by
+the HIP kernels; nothing here falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BatchIn, BatchOut, BatchStats, Params, check
+
+CIGAR_OPS = "MIDNSHP=X"
+SCORE_FP64 = 0
+SCORE_INT32_TRUNC = 1
+FLAG_HAS_QUAL = 1
+FLAG_HAS_MATE = 2
+NO_MATE = 0xFFFFFFFF
+RUN_DTYPE = np.dtype([("query_location", "<u4"), ("query_length", "<u4"), ("ref_position", "<u4"), ("ref_length", "<u4")])
+_SEQ4 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+
+
+def cigar_encode(text):
+	out, num = [], ""
+	for ch in text:
+		if ch.isdigit():
+			num += ch
+		else:
+			out.append((int(num) << 4) | CIGAR_OPS.index(ch))
+			num = ""
+	if num:
+		raise ValueError("trailing digits in CIGAR %r" % text)
+	return np.array(out, dtype=np.uint32)
+
+
+def cigar_decode(arr):
+	return "".join("%d%s" % (int(v) >> 4, CIGAR_OPS[int(v) & 0xf]) for v in arr)
+
+
+def seq4_encode(seq):
+	"""ASCII bases -> BAM 4-bit packing (high nibble first); unknown characters become N (15)."""
+	codes = np.fromiter((_SEQ4.get(c.upper(), 15) for c in seq), dtype=np.uint8, count=len(seq))
+	if codes.size & 1:
+		codes = np.append(codes, np.uint8(0))
+	return ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8)
+
+
+def device_count():
+	n = C.c_int()
+	check(_lib.lib().pvc3_device_count(C.byref(n)))
+	return n.value
+
+
+class Index:
+	"""The MSA gap bit-vector index (msa_index, include/panvc3/msa_index.hh): one entry per (chromosome, sequence)."""
+
+	def __init__(self):
+		self._L = _lib.lib()
+		self._h = C.c_void_p()
+		check(self._L.pvc3_index_create(C.byref(self._h)))
+
+	def __del__(self):
+		if getattr(self, "_h", None):
+			self._L.pvc3_index_destroy(self._h)
+			self._h = None
+
+	def add_aligned(self, aligned):
+		b = aligned.encode() if isinstance(aligned, str) else bytes(aligned)
+		e = C.c_uint32()
+		check(self._L.pvc3_index_add_aligned(self._h, b, len(b), C.byref(e)))
+		return e.value
+
+	def add_bits(self, words, n_cols):
+		words = np.ascontiguousarray(words, dtype=np.uint64)
+		if words.size < (n_cols + 63) // 64:
+			raise ValueError("too few words")
+		e = C.c_uint32()
+		check(self._L.pvc3_index_add_bits(self._h, words.ctypes.data, n_cols, C.byref(e)))
+		return e.value
+
+	def set_reference(self, entry, text):
+		if isinstance(text, str):
+			text = text.encode()
+		buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, dtype=np.uint8)
+		check(self._L.pvc3_index_set_reference(self._h, entry, buf.ctypes.data, buf.size))
+
+	def entry_count(self):
+		n = C.c_uint32()
+		check(self._L.pvc3_index_entry_count(self._h, C.byref(n)))
+		return n.value
+
+	def entry_info(self, entry):
+		a, b = C.c_uint64(), C.c_uint64()
+		check(self._L.pvc3_index_entry_info(self._h, entry, C.byref(a), C.byref(b)))
+		return a.value, b.value
+
+	def entry_layout(self, entry):
+		"""(blocks [n_blocks, 8] uint64, sel uint32): host copy of the HBM layout."""
+		bp, sp = C.c_void_p(), C.c_void_p()
+		nb, ns = C.c_uint64(), C.c_uint64()
+		check(self._L.pvc3_index_entry_layout(self._h, entry, C.byref(bp), C.byref(nb), C.byref(sp), C.byref(ns)))
+		blocks = np.ctypeslib.as_array(C.cast(bp, C.POINTER(C.c_uint64)), shape=(nb.value * 8,)).copy().reshape(nb.value, 8)
+		sel = np.ctypeslib.as_array(C.cast(sp, C.POINTER(C.c_uint32)), shape=(ns.value,)).copy()
+		return blocks, sel
+
+
+def make_sequence_entry_pair(index, lhs, rhs):
+	"""panvc3::make_sequence_entry_pair (msa_index.hh:214-236): two gapped strings -> (src entry, dst entry)."""
+	if len(lhs) != len(rhs):
+		raise ValueError("aligned sequences differ in length")
+	return index.add_aligned(lhs), index.add_aligned(rhs)
+
+
+_BATCH_FIELDS = [
+	("src_pos", np.uint32, False), ("src_entry", np.uint32, False), ("dst_entry", np.uint32, False), ("flags", np.uint32, False),
+	("cigar_off", np.uint64, False), ("cigar", np.uint32, False),
+	("seq_off", np.uint64, False), ("l_seq", np.uint32, False), ("seq4", np.uint8, False),
+	("qual_off", np.uint64, True), ("qual", np.uint8, True),
+	("mate_src_entry", np.uint32, True), ("mate_dst_entry", np.uint32, True), ("mate_pos", np.uint32, True),
+]
+
+
+def _pack_batch_in(batch):
+	bi = BatchIn()
+	keep = []
+	bi.n = int(np.asarray(batch["src_pos"]).size)
+	for name, dtype, optional in _BATCH_FIELDS:
+		a = batch.get(name)
+		if a is None:
+			if not optional:
+				raise KeyError(name)
+			setattr(bi, name, None)
+			continue
+		a = np.ascontiguousarray(a, dtype=dtype)
+		keep.append(a)
+		setattr(bi, name, a.ctypes.data if a.size else None)
+	# zero-length but required arrays still need a non-null offset array
+	for name in ("cigar_off", "seq_off"):
+		a = np.ascontiguousarray(batch[name], dtype=np.uint64)
+		keep.append(a)
+		setattr(bi, name, a.ctypes.data)
+	return bi, keep
+
+
+def _stats_dict(st):
+	return {k: getattr(st, k) for k, _ in BatchStats._fields_ if k != "reserved"}
+
+
+class Context:
+	"""One GPU: stream, index replica in HBM, workspaces."""
+
+	def __init__(self, device=0):
+		self._L = _lib.lib()
+		self._h = C.c_void_p()
+		check(self._L.pvc3_context_create(device, C.byref(self._h)))
+		self.device = device
+
+	def close(self):
+		if getattr(self, "_h", None):
+			self._L.pvc3_context_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		self.close()
+
+	def upload_index(self, index):
+		check(self._L.pvc3_context_upload_index(self._h, index._h))
+
+	def set_stream(self, hip_stream_ptr):
+		check(self._L.pvc3_context_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+	def set_timing(self, enabled=True):
+		check(self._L.pvc3_context_set_timing(self._h, int(enabled)))
+
+	def set_option(self, key, value):
+		check(self._L.pvc3_context_set_option(self._h, key.encode(), int(value)))
+
+	def synchronize(self):
+		check(self._L.pvc3_context_synchronize(self._h))
+
+	def hbm_bytes(self):
+		a, b = C.c_uint64(), C.c_uint64()
+		check(self._L.pvc3_context_hbm_bytes(self._h, C.byref(a), C.byref(b)))
+		return a.value, b.value
+
+	def project_positions(self, src_entry, dst_entry, pos):
+		"""Batched msa_index::sequence_entry::project_position (msa_index.hh:253-258)."""
+		pos = np.ascontiguousarray(pos, dtype=np.uint32)
+		src = np.ascontiguousarray(np.broadcast_to(np.asarray(src_entry, dtype=np.uint32), pos.shape))
+		dst = np.ascontiguousarray(np.broadcast_to(np.asarray(dst_entry, dtype=np.uint32), pos.shape))
+		out = np.zeros(pos.size, dtype=np.uint32)
+		check(self._L.pvc3_project_positions(self._h, pos.size, src.ctypes.data, dst.ctypes.data, pos.ctypes.data, out.ctypes.data))
+		return out
+
+
+class DeviceBatch:
+	"""A batch resident in HBM (pvc3_dbatch_*)."""
+
+	def __init__(self, ctx, batch):
+		self._L = _lib.lib()
+		self.ctx = ctx
+		self._h = C.c_void_p()
+		bi, keep = _pack_batch_in(batch)
+		check(self._L.pvc3_dbatch_create(ctx._h, C.byref(bi), C.byref(self._h)))
+		self.n = bi.n
+
+	def close(self):
+		if getattr(self, "_h", None):
+			self._L.pvc3_dbatch_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		self.close()
+
+	def project(self, params=None):
+		"""Enqueues the kernels on the context's stream (asynchronous)."""
+		p = params if isinstance(params, Params) else make_params(**(params or {}))
+		check(self._L.pvc3_dbatch_project(self.ctx._h, self._h, C.byref(p)))
+
+	def finish(self):
+		st = BatchStats()
+		check(self._L.pvc3_dbatch_finish(self.ctx._h, self._h, C.byref(st)))
+		self.stats = _stats_dict(st)
+		return self.stats
+
+	def download(self):
+		n = self.n
+		res = dict(
+			dst_pos=np.zeros(n, dtype=np.uint32), mate_dst_pos=np.zeros(n, dtype=np.uint32), status=np.zeros(n, dtype=np.int32),
+			out_cigar_off=np.zeros(n + 1, dtype=np.uint64), run_off=np.zeros(n + 1, dtype=np.uint64),
+		)
+		ccap = int(self.stats["out_cigar_total"])
+		rcap = int(self.stats["n_runs"])
+		res["out_cigar"] = np.zeros(max(1, ccap), dtype=np.uint32)
+		res["runs"] = np.zeros(max(1, rcap), dtype=RUN_DTYPE)
+		bo = BatchOut()
+		for k in ("dst_pos", "mate_dst_pos", "status", "out_cigar_off", "out_cigar", "run_off", "runs"):
+			setattr(bo, k, res[k].ctypes.data)
+		bo.out_cigar_cap = res["out_cigar"].size
+		bo.run_cap = res["runs"].size
+		check(self._L.pvc3_dbatch_download(self.ctx._h, self._h, C.byref(bo)))
+		res["out_cigar"] = res["out_cigar"][:ccap]
+		res["runs"] = res["runs"][:rcap]
+		return res
+
+	def checksum(self, first_record=0):
+		v = C.c_uint64()
+		check(self._L.pvc3_dbatch_checksum(self.ctx._h, self._h, first_record, C.byref(v)))
+		return v.value
+
+
+def make_params(gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, tiebreak_mode=0):
+	return Params(gap_open, gap_ext, score_mode, tiebreak_mode)
+
+
+def project_batch(ctx, batch, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64):
+	"""Host arrays in, host arrays out through pvc3_dbatch_* (upload, kernels, pack, download).  Returns (results, stats)."""
+	db = DeviceBatch(ctx, batch)
+	try:
+		db.project(make_params(gap_open, gap_ext, score_mode))
+		stats = db.finish()
+		return db.download(), stats
+	finally:
+		db.close()
+
+
+class AlignmentProjector:
+	"""Mirror of panvc3::alignment_projector (include/panvc3/alignment_projector.hh:32-75) over the GPU path.
+
+	The reference takes `msa_index::sequence_entry` objects; here entries are ids in an `Index` that has been uploaded to
+	the `Context`, and `ref_seq` is the text attached to the destination entry with Index.set_reference().
+	"""
+
+	def __init__(self, ctx):
+		self.ctx = ctx
+		self.reset()
+
+	def reset(self):
+		self._alignment = np.zeros(0, dtype=np.uint32)
+		self._ref_ranges = []
+		self._query_ranges = []
+
+	def project_alignment(self, src_pos, src_seq_entry, dst_seq_entry, query_seq, cigar_seq, base_qualities=None, gap_opening_cost=0, gap_extension_cost=-1, score_mode=SCORE_FP64):
+		"""Returns the projected position; raises ValueError if the record is rejected (the reference would assert)."""
+		cig = cigar_encode(cigar_seq) if isinstance(cigar_seq, str) else np.ascontiguousarray(cigar_seq, dtype=np.uint32)
+		seq4 = seq4_encode(query_seq)
+		batch = dict(
+			src_pos=[src_pos], src_entry=[src_seq_entry], dst_entry=[dst_seq_entry],
+			flags=[FLAG_HAS_QUAL if base_qualities is not None and len(base_qualities) else 0],
+			cigar_off=[0, cig.size], cigar=cig, seq_off=[0, seq4.size], l_seq=[len(query_seq)], seq4=seq4,
+		)
+		if base_qualities is not None and len(base_qualities):
+			batch["qual_off"] = [0, len(base_qualities)]
+			batch["qual"] = np.asarray(base_qualities, dtype=np.uint8)
+		res, _ = project_batch(self.ctx, batch, gap_opening_cost, gap_extension_cost, score_mode)
+		if res["status"][0]:
+			raise ValueError("record rejected, status %d" % res["status"][0])
+		self._alignment = res["out_cigar"]
+		self._ref_ranges = [(int(r["ref_position"]), int(r["ref_length"])) for r in res["runs"]]
+		self._query_ranges = [(int(r["query_location"]), int(r["query_length"])) for r in res["runs"]]
+		return int(res["dst_pos"][0])
+
+	def alignment(self):
+		return self._alignment
+
+	def realigned_reference_ranges(self):
+		return self._ref_ranges
+
+	def realigned_query_ranges(self):
+		return self._query_ranges

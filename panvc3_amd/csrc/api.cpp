@@ -1,0 +1,670 @@
+// api.cpp — the C ABI of include/pvc3.h over the HIP kernels.  No CPU fallback anywhere: every compute entry point
+// needs a pvc3_context, and pvc3_context_create() fails without a GPU.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "host_state.hpp"
+#include "pvc3_internal.hpp"
+
+using namespace pvc3;
+
+namespace pvc3 {
+
+static thread_local char g_error[768] = "";
+
+int set_error(int code, char const *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_error, sizeof(g_error), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+}
+
+#define HIP_TRY(expr) do { hipError_t const e_ = (expr); if (hipSuccess != e_) return set_error((hipErrorOutOfMemory == e_) ? PVC3_E_NOMEM : PVC3_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+#define PVC3_TRY(expr) do { int const rc_ = (expr); if (rc_) return rc_; } while (0)
+
+struct pvc3_context
+{
+	int device{};
+	hipStream_t own_stream{};
+	hipStream_t stream{};
+	bool timing{};
+	hipEvent_t ev[8]{};
+
+	// Index replica in HBM.
+	std::vector <void *> index_allocs;
+	dev_entry *d_entries{};
+	uint32_t n_entries{};
+	uint64_t index_bytes{};
+	uint64_t workspace_bytes{};
+
+	dev_params *d_params{};
+	pvc3_params params{0, 0, -1, 0};
+
+	// Options.
+	uint32_t realign_waves{2048};
+	uint32_t realign_lds_bytes{};
+	uint64_t scratch_per_wave{256 * 1024};
+	uint64_t arena_initial{};
+	uint64_t runs_initial{};
+	uint8_t *scratch{};
+	uint64_t scratch_alloc{};
+};
+
+struct pvc3_dbatch
+{
+	pvc3_context *ctx{};
+	uint64_t n{};
+	dev_batch_in in{};
+	dev_batch_work work{};
+	dev_batch_packed packed{};
+	uint64_t *scan_tmp{};
+	unsigned long long *d_checksum{};
+	std::vector <void *> allocs;		// everything except the growable arenas
+	uint64_t bytes{};
+	// host-side facts for the statistics
+	uint64_t sum_cigar{}, sum_seq_bytes{}, n_mates{};
+	bool projected{};
+	bool finished{};
+	pvc3_params params{};
+	uint32_t attempts{};
+	dev_counters counters{};
+};
+
+namespace {
+
+int check_device(pvc3_context *ctx)
+{
+	HIP_TRY(hipSetDevice(ctx->device));
+	return PVC3_OK;
+}
+
+template <typename t_value>
+int dev_alloc(t_value **dst, uint64_t count, std::vector <void *> *track, uint64_t *bytes_acc)
+{
+	void *p{};
+	uint64_t const bytes = (count ? count : 1) * sizeof(t_value);
+	HIP_TRY(hipMalloc(&p, bytes));
+	*dst = (t_value *) p;
+	if (track) track->push_back(p);
+	if (bytes_acc) *bytes_acc += bytes;
+	return PVC3_OK;
+}
+
+template <typename t_value>
+int dev_upload(t_value const **dst, t_value const *src, uint64_t count, uint64_t pad_bytes, hipStream_t stream, std::vector <void *> *track, uint64_t *bytes_acc)
+{
+	uint8_t *p{};
+	PVC3_TRY(dev_alloc(&p, count * sizeof(t_value) + pad_bytes, track, bytes_acc));
+	if (count)
+		HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(t_value), hipMemcpyHostToDevice, stream));
+	if (pad_bytes)
+		HIP_TRY(hipMemsetAsync(p + count * sizeof(t_value), 0, pad_bytes, stream));
+	*dst = (t_value const *) p;
+	return PVC3_OK;
+}
+
+// align.hh:28-37, evaluation order as written; reference base quality fixed at 41 (alignment_projector.cc:108).
+double malde_score(bool matches, int lhs_phred, int rhs_phred)
+{
+	double const lhs_e = 1.0 / std::pow(10.0, lhs_phred / 10.0);
+	double const rhs_e = 1.0 / std::pow(10.0, rhs_phred / 10.0);
+	double const combined_e = lhs_e + rhs_e - lhs_e / 3.0 * rhs_e * 4.0;
+	if (matches)
+		return 2.0 + std::log2(1.0 - combined_e);
+	else
+		return 2.0 - std::log2(3.0) + std::log2(combined_e);
+}
+
+int upload_params(pvc3_context *ctx, pvc3_params const &p)
+{
+	if (ctx->d_params && 0 == std::memcmp(&p, &ctx->params, sizeof(p)))
+		return PVC3_OK;
+	if (p.score_mode != PVC3_SCORE_FP64 && p.score_mode != PVC3_SCORE_INT32_TRUNC)
+		return set_error(PVC3_E_INVALID, "pvc3_params.score_mode %d is not a PVC3_SCORE_* value", p.score_mode);
+	if (0 != p.tiebreak_mode)
+		return set_error(PVC3_E_INVALID, "pvc3_params.tiebreak_mode %d: only 0 (restated seqan3 order) is defined", p.tiebreak_mode);
+	dev_params hp{};
+	hp.gap_open = p.gap_open; hp.gap_ext = p.gap_ext; hp.score_mode = p.score_mode;
+	for (int q = 0; q <= 41; ++q)
+	{
+		hp.s_match[q] = malde_score(true, 41, q);
+		hp.s_mismatch[q] = malde_score(false, 41, q);
+		if (PVC3_SCORE_INT32_TRUNC == p.score_mode)
+		{
+			hp.s_match[q] = (double) (int32_t) hp.s_match[q];
+			hp.s_mismatch[q] = (double) (int32_t) hp.s_mismatch[q];
+		}
+	}
+	if (!ctx->d_params)
+		PVC3_TRY(dev_alloc(&ctx->d_params, 1, nullptr, &ctx->workspace_bytes));
+	// Stream-ordered so that an in-flight projection with the previous parameters is not disturbed.
+	HIP_TRY(hipMemcpyAsync(ctx->d_params, &hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	ctx->params = p;
+	return PVC3_OK;
+}
+
+void free_index_replica(pvc3_context *ctx)
+{
+	for (void *p : ctx->index_allocs) (void) hipFree(p);
+	ctx->index_allocs.clear();
+	ctx->d_entries = nullptr;
+	ctx->n_entries = 0;
+	ctx->index_bytes = 0;
+}
+
+int ensure_scratch(pvc3_context *ctx)
+{
+	uint64_t const need = ctx->scratch_per_wave * ctx->realign_waves;
+	if (ctx->scratch && ctx->scratch_alloc >= need)
+		return PVC3_OK;
+	if (ctx->scratch) { (void) hipFree(ctx->scratch); ctx->workspace_bytes -= ctx->scratch_alloc; ctx->scratch = nullptr; }
+	PVC3_TRY(dev_alloc(&ctx->scratch, need, nullptr, &ctx->workspace_bytes));
+	ctx->scratch_alloc = need;
+	return PVC3_OK;
+}
+
+int alloc_arenas(pvc3_dbatch *b, uint64_t arena_cap, uint64_t runs_cap)
+{
+	pvc3_context *ctx = b->ctx;
+	if (b->work.arena) { (void) hipFree(b->work.arena); (void) hipFree(b->packed.out_cigar); b->bytes -= 8 * b->work.arena_cap; }
+	if (b->work.runs_arena) { (void) hipFree(b->work.runs_arena); (void) hipFree(b->packed.runs); b->bytes -= 2 * sizeof(pvc3_run) * b->work.runs_cap; }
+	b->work.arena = nullptr; b->packed.out_cigar = nullptr; b->work.runs_arena = nullptr; b->packed.runs = nullptr;
+	PVC3_TRY(dev_alloc(&b->work.arena, arena_cap, nullptr, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->packed.out_cigar, arena_cap, nullptr, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->work.runs_arena, runs_cap, nullptr, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->packed.runs, runs_cap, nullptr, &b->bytes));
+	b->work.arena_cap = arena_cap; b->packed.out_cigar_cap = arena_cap;
+	b->work.runs_cap = runs_cap; b->packed.run_cap = runs_cap;
+	(void) ctx;
+	return PVC3_OK;
+}
+
+int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
+{
+	hipStream_t const s = ctx->stream;
+	b->work.scratch = ctx->scratch;
+	b->work.scratch_per_wave = ctx->scratch_per_wave;
+	HIP_TRY(hipMemsetAsync(b->work.counters, 0, sizeof(dev_counters), s));
+	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
+	if (int const e = launch_project(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_project launch: %s", hipGetErrorString((hipError_t) e));
+	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
+	if (int const e = launch_mates(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_mates launch: %s", hipGetErrorString((hipError_t) e));
+	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
+	uint32_t const lds = ctx->realign_lds_bytes ? ctx->realign_lds_bytes : realign_lds_bytes();
+	if (int const e = launch_realign(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->d_params, ctx->realign_waves, lds, s)) return set_error(PVC3_E_HIP, "k_realign launch: %s", hipGetErrorString((hipError_t) e));
+	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[3], s));
+	if (int const e = launch_pack(b->n, b->work, b->packed, b->scan_tmp, s)) return set_error(PVC3_E_HIP, "pack launch: %s", hipGetErrorString((hipError_t) e));
+	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[4], s));
+	return PVC3_OK;
+}
+
+}	// anonymous namespace
+
+
+extern "C" {
+
+int pvc3_version(void) { return PVC3_VERSION; }
+
+char const *pvc3_strerror(int code)
+{
+	switch (code)
+	{
+		case PVC3_OK: return "ok";
+		case PVC3_E_INVALID: return "invalid argument";
+		case PVC3_E_NOMEM: return "out of memory";
+		case PVC3_E_HIP: return "HIP runtime error";
+		case PVC3_E_NO_DEVICE: return "no usable GPU";
+		case PVC3_E_CAPACITY: return "output buffer too small";
+		case PVC3_E_STATE: return "invalid call sequence";
+		default: return "unknown error";
+	}
+}
+
+char const *pvc3_last_error(void) { return g_error; }
+
+int pvc3_device_count(int *count)
+{
+	if (!count) return set_error(PVC3_E_INVALID, "pvc3_device_count: null argument");
+	int n = 0;
+	hipError_t const e = hipGetDeviceCount(&n);
+	if (hipSuccess != e) { (void) hipGetLastError(); n = 0; }
+	*count = n;
+	return PVC3_OK;
+}
+
+// ---- index -------------------------------------------------------------------------------------------------------
+int pvc3_index_create(pvc3_index **idx)
+{
+	if (!idx) return set_error(PVC3_E_INVALID, "pvc3_index_create: null argument");
+	*idx = new (std::nothrow) pvc3_index;
+	return *idx ? PVC3_OK : set_error(PVC3_E_NOMEM, "pvc3_index_create: out of memory");
+}
+
+void pvc3_index_destroy(pvc3_index *idx) { delete idx; }
+
+int pvc3_index_add_aligned(pvc3_index *idx, char const *aligned, uint64_t n_cols, uint32_t *entry)
+{
+	if (!idx || (!aligned && n_cols) || !entry) return set_error(PVC3_E_INVALID, "pvc3_index_add_aligned: null argument");
+	try { return index_add_aligned(idx, aligned, n_cols, entry); }
+	catch (std::bad_alloc const &) { return set_error(PVC3_E_NOMEM, "pvc3_index_add_aligned: out of memory"); }
+}
+
+int pvc3_index_add_bits(pvc3_index *idx, uint64_t const *gap_words, uint64_t n_cols, uint32_t *entry)
+{
+	if (!idx || (!gap_words && n_cols) || !entry) return set_error(PVC3_E_INVALID, "pvc3_index_add_bits: null argument");
+	try { return index_add_bits(idx, gap_words, n_cols, entry); }
+	catch (std::bad_alloc const &) { return set_error(PVC3_E_NOMEM, "pvc3_index_add_bits: out of memory"); }
+}
+
+int pvc3_index_set_reference(pvc3_index *idx, uint32_t entry, char const *text, uint64_t len)
+{
+	if (!idx || (!text && len)) return set_error(PVC3_E_INVALID, "pvc3_index_set_reference: null argument");
+	try { return index_set_reference(idx, entry, text, len); }
+	catch (std::bad_alloc const &) { return set_error(PVC3_E_NOMEM, "pvc3_index_set_reference: out of memory"); }
+}
+
+int pvc3_index_entry_count(pvc3_index const *idx, uint32_t *count)
+{
+	if (!idx || !count) return set_error(PVC3_E_INVALID, "pvc3_index_entry_count: null argument");
+	*count = (uint32_t) idx->entries.size();
+	return PVC3_OK;
+}
+
+int pvc3_index_entry_info(pvc3_index const *idx, uint32_t entry, uint64_t *n_cols, uint64_t *n_non_gap)
+{
+	if (!idx || entry >= idx->entries.size()) return set_error(PVC3_E_INVALID, "pvc3_index_entry_info: no entry %u", entry);
+	if (n_cols) *n_cols = idx->entries[entry].n_cols;
+	if (n_non_gap) *n_non_gap = idx->entries[entry].n_zeros;
+	return PVC3_OK;
+}
+
+int pvc3_index_entry_layout(pvc3_index const *idx, uint32_t entry, uint64_t const **blocks, uint64_t *n_blocks, uint32_t const **sel, uint64_t *n_sel)
+{
+	if (!idx || entry >= idx->entries.size()) return set_error(PVC3_E_INVALID, "pvc3_index_entry_layout: no entry %u", entry);
+	host_entry const &e = idx->entries[entry];
+	if (blocks) *blocks = e.blocks.data();
+	if (n_blocks) *n_blocks = e.n_blocks + PAD_BLOCKS;
+	if (sel) *sel = e.sel.data();
+	if (n_sel) *n_sel = e.sel.size();
+	return PVC3_OK;
+}
+
+// ---- context -------------------------------------------------------------------------------------------------------
+int pvc3_context_create(int device, pvc3_context **out)
+{
+	if (!out) return set_error(PVC3_E_INVALID, "pvc3_context_create: null argument");
+	*out = nullptr;
+	int n = 0;
+	if (hipSuccess != hipGetDeviceCount(&n) || n <= 0)
+	{
+		(void) hipGetLastError();
+		return set_error(PVC3_E_NO_DEVICE, "pvc3_context_create: no HIP device is visible; this library has no CPU path");
+	}
+	if (device < 0 || device >= n)
+		return set_error(PVC3_E_NO_DEVICE, "pvc3_context_create: device %d out of range (%d visible)", device, n);
+	HIP_TRY(hipSetDevice(device));
+	pvc3_context *ctx = new (std::nothrow) pvc3_context;
+	if (!ctx) return set_error(PVC3_E_NOMEM, "pvc3_context_create: out of memory");
+	ctx->device = device;
+	hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+	if (hipSuccess != e) { delete ctx; return set_error(PVC3_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+	ctx->stream = ctx->own_stream;
+	for (auto &ev : ctx->ev)
+	{
+		e = hipEventCreate(&ev);
+		if (hipSuccess != e) { delete ctx; return set_error(PVC3_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+	}
+	*out = ctx;
+	return PVC3_OK;
+}
+
+void pvc3_context_destroy(pvc3_context *ctx)
+{
+	if (!ctx) return;
+	(void) hipSetDevice(ctx->device);
+	(void) hipStreamSynchronize(ctx->stream);
+	free_index_replica(ctx);
+	if (ctx->d_params) (void) hipFree(ctx->d_params);
+	if (ctx->scratch) (void) hipFree(ctx->scratch);
+	for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
+	if (ctx->own_stream) (void) hipStreamDestroy(ctx->own_stream);
+	delete ctx;
+}
+
+int pvc3_context_set_stream(pvc3_context *ctx, void *hip_stream)
+{
+	if (!ctx) return set_error(PVC3_E_INVALID, "pvc3_context_set_stream: null context");
+	PVC3_TRY(check_device(ctx));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	ctx->stream = hip_stream ? (hipStream_t) hip_stream : ctx->own_stream;
+	return PVC3_OK;
+}
+
+int pvc3_context_set_timing(pvc3_context *ctx, int enabled)
+{
+	if (!ctx) return set_error(PVC3_E_INVALID, "pvc3_context_set_timing: null context");
+	ctx->timing = (0 != enabled);
+	return PVC3_OK;
+}
+
+int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value)
+{
+	if (!ctx || !key) return set_error(PVC3_E_INVALID, "pvc3_context_set_option: null argument");
+	std::string const k(key);
+	if (value < 0) return set_error(PVC3_E_INVALID, "pvc3_context_set_option: negative value for %s", key);
+	if ("realign_waves" == k) { if (value < 1 || value > 65536) return set_error(PVC3_E_INVALID, "realign_waves out of range"); ctx->realign_waves = (uint32_t) value; }
+	else if ("realign_lds_bytes" == k) ctx->realign_lds_bytes = (uint32_t) value;
+	else if ("scratch_per_wave" == k) ctx->scratch_per_wave = (uint64_t) value;
+	else if ("arena_initial" == k) ctx->arena_initial = (uint64_t) value;
+	else if ("runs_initial" == k) ctx->runs_initial = (uint64_t) value;
+	else return set_error(PVC3_E_INVALID, "pvc3_context_set_option: unknown option %s", key);
+	return PVC3_OK;
+}
+
+int pvc3_context_synchronize(pvc3_context *ctx)
+{
+	if (!ctx) return set_error(PVC3_E_INVALID, "pvc3_context_synchronize: null context");
+	PVC3_TRY(check_device(ctx));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PVC3_OK;
+}
+
+int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
+{
+	if (!ctx || !idx) return set_error(PVC3_E_INVALID, "pvc3_context_upload_index: null argument");
+	PVC3_TRY(check_device(ctx));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	free_index_replica(ctx);
+	std::vector <dev_entry> table(idx->entries.size());
+	for (size_t i = 0; i < idx->entries.size(); ++i)
+	{
+		host_entry const &e = idx->entries[i];
+		dev_entry &d = table[i];
+		PVC3_TRY(dev_upload(&d.blocks, e.blocks.data(), e.blocks.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
+		PVC3_TRY(dev_upload(&d.sel, e.sel.data(), e.sel.size(), 64, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
+		d.text = nullptr;
+		if (!e.text.empty())
+			PVC3_TRY(dev_upload(&d.text, (uint8_t const *) e.text.data(), e.text.size(), TEXT_PAD, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
+		d.n_cols = (uint32_t) e.n_cols;
+		d.n_zeros = (uint32_t) e.n_zeros;
+		d.text_len = (uint32_t) e.text.size();
+		d.n_blocks = (uint32_t) e.n_blocks;
+	}
+	dev_entry const *d_table{};
+	PVC3_TRY(dev_upload(&d_table, table.data(), table.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	ctx->d_entries = const_cast <dev_entry *>(d_table);
+	ctx->n_entries = (uint32_t) table.size();
+	return PVC3_OK;
+}
+
+int pvc3_context_hbm_bytes(pvc3_context const *ctx, uint64_t *index_bytes, uint64_t *workspace_bytes)
+{
+	if (!ctx) return set_error(PVC3_E_INVALID, "pvc3_context_hbm_bytes: null context");
+	if (index_bytes) *index_bytes = ctx->index_bytes;
+	if (workspace_bytes) *workspace_bytes = ctx->workspace_bytes;
+	return PVC3_OK;
+}
+
+// ---- device batches ------------------------------------------------------------------------------------------------
+void pvc3_dbatch_destroy(pvc3_dbatch *b)
+{
+	if (!b) return;
+	(void) hipSetDevice(b->ctx->device);
+	(void) hipStreamSynchronize(b->ctx->stream);
+	for (void *p : b->allocs) (void) hipFree(p);
+	if (b->work.arena) (void) hipFree(b->work.arena);
+	if (b->packed.out_cigar) (void) hipFree(b->packed.out_cigar);
+	if (b->work.runs_arena) (void) hipFree(b->work.runs_arena);
+	if (b->packed.runs) (void) hipFree(b->packed.runs);
+	delete b;
+}
+
+int pvc3_dbatch_create(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_dbatch **out)
+{
+	if (!ctx || !in || !out) return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: null argument");
+	*out = nullptr;
+	uint64_t const n = in->n;
+	if (n && (!in->src_pos || !in->src_entry || !in->dst_entry || !in->flags || !in->cigar_off || !in->seq_off || !in->l_seq))
+		return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: a required input array is null");
+	if (n >= (UINT64_C(1) << 32))
+		return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: at most 2^32 - 1 records per batch");
+	PVC3_TRY(check_device(ctx));
+	if (!ctx->d_entries) return set_error(PVC3_E_STATE, "pvc3_dbatch_create: no index has been uploaded to this context");
+
+	pvc3_dbatch *b = new (std::nothrow) pvc3_dbatch;
+	if (!b) return set_error(PVC3_E_NOMEM, "pvc3_dbatch_create: out of memory");
+	b->ctx = ctx; b->n = n;
+	struct guard { pvc3_dbatch *p; ~guard() { if (p) pvc3_dbatch_destroy(p); } } g{b};
+
+	static uint64_t const zero_off[1] = {0};
+	uint64_t const n_cigar = n ? in->cigar_off[n] : 0;
+	uint64_t const n_seq = n ? in->seq_off[n] : 0;
+	bool const has_qual = n && in->qual_off && in->qual;
+	uint64_t const n_qual = has_qual ? in->qual_off[n] : 0;
+	bool const has_mates = n && in->mate_src_entry && in->mate_dst_entry && in->mate_pos;
+	if (n_cigar && !in->cigar) return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: cigar is null");
+	if (n_seq && !in->seq4) return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: seq4 is null");
+
+	hipStream_t const s = ctx->stream;
+	dev_batch_in &d = b->in;
+	d.n = n;
+	PVC3_TRY(dev_upload(&d.src_pos, in->src_pos, n, 0, s, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_upload(&d.src_entry, in->src_entry, n, 0, s, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_upload(&d.dst_entry, in->dst_entry, n, 0, s, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_upload(&d.flags, in->flags, n, 0, s, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_upload(&d.cigar_off, n ? in->cigar_off : zero_off, n + 1, 0, s, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_upload(&d.cigar, in->cigar, n_cigar, 256, s, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_upload(&d.seq_off, n ? in->seq_off : zero_off, n + 1, 0, s, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_upload(&d.l_seq, in->l_seq, n, 0, s, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_upload(&d.seq4, in->seq4, n_seq, 256, s, &b->allocs, &b->bytes));		// padded: whole-dword reads
+	if (has_qual)
+	{
+		PVC3_TRY(dev_upload(&d.qual_off, in->qual_off, n + 1, 0, s, &b->allocs, &b->bytes));
+		PVC3_TRY(dev_upload(&d.qual, in->qual, n_qual, 16, s, &b->allocs, &b->bytes));
+	}
+	if (has_mates)
+	{
+		PVC3_TRY(dev_upload(&d.mate_src_entry, in->mate_src_entry, n, 0, s, &b->allocs, &b->bytes));
+		PVC3_TRY(dev_upload(&d.mate_dst_entry, in->mate_dst_entry, n, 0, s, &b->allocs, &b->bytes));
+		PVC3_TRY(dev_upload(&d.mate_pos, in->mate_pos, n, 0, s, &b->allocs, &b->bytes));
+	}
+
+	dev_batch_work &w = b->work;
+	PVC3_TRY(dev_alloc(&w.dst_pos, n, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.mate_dst_pos, n, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.rec_flags, n, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.cig_loc, n, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.cig_n, n, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.run_loc, n, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.run_n, n, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.counters, 1, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->packed.out_cigar_off, n + 1, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->packed.run_off, n + 1, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->packed.status, n, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->scan_tmp, pack_scan_tmp_words(n), &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->d_checksum, 1, &b->allocs, &b->bytes));
+
+	// Arena sizing: twice the input operations + 8 per record + the chunk slack of every wave that may allocate.
+	uint64_t const realign_waves = (ctx->realign_waves < (n + 63) / 64) ? ctx->realign_waves : (n + 63) / 64;
+	uint64_t const chunk_slack = ((uint64_t) project_wave_count(n) + realign_waves) * 2048 * 2;
+	uint64_t arena_cap = ctx->arena_initial ? ctx->arena_initial : (2 * n_cigar + 8 * n + chunk_slack + 4096);
+	uint64_t runs_cap = ctx->runs_initial ? ctx->runs_initial : (n / 16 + realign_waves * 128 * 2 + 1024);
+	PVC3_TRY(alloc_arenas(b, arena_cap, runs_cap));
+
+	b->sum_cigar = n_cigar;
+	b->sum_seq_bytes = n_seq;
+	for (uint64_t i = 0; has_mates && i < n; ++i)
+		b->n_mates += (0 != (in->flags[i] & PVC3_FLAG_HAS_MATE));
+
+	HIP_TRY(hipStreamSynchronize(s));
+	g.p = nullptr;
+	*out = b;
+	return PVC3_OK;
+}
+
+int pvc3_dbatch_project(pvc3_context *ctx, pvc3_dbatch *b, pvc3_params const *params)
+{
+	if (!ctx || !b || !params) return set_error(PVC3_E_INVALID, "pvc3_dbatch_project: null argument");
+	if (b->ctx != ctx) return set_error(PVC3_E_INVALID, "pvc3_dbatch_project: the batch belongs to another context");
+	PVC3_TRY(check_device(ctx));
+	if (!ctx->d_entries) return set_error(PVC3_E_STATE, "pvc3_dbatch_project: no index has been uploaded to this context");
+	PVC3_TRY(upload_params(ctx, *params));
+	PVC3_TRY(ensure_scratch(ctx));
+	b->params = *params;
+	b->attempts = 1;
+	b->finished = false;
+	PVC3_TRY(enqueue_projection(ctx, b));
+	b->projected = true;
+	return PVC3_OK;
+}
+
+int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stats)
+{
+	if (!ctx || !b) return set_error(PVC3_E_INVALID, "pvc3_dbatch_finish: null argument");
+	if (!b->projected) return set_error(PVC3_E_STATE, "pvc3_dbatch_finish: pvc3_dbatch_project has not been called");
+	PVC3_TRY(check_device(ctx));
+	for (;;)
+	{
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		HIP_TRY(hipMemcpy(&b->counters, b->work.counters, sizeof(dev_counters), hipMemcpyDeviceToHost));
+		dev_counters const &c = b->counters;
+		if (!c.arena_overflow && !c.runs_overflow && !c.scratch_overflow)
+			break;
+		if (b->attempts >= 8)
+			return set_error(PVC3_E_NOMEM, "pvc3_dbatch_finish: workspaces still too small after %u attempts", b->attempts);
+		// Grow whatever overflowed and repeat the whole batch on the GPU.
+		if (c.scratch_overflow)
+		{
+			ctx->scratch_per_wave = ((uint64_t) c.scratch_needed + 4095) / 4096 * 4096;
+			if (0xFFFFFFFFu == c.scratch_needed)
+				return set_error(PVC3_E_NOMEM, "pvc3_dbatch_finish: an indel run needs more than 4 GiB of alignment scratch");
+			PVC3_TRY(ensure_scratch(ctx));
+		}
+		if (c.arena_overflow || c.runs_overflow)
+		{
+			uint64_t const arena_cap = c.arena_overflow ? (2 * (uint64_t) c.arena_head + 4096) : b->work.arena_cap;
+			uint64_t const runs_cap = c.runs_overflow ? (2 * (uint64_t) c.runs_head + 1024) : b->work.runs_cap;
+			PVC3_TRY(alloc_arenas(b, arena_cap, runs_cap));
+		}
+		++b->attempts;
+		PVC3_TRY(enqueue_projection(ctx, b));
+	}
+	b->finished = true;
+	if (stats)
+	{
+		dev_counters const &c = b->counters;
+		std::memset(stats, 0, sizeof(*stats));
+		uint64_t totals[2] = {0, 0};
+		HIP_TRY(hipMemcpy(&totals[0], b->packed.out_cigar_off + b->n, sizeof(uint64_t), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(&totals[1], b->packed.run_off + b->n, sizeof(uint64_t), hipMemcpyDeviceToHost));
+		stats->n_records = b->n;
+		stats->n_failed = c.n_failed;
+		stats->n_realigned_records = c.n_realigned_records;
+		stats->n_runs = totals[1];
+		stats->out_cigar_total = totals[0];
+		// Algorithmic bytes (DESIGN.md "Algorithmic bytes per alignment"): what one pass must read and write at minimum.
+		uint64_t const n = b->n;
+		stats->algorithmic_bytes =
+			n * (4 + 4 + 4 + 4 + 8 + 8 + 4)			// src_pos, src_entry, dst_entry, flags, cigar_off, seq_off, l_seq
+			+ 4 * b->sum_cigar + b->sum_seq_bytes		// input CIGAR, packed SEQ
+			+ n * (4 + 8)								// one select sample, one dst rank word
+			+ c.bitvec_bytes + c.ref_bytes				// src + dst gap-bit windows, dst text window
+			+ b->n_mates * (12 + 4 + 64 + 64)			// mate fields, select sample, one src and one dst block
+			+ c.qual_bytes								// QUAL of realigned records only
+			+ n * (4 + 4 + 4 + 8 + 8)					// dst_pos, mate_dst_pos, status, out_cigar_off, run_off
+			+ 4 * totals[0] + sizeof(pvc3_run) * totals[1];
+		if (ctx->timing)
+		{
+			(void) hipEventElapsedTime(&stats->ms_project, ctx->ev[0], ctx->ev[1]);
+			(void) hipEventElapsedTime(&stats->ms_mate, ctx->ev[1], ctx->ev[2]);
+			(void) hipEventElapsedTime(&stats->ms_realign, ctx->ev[2], ctx->ev[3]);
+			(void) hipEventElapsedTime(&stats->ms_pack, ctx->ev[3], ctx->ev[4]);
+		}
+		stats->attempts = b->attempts;
+	}
+	return PVC3_OK;
+}
+
+int pvc3_dbatch_download(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_out *out)
+{
+	if (!ctx || !b || !out) return set_error(PVC3_E_INVALID, "pvc3_dbatch_download: null argument");
+	if (!b->finished) return set_error(PVC3_E_STATE, "pvc3_dbatch_download: pvc3_dbatch_finish has not succeeded");
+	PVC3_TRY(check_device(ctx));
+	uint64_t const n = b->n;
+	if (!out->out_cigar_off || !out->run_off || (n && (!out->dst_pos || !out->mate_dst_pos || !out->status)))
+		return set_error(PVC3_E_INVALID, "pvc3_dbatch_download: a required output array is null");
+	HIP_TRY(hipMemcpy(out->out_cigar_off, b->packed.out_cigar_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(out->run_off, b->packed.run_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	uint64_t const n_cig = out->out_cigar_off[n], n_runs = out->run_off[n];
+	if (n_cig > out->out_cigar_cap || n_runs > out->run_cap)
+		return set_error(PVC3_E_CAPACITY, "pvc3_dbatch_download: need room for %llu CIGAR operations and %llu runs", (unsigned long long) n_cig, (unsigned long long) n_runs);
+	if (n)
+	{
+		HIP_TRY(hipMemcpy(out->dst_pos, b->work.dst_pos, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(out->mate_dst_pos, b->work.mate_dst_pos, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(out->status, b->packed.status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+	}
+	if (n_cig) HIP_TRY(hipMemcpy(out->out_cigar, b->packed.out_cigar, n_cig * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	if (n_runs) HIP_TRY(hipMemcpy(out->runs, b->packed.runs, n_runs * sizeof(pvc3_run), hipMemcpyDeviceToHost));
+	return PVC3_OK;
+}
+
+int pvc3_dbatch_checksum(pvc3_context *ctx, pvc3_dbatch *b, uint64_t first_record, uint64_t *checksum)
+{
+	if (!ctx || !b || !checksum) return set_error(PVC3_E_INVALID, "pvc3_dbatch_checksum: null argument");
+	if (!b->finished) return set_error(PVC3_E_STATE, "pvc3_dbatch_checksum: pvc3_dbatch_finish has not succeeded");
+	PVC3_TRY(check_device(ctx));
+	if (int const e = launch_checksum(b->n, first_record, b->work, b->packed, b->d_checksum, ctx->stream)) return set_error(PVC3_E_HIP, "k_checksum launch: %s", hipGetErrorString((hipError_t) e));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	unsigned long long v = 0;
+	HIP_TRY(hipMemcpy(&v, b->d_checksum, sizeof(v), hipMemcpyDeviceToHost));
+	*checksum = v;
+	return PVC3_OK;
+}
+
+int pvc3_batch_project(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_batch_out *out, pvc3_params const *params, pvc3_batch_stats *stats)
+{
+	if (!ctx || !in || !out || !params) return set_error(PVC3_E_INVALID, "pvc3_batch_project: null argument");
+	pvc3_dbatch *b{};
+	PVC3_TRY(pvc3_dbatch_create(ctx, in, &b));
+	int rc = pvc3_dbatch_project(ctx, b, params);
+	if (!rc) rc = pvc3_dbatch_finish(ctx, b, stats);
+	if (!rc) rc = pvc3_dbatch_download(ctx, b, out);
+	pvc3_dbatch_destroy(b);
+	return rc;
+}
+
+int pvc3_project_positions(pvc3_context *ctx, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out)
+{
+	if (!ctx || (n && (!src_entry || !dst_entry || !pos || !out))) return set_error(PVC3_E_INVALID, "pvc3_project_positions: null argument");
+	PVC3_TRY(check_device(ctx));
+	if (!ctx->d_entries) return set_error(PVC3_E_STATE, "pvc3_project_positions: no index has been uploaded to this context");
+	if (0 == n) return PVC3_OK;
+	std::vector <void *> allocs;
+	struct guard { std::vector <void *> &a; ~guard() { for (void *p : a) (void) hipFree(p); } } g{allocs};
+	uint32_t const *d_src{}, *d_dst{}, *d_pos{};
+	uint32_t *d_out{};
+	PVC3_TRY(dev_upload(&d_src, src_entry, n, 0, ctx->stream, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d_dst, dst_entry, n, 0, ctx->stream, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d_pos, pos, n, 0, ctx->stream, &allocs, nullptr));
+	PVC3_TRY(dev_alloc(&d_out, n, &allocs, nullptr));
+	if (int const e = launch_project_positions(ctx->d_entries, ctx->n_entries, n, d_src, d_dst, d_pos, d_out, ctx->stream)) return set_error(PVC3_E_HIP, "k_project_positions launch: %s", hipGetErrorString((hipError_t) e));
+	HIP_TRY(hipMemcpyAsync(out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PVC3_OK;
+}
+
+}	// extern "C"

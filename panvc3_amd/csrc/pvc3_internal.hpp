@@ -1,0 +1,138 @@
+// pvc3_internal.hpp — layouts shared by the host side and the HIP kernels (not part of the ABI).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pvc3.h"
+
+namespace pvc3 {
+
+// ---- HBM layout of one gap bit-vector ---------------------------------------------------------------------------
+// A sequence entry (msa_index::sequence_entry, include/panvc3/msa_index.hh:47-74) is stored as 64-byte blocks:
+//   word 0      number of non-gap columns ("zeros") before the block  -> rank0 in one cache line
+//   words 1..7  448 gap bits (1 = gap), bit (c & 63) of word 1 + ((c % 448) >> 6)
+// plus one select sample per 64 zeros (the column of zero number 64 j).  Two all-gap padding blocks follow the
+// last real block so that a two-block window load never leaves the allocation.
+constexpr uint32_t BLOCK_WORDS = 8;
+constexpr uint32_t BLOCK_DATA_WORDS = 7;
+constexpr uint32_t BLOCK_COLS = 448;
+constexpr uint32_t PAD_BLOCKS = 2;
+constexpr uint32_t SELECT_SAMPLE = 64;
+constexpr uint32_t SELECT_SAMPLE_SHIFT = 6;
+constexpr uint32_t TEXT_PAD = 512;		// bytes readable past the end of a device text
+
+struct host_entry
+{
+	uint64_t n_cols{};
+	uint64_t n_zeros{};
+	uint64_t n_blocks{};				// without padding
+	std::vector <uint64_t> blocks;		// (n_blocks + PAD_BLOCKS) * 8
+	std::vector <uint32_t> sel;			// ceil(n_zeros / 64) + 1
+	std::vector <char> text;			// unaligned text, may be empty
+};
+
+struct dev_entry
+{
+	uint64_t const *blocks;
+	uint32_t const *sel;
+	uint8_t const *text;
+	uint32_t n_cols;
+	uint32_t n_zeros;
+	uint32_t text_len;
+	uint32_t n_blocks;
+};
+
+// ---- device batch ------------------------------------------------------------------------------------------------
+struct dev_batch_in
+{
+	uint64_t n;
+	uint32_t const *src_pos;
+	uint32_t const *src_entry;
+	uint32_t const *dst_entry;
+	uint32_t const *flags;
+	uint64_t const *cigar_off;
+	uint32_t const *cigar;
+	uint64_t const *seq_off;
+	uint32_t const *l_seq;
+	uint8_t const *seq4;
+	uint64_t const *qual_off;
+	uint8_t const *qual;
+	uint32_t const *mate_src_entry;
+	uint32_t const *mate_dst_entry;
+	uint32_t const *mate_pos;
+};
+
+// Global counters of one projection attempt (zeroed before every launch sequence).
+struct dev_counters
+{
+	unsigned long long arena_head;		// next free uint32 in the CIGAR arena
+	unsigned long long runs_head;		// next free pvc3_run in the runs arena
+	unsigned int arena_overflow;
+	unsigned int runs_overflow;
+	unsigned int scratch_needed;		// max bytes of DP scratch a single wave asked for
+	unsigned int scratch_overflow;
+	unsigned long long n_failed;
+	unsigned long long n_realigned_records;
+	unsigned long long n_runs;
+	unsigned long long bitvec_bytes;	// sum over records of 2 * ceil(columns walked / 8)
+	unsigned long long ref_bytes;		// sum over records of destination characters spanned
+	unsigned long long qual_bytes;		// sum of l_seq over realigned records
+};
+
+// Per-record results before packing.  flags: bits 0-7 status, bit 8 = has at least one indel run.
+struct dev_batch_work
+{
+	uint32_t *dst_pos;
+	uint32_t *mate_dst_pos;
+	uint32_t *rec_flags;
+	uint64_t *cig_loc;					// arena offset of the record's CIGAR
+	uint32_t *cig_n;
+	uint64_t *run_loc;
+	uint32_t *run_n;
+	uint32_t *arena;
+	uint64_t arena_cap;
+	pvc3_run *runs_arena;
+	uint64_t runs_cap;
+	uint8_t *scratch;					// DP scratch, scratch_per_wave bytes per realign wave
+	uint64_t scratch_per_wave;
+	dev_counters *counters;
+};
+
+struct dev_batch_packed
+{
+	uint64_t *out_cigar_off;			// [n + 1]
+	uint32_t *out_cigar;
+	uint64_t out_cigar_cap;
+	uint64_t *run_off;					// [n + 1]
+	pvc3_run *runs;
+	uint64_t run_cap;
+	int32_t *status;					// [n]
+};
+
+constexpr uint32_t REC_STATUS_MASK = 0xffu;
+constexpr uint32_t REC_HAS_RUN = 0x100u;
+
+struct dev_params
+{
+	int32_t gap_open;
+	int32_t gap_ext;
+	int32_t score_mode;
+	int32_t pad;
+	double s_match[42];					// Malde scores vs. reference quality 41, indexed by read phred
+	double s_mismatch[42];
+};
+
+// Launch wrappers (kernels.hip).  All enqueue on `stream` and return a hipError_t as int.
+int launch_project(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
+int launch_mates(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
+int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream);
+int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &packed, uint64_t *scan_tmp, void *stream);
+int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);
+int launch_project_positions(dev_entry const *entries, uint32_t n_entries, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out, void *stream);
+uint32_t realign_lds_bytes();
+uint32_t project_wave_count(uint64_t n);
+uint64_t pack_scan_tmp_words(uint64_t n);
+
+}

@@ -1,0 +1,383 @@
+// realign.hip — local realignment of indel runs (the rare, compute-heavy leg of the hot path).
+//
+// One wavefront per flagged record.  Replays indel_run_checker (libpanvc3/indel_run_checker.cc:31-121) over the rewritten
+// CIGAR, realigns every run that has both insertions and deletions with a global affine alignment of the run's reference
+// slice against its query slice (include/panvc3/align.hh:59-112; seqan3::align_pairwise restated, see oracle/pvc3_oracle.c
+// for the recurrence and the traceback priority), splices the result (libpanvc3/alignment_projector.cc:58-148) and
+// merges adjacent equal operations (collapse_cigar_operations, libpanvc3/cigar.cc:13-51).
+//
+// DP: anti-diagonal wavefront, one lane per query row in stripes of 64 rows, fp64 adds / compares only (score tables are
+// computed on the host with libm), one trace byte per cell in LDS (or in the wave's global scratch slot for large runs).
+#include <hip/hip_runtime.h>
+
+#include "pvc3_internal.hpp"
+#include "wave.hpp"
+#include "device_common.hpp"
+
+namespace pvc3 {
+
+namespace {
+
+constexpr uint32_t REALIGN_LDS_BYTES = 32768;
+constexpr uint32_t TR_DIAG = 0, TR_UP = 1, TR_LEFT = 2, TR_DIR_MASK = 3, TR_V_OPEN = 4, TR_H_OPEN = 8;
+constexpr uint32_t MAX_PHRED = 41;
+
+// seqan3::dna5 ranks (A C G N T); assign_char is case-insensitive, U -> T, anything else -> N.
+__device__ __forceinline__ uint32_t dna5_rank_of_char(uint32_t c)
+{
+	c &= ~0x20u;	// upper case for letters
+	return ('A' == c) ? 0 : ('C' == c) ? 1 : ('G' == c) ? 2 : ('T' == c || 'U' == c) ? 4 : 3;
+}
+
+__device__ __forceinline__ uint32_t dna5_rank_of_seq4(uint32_t code)
+{
+	return (1 == code) ? 0 : (2 == code) ? 1 : (4 == code) ? 2 : (8 == code) ? 4 : 3;
+}
+
+__device__ __forceinline__ uint32_t seq4_at(uint8_t const *seq4, uint32_t i)
+{
+	uint32_t const b = seq4[i >> 1];
+	return (i & 1) ? (b & 0xf) : (b >> 4);
+}
+
+__device__ __forceinline__ double shfl_up_f64(double v)
+{
+	return __shfl_up(v, 1);
+}
+
+struct dp_memory
+{
+	double *col_m;		// M(i, 0), i = 0..n
+	double *bnd_m;		// M(i0, j), j = 0..m   (row above the current stripe)
+	double *bnd_v;		// V(i0, j)
+	uint8_t *trace;		// n * m bytes
+	uint8_t *rev;		// m + n bytes
+};
+
+__device__ __forceinline__ uint64_t dp_bytes(uint32_t m, uint32_t n)
+{
+	return 8ull * (n + 1) + 16ull * (m + 1) + (uint64_t) m * n + (m + n) + 8;
+}
+
+__device__ __forceinline__ dp_memory dp_carve(uint8_t *base, uint32_t m, uint32_t n)
+{
+	dp_memory d;
+	d.col_m = (double *) base;
+	d.bnd_m = d.col_m + (n + 1);
+	d.bnd_v = d.bnd_m + (m + 1);
+	d.trace = (uint8_t *) (d.bnd_v + (m + 1));
+	d.rev = d.trace + (uint64_t) m * n;
+	return d;
+}
+
+// Global affine alignment of ref[0, m) (horizontal) against query bases [q0, q0 + n) (vertical); pushes the resulting
+// operations into `out`.  All control flow is wave-uniform.
+__device__ __forceinline__ void align_global(
+	uint8_t const *ref, uint32_t m, uint8_t const *seq4, uint32_t q0, uint32_t n, uint8_t const *qual /* or nullptr */,
+	dev_params const *__restrict__ prm, dp_memory const mem, sink &out, uint32_t lane
+)
+{
+	double const go = (double) prm->gap_open + (double) prm->gap_ext;	// seqan3's internal gap-open score = open + extension
+	double const ge = (double) prm->gap_ext;
+	double const neg_inf = -__builtin_inf();
+
+	// First column and first row, serially (initialise_first_column_cell / initialise_first_row_cell).
+	if (0 == lane)
+	{
+		double mm = 0.0, v = neg_inf;
+		mem.col_m[0] = 0.0;
+		for (uint32_t i = 1; i <= n; ++i)
+		{
+			double const open = mm + go, ext = v + ge;
+			v = (ext < open) ? open : ext;
+			mm = v;
+			mem.col_m[i] = mm;
+		}
+		double h = neg_inf;
+		mm = 0.0;
+		mem.bnd_m[0] = 0.0; mem.bnd_v[0] = neg_inf;
+		for (uint32_t j = 1; j <= m; ++j)
+		{
+			double const open = mm + go, ext = h + ge;
+			h = (ext < open) ? open : ext;
+			mm = h;
+			mem.bnd_m[j] = mm; mem.bnd_v[j] = neg_inf;
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+	for (uint32_t i0 = 0; i0 < n; i0 += 64)
+	{
+		uint32_t const nr = (n - i0 < 64) ? (n - i0) : 64;		// rows in this stripe
+		bool const row_ok = lane < nr;
+		uint32_t const i = i0 + lane + 1;						// this lane's row (1-based)
+		uint32_t q_rank = 3;
+		double s_match = 0.0, s_mismatch = -1.0;				// nucleotide_scoring_scheme<> default: 0 / -1
+		double m_left = 0.0, h_left = neg_inf, diag = 0.0;
+		if (row_ok)
+		{
+			q_rank = dna5_rank_of_seq4(seq4_at(seq4, q0 + i - 1));
+			if (qual)
+			{
+				uint32_t qq = qual[q0 + i - 1];
+				qq = (qq > MAX_PHRED) ? MAX_PHRED : qq;			// phred42 saturates
+				s_match = prm->s_match[qq];
+				s_mismatch = prm->s_mismatch[qq];
+			}
+			m_left = mem.col_m[i];
+			diag = mem.col_m[i - 1];
+		}
+		double cur_m = 0.0, cur_v = neg_inf;
+		uint32_t const steps = m + nr - 1;
+		for (uint32_t t = 0; t < steps; ++t)
+		{
+			double up_m = shfl_up_f64(cur_m);
+			double up_v = shfl_up_f64(cur_v);
+			uint32_t const j = t - lane + 1;					// column handled by this lane in this step
+			bool const active = row_ok && (t >= lane) && (j <= m);
+			if (active)
+			{
+				if (0 == lane) { up_m = mem.bnd_m[j]; up_v = mem.bnd_v[j]; }
+				uint32_t const r_rank = dna5_rank_of_char(ref[j - 1]);
+				double const s = (r_rank == q_rank) ? s_match : s_mismatch;
+				uint32_t tr = 0;
+				double const v_open = up_m + go, v_ext = up_v + ge;
+				double v;
+				if (v_ext < v_open) { v = v_open; tr |= TR_V_OPEN; } else v = v_ext;
+				double const h_open = m_left + go, h_ext = h_left + ge;
+				double h;
+				if (h_ext < h_open) { h = h_open; tr |= TR_H_OPEN; } else h = h_ext;
+				double best = diag + s;
+				uint32_t dir = TR_DIAG;
+				if (best < v) { best = v; dir = TR_UP; }
+				if (best < h) { best = h; dir = TR_LEFT; }
+				mem.trace[(uint64_t) (i - 1) * m + (j - 1)] = (uint8_t) (tr | dir);
+				m_left = best; h_left = h; cur_m = best; cur_v = v; diag = up_m;
+				if (lane == nr - 1) { mem.bnd_m[j] = best; mem.bnd_v[j] = v; }
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	}
+
+	// Traceback (trace_iterator_base): diagonal > up > left where the direction is decided; a gap continues until the
+	// cell whose gap score was formed by opening.
+	uint32_t k = 0;
+	{
+		uint32_t i = n, j = m;
+		uint32_t st = 0;	// 0 = M, 1 = V (up), 2 = H (left)
+		while (i || j)
+		{
+			uint32_t t;
+			if (0 == i) t = TR_LEFT | ((1 == j) ? TR_H_OPEN : 0);		// first row: left, opened at column 1
+			else if (0 == j) t = TR_UP | ((1 == i) ? TR_V_OPEN : 0);	// first column
+			else t = mem.trace[(uint64_t) (i - 1) * m + (j - 1)];
+			t = rfl(t);
+			if (0 == st)
+			{
+				uint32_t const dir = t & TR_DIR_MASK;
+				if (TR_DIAG == dir)
+				{
+					uint32_t const eq = dna5_rank_of_char(ref[j - 1]) == dna5_rank_of_seq4(seq4_at(seq4, q0 + i - 1));
+					if (0 == lane) mem.rev[k] = (uint8_t) (rfl(eq) ? OP_EQ : OP_X);
+					++k; --i; --j;
+					continue;
+				}
+				st = (TR_UP == dir) ? 1 : 2;
+			}
+			if (1 == st)
+			{
+				if (0 == lane) mem.rev[k] = (uint8_t) OP_I;
+				++k;
+				if (t & TR_V_OPEN) st = 0;
+				--i;
+			}
+			else
+			{
+				if (0 == lane) mem.rev[k] = (uint8_t) OP_D;
+				++k;
+				if (t & TR_H_OPEN) st = 0;
+				--j;
+			}
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	for (uint32_t x = k; x > 0; --x)
+		out.push(rfl(mem.rev[x - 1]), 1, lane);		// align.hh:94-108 through cigar_buffer
+}
+
+__global__ __launch_bounds__(64) void k_realign(
+	dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W,
+	dev_params const *__restrict__ prm, uint32_t lds_budget
+)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[REALIGN_LDS_BYTES];
+	uint32_t const lane = lane_id();
+	uint32_t const wave = blockIdx.x;
+	uint32_t const n_waves = gridDim.x;
+	arena_alloc arena{0, 0}, runs_alloc{0, 0};
+	uint32_t total_runs = 0;
+	uint64_t qual_bytes = 0;
+
+	for (uint64_t base = (uint64_t) wave * 64; base < in.n; base += (uint64_t) n_waves * 64)
+	{
+		uint32_t const fl = (base + lane < in.n) ? W.rec_flags[base + lane] : 0;
+		uint64_t todo = ballot(0 != (fl & REC_HAS_RUN));
+		while (todo)
+		{
+			uint64_t const rec = base + ctz64(todo);
+			todo &= todo - 1;
+
+			uint32_t const *ops = W.arena + W.cig_loc[rec];
+			uint32_t const n_ops = W.cig_n[rec];
+			uint32_t const dst_pos = W.dst_pos[rec];
+			dev_entry const D = entries[in.dst_entry[rec]];
+			uint8_t const *seq4 = in.seq4 + in.seq_off[rec];
+			uint32_t const l_seq = in.l_seq[rec];
+			uint8_t const *qual = ((in.flags[rec] & PVC3_FLAG_HAS_QUAL) && in.qual) ? (in.qual + in.qual_off[rec]) : nullptr;
+
+			// Upper bounds: every run of total length m + n yields at most m + n operations.
+			uint32_t indel_total = 0, n_indel_ops = 0;
+			for (uint32_t x = lane; x < n_ops; x += 64)
+			{
+				uint32_t const c = ops[x];
+				uint32_t const op = c & 0xf;
+				if (OP_I == op || OP_D == op) { indel_total += c >> 4; ++n_indel_ops; }
+			}
+			for (int off = 32; off; off >>= 1)
+			{
+				indel_total += __shfl_xor(indel_total, off);
+				n_indel_ops += __shfl_xor(n_indel_ops, off);
+			}
+			indel_total = rfl(indel_total); n_indel_ops = rfl(n_indel_ops);
+
+			uint64_t out_loc = 0, runs_loc = 0;
+			bool ok = arena_take(arena, n_ops + indel_total + 1, W, lane, out_loc);
+			ok = ok && runs_take(runs_alloc, n_indel_ops / 2 + 1, W, lane, runs_loc);
+			if (!ok)
+				continue;	// the overflow flag is set; the host grows the arenas and repeats the batch
+
+			sink out;
+			out.init();
+			out.spill = W.arena + out_loc;
+			pvc3_run *runs = W.runs_arena + runs_loc;
+			uint32_t n_runs = 0;
+			uint32_t status = PVC3_ST_OK;
+
+			// indel_run_checker state (indel_run_checker.cc:13-21)
+			uint32_t ref_pos = dst_pos, query_pos = 0, run_type = 0;
+			uint32_t run_first = 0, run_ref_loc = dst_pos, run_query_loc = 0;
+
+			for (uint32_t x = 0; x <= n_ops && !status; ++x)
+			{
+				bool const at_end = (x == n_ops);
+				uint32_t op = 0xf, cnt = 0;
+				if (!at_end)
+				{
+					uint32_t const c = rfl(ops[x]);
+					op = c & 0xf; cnt = c >> 4;
+					if (0 == run_type) { run_ref_loc = ref_pos; run_query_loc = query_pos; run_first = x; }	// :45-50
+					if (OP_I == op) { query_pos += cnt; run_type |= 1; continue; }							// :62-65
+					if (OP_D == op) { ref_pos += cnt; run_type |= 2; continue; }							// :67-70
+				}
+				// A run-terminating operation (:55-60, :72-94) or the end of the CIGAR (:111-118).
+				uint32_t const prev_type = run_type;
+				uint32_t const run_ref_end = ref_pos, run_query_end = query_pos;
+				run_type = 0;
+				if (!at_end)
+				{
+					if (OP_S == op) query_pos += cnt;
+					else if (OP_N == op) ref_pos += cnt;
+					else if (OP_M == op || OP_EQ == op || OP_X == op) { ref_pos += cnt; query_pos += cnt; }
+				}
+				if (3 == prev_type)
+				{
+					uint32_t const m = run_ref_end - run_ref_loc, nq = run_query_end - run_query_loc;
+					// alignment_projector.cc:69-73: reference_position() already includes the terminating operation.
+					if (0 == lane)
+					{
+						pvc3_run rr;
+						rr.query_location = run_query_loc; rr.query_length = nq; rr.ref_position = ref_pos; rr.ref_length = m;
+						runs[n_runs] = rr;
+					}
+					++n_runs;
+					if (!D.text || (uint64_t) run_ref_loc + m > D.text_len) { status = PVC3_ST_REF_RANGE; break; }
+					if ((uint64_t) run_query_loc + nq > l_seq) { status = PVC3_ST_QUERY_RANGE; break; }
+
+					uint64_t const need = dp_bytes(m, nq);
+					uint8_t *mem_base = lds;
+					if (need > lds_budget)
+					{
+						if (need > W.scratch_per_wave)
+						{
+							if (0 == lane)
+							{
+								atomicMax(&W.counters->scratch_needed, (unsigned int) ((need > 0xFFFFFFFFull) ? 0xFFFFFFFFu : need));
+								W.counters->scratch_overflow = 1;
+							}
+							status = 0xff;	// not a record status: the host grows the scratch and repeats
+							break;
+						}
+						mem_base = W.scratch + (uint64_t) wave * W.scratch_per_wave;
+					}
+					align_global(D.text + run_ref_loc, m, seq4, run_query_loc, nq, qual, prm, dp_carve(mem_base, m, nq), out, lane);
+				}
+				else if (prev_type)
+				{
+					for (uint32_t y = run_first; y < x; ++y)	// single-type run: copied as is (alignment_projector.cc:61-65)
+					{
+						uint32_t const c = rfl(ops[y]);
+						out.push(c & 0xf, c >> 4, lane);
+					}
+				}
+				if (!at_end)
+					out.push(op, cnt, lane);
+			}
+			out.finish(lane);
+
+			if (0xff == status)
+				continue;
+			if (0 == lane)
+			{
+				if (status)
+				{
+					W.cig_n[rec] = 0; W.run_n[rec] = 0;
+					W.rec_flags[rec] = status;
+					atomicAdd(&W.counters->n_failed, 1ull);
+				}
+				else
+				{
+					W.cig_loc[rec] = out_loc; W.cig_n[rec] = out.n_out;
+					W.run_loc[rec] = runs_loc; W.run_n[rec] = n_runs;
+				}
+			}
+			if (!status) { total_runs += n_runs; qual_bytes += qual ? l_seq : 0; }
+		}
+	}
+	if (0 == lane && total_runs)
+	{
+		atomicAdd(&W.counters->n_runs, (unsigned long long) total_runs);
+		atomicAdd(&W.counters->qual_bytes, (unsigned long long) qual_bytes);
+	}
+}
+
+}	// anonymous namespace
+
+uint32_t realign_lds_bytes() { return REALIGN_LDS_BYTES; }
+
+int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream)
+{
+	if (0 == in.n) return 0;
+	if (lds_budget > REALIGN_LDS_BYTES) lds_budget = REALIGN_LDS_BYTES;
+	uint64_t const useful = (in.n + 63) / 64;
+	if (n_waves > useful) n_waves = (uint32_t) useful;
+	hipLaunchKernelGGL(k_realign, dim3(n_waves), dim3(64), 0, (hipStream_t) stream, entries, n_entries, in, work, params, lds_budget);
+	return (int) hipGetLastError();
+}
+
+}

@@ -1,0 +1,199 @@
+// wave.hpp — wavefront (64-lane) primitives for gfx950 and the gap bit-vector window.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pvc3_internal.hpp"
+
+namespace pvc3 {
+
+__device__ __forceinline__ uint32_t lane_id()
+{
+	return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Number of set bits of m below the calling lane (v_mbcnt_lo/hi): the wavefront prefix popcount.
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+}
+
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+
+__device__ __forceinline__ uint64_t rfl64(uint64_t v)
+{
+	return ((uint64_t) rfl((uint32_t) (v >> 32)) << 32) | rfl((uint32_t) v);
+}
+
+template <typename t_ptr>
+__device__ __forceinline__ t_ptr *rfl_ptr(t_ptr *p) { return (t_ptr *) rfl64((uint64_t) p); }
+
+__device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t lane)
+{
+	return (uint32_t) __builtin_amdgcn_readlane((int) v, (int) lane);
+}
+
+// Replaces lane `lane` (wave-uniform) of a VGPR: v_cmp + v_cndmask (clang has no writelane builtin and v_writelane_b32
+// with two SGPR operands violates the gfx9 constant-bus limit).
+__device__ __forceinline__ uint32_t writelane(uint32_t old, uint32_t v, uint32_t lane)
+{
+	return (lane_id() == lane) ? v : old;
+}
+
+__device__ __forceinline__ uint32_t popc64(uint64_t v) { return (uint32_t) __builtin_popcountll(v); }
+__device__ __forceinline__ uint32_t ctz64(uint64_t v) { return (uint32_t) __builtin_ctzll(v); }
+
+// Bits [0, n) set; n in [0, 64].
+__device__ __forceinline__ uint64_t low_mask(uint32_t n) { return (n >= 64) ? ~UINT64_C(0) : ((UINT64_C(1) << n) - 1); }
+
+// Position of the t-th (0-based) set bit of the wave-uniform word z; all 64 lanes cooperate.
+__device__ __forceinline__ uint32_t wave_select_in_word(uint64_t z, uint32_t t, uint32_t lane)
+{
+	bool const mine = ((z >> lane) & 1) && (mbcnt64(z) == t);
+	return ctz64(ballot(mine));
+}
+
+// Same, one thread on its own word (6 halving steps).
+__device__ __forceinline__ uint32_t thread_select_in_word(uint64_t z, uint32_t t)
+{
+	uint32_t x = (uint32_t) z, base = 0;
+	uint32_t c = (uint32_t) __builtin_popcount(x);
+	if (t >= c) { t -= c; x = (uint32_t) (z >> 32); base = 32; }
+	c = (uint32_t) __builtin_popcount(x & 0xffffu); if (t >= c) { t -= c; x >>= 16; base += 16; }
+	c = (uint32_t) __builtin_popcount(x & 0xffu); if (t >= c) { t -= c; x >>= 8; base += 8; }
+	c = (uint32_t) __builtin_popcount(x & 0xfu); if (t >= c) { t -= c; x >>= 4; base += 4; }
+	c = (uint32_t) __builtin_popcount(x & 0x3u); if (t >= c) { t -= c; x >>= 2; base += 2; }
+	c = x & 1u; if (t >= c) { base += 1; }
+	return base;
+}
+
+// ---- two-block window over the src and dst bit-vectors of one record ---------------------------------------------
+// Lane l < 16 holds src physical word 8 b0 + l, lane 16 + l holds dst physical word 8 b0 + l (l < 16): one vector
+// load instruction fetches four 64-byte blocks {rank, 7 x 64 bits}; words are then read as wave-uniform scalars.
+struct window
+{
+	uint32_t lo, hi;
+	uint32_t b0;	// wave-uniform
+};
+
+__device__ __forceinline__ void window_load(window &w, uint64_t const *src_blocks, uint64_t const *dst_blocks, uint32_t b0, uint32_t lane)
+{
+	uint64_t v = 0;
+	if (lane < 32)
+	{
+		uint64_t const *p = (lane < 16) ? src_blocks : dst_blocks;
+		v = p[(uint64_t) b0 * BLOCK_WORDS + (lane & 15)];
+	}
+	w.lo = (uint32_t) v;
+	w.hi = (uint32_t) (v >> 32);
+	w.b0 = b0;
+}
+
+__device__ __forceinline__ uint64_t window_word(window const &w, uint32_t idx)
+{
+	return ((uint64_t) readlane(w.hi, idx) << 32) | readlane(w.lo, idx);
+}
+
+struct col_pos
+{
+	uint32_t blk, w, bit;
+};
+
+__device__ __forceinline__ col_pos split_col(uint32_t col)
+{
+	col_pos p;
+	p.blk = col / BLOCK_COLS;
+	uint32_t const r = col - p.blk * BLOCK_COLS;
+	p.w = r >> 6;
+	p.bit = r & 63;
+	return p;
+}
+
+// rank0 of the dst vector at column (blk, w, bit); the window must cover blk.
+__device__ __forceinline__ uint32_t window_rank_dst(window const &win, col_pos const p)
+{
+	uint32_t const base = 16 + (p.blk - win.b0) * BLOCK_WORDS;
+	uint32_t r = readlane(win.lo, base);
+	for (uint32_t i = 0; i < p.w; ++i)
+		r += popc64(~window_word(win, base + 1 + i));
+	r += popc64(~window_word(win, base + 1 + p.w) & low_mask(p.bit));
+	return r;
+}
+
+// Column of non-gap number k (0-based) of the src vector, i.e. select0(k + 1) in sdsl terms (msa_index.hh:239-243).
+// Requires k < n_zeros.  Leaves `win` covering the block of the result.
+__device__ __forceinline__ uint32_t wave_select0(dev_entry const &S, uint64_t const *dst_blocks, uint32_t k, window &win, uint32_t lane)
+{
+	uint32_t const col0 = S.sel[k >> SELECT_SAMPLE_SHIFT];
+	uint32_t rem = k & (SELECT_SAMPLE - 1);
+	col_pos p = split_col(col0);
+	window_load(win, S.blocks, dst_blocks, p.blk, lane);
+	for (;;)
+	{
+		if (p.blk - win.b0 >= 2)
+		{
+			// Entering a block outside the window: gallop over all-gap stretches with the rank words.
+			uint32_t blk = p.blk;
+			for (;;)
+			{
+				uint32_t probe = blk + 1 + lane;
+				if (probe > S.n_blocks) probe = S.n_blocks;		// padding block: rank = n_zeros > k
+				uint64_t const m = ballot((uint32_t) S.blocks[(uint64_t) probe * BLOCK_WORDS] <= k);
+				uint32_t const skip = popc64(m);
+				blk += skip;
+				if (skip < 64) break;
+			}
+			p.blk = blk; p.w = 0; p.bit = 0;
+			window_load(win, S.blocks, dst_blocks, blk, lane);
+			rem = k - readlane(win.lo, 0);
+		}
+		uint64_t const sw = window_word(win, (p.blk - win.b0) * BLOCK_WORDS + 1 + p.w);
+		uint64_t const z = ~sw & (~UINT64_C(0) << p.bit);
+		uint32_t const cnt = popc64(z);
+		if (rem < cnt)
+			return p.blk * BLOCK_COLS + p.w * 64 + wave_select_in_word(z, rem, lane);
+		rem -= cnt;
+		p.bit = 0;
+		if (++p.w == BLOCK_DATA_WORDS) { p.w = 0; ++p.blk; }
+	}
+}
+
+// One thread: project_position (msa_index.hh:253-258) = rank0_dst(select0_src(pos + 1)).
+__device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, dev_entry const &D, uint32_t pos)
+{
+	if (pos >= S.n_zeros || S.n_cols != D.n_cols)
+		return PVC3_NO_MATE;
+	uint32_t const col0 = S.sel[pos >> SELECT_SAMPLE_SHIFT];
+	uint32_t rem = pos & (SELECT_SAMPLE - 1);
+	col_pos p = split_col(col0);
+	uint32_t col;
+	for (;;)
+	{
+		uint64_t const z = ~S.blocks[(uint64_t) p.blk * BLOCK_WORDS + 1 + p.w] & (~UINT64_C(0) << p.bit);
+		uint32_t const cnt = popc64(z);
+		if (rem < cnt)
+		{
+			col = p.blk * BLOCK_COLS + p.w * 64 + thread_select_in_word(z, rem);
+			break;
+		}
+		rem -= cnt;
+		p.bit = 0;
+		if (++p.w == BLOCK_DATA_WORDS)
+		{
+			p.w = 0; ++p.blk;
+			while ((uint32_t) S.blocks[(uint64_t) (p.blk + 1) * BLOCK_WORDS] <= pos)	// skip blocks that end before zero #pos
+				++p.blk;
+			rem = pos - (uint32_t) S.blocks[(uint64_t) p.blk * BLOCK_WORDS];
+		}
+	}
+	col_pos const q = split_col(col);
+	uint64_t const *blk = D.blocks + (uint64_t) q.blk * BLOCK_WORDS;
+	uint32_t r = (uint32_t) blk[0];
+	for (uint32_t i = 0; i < q.w; ++i)
+		r += popc64(~blk[1 + i]);
+	r += popc64(~blk[1 + q.w] & low_mask(q.bit));
+	return r;
+}
+
+}

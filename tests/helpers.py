@@ -271,3 +271,77 @@ def gen_indel_run_case(rng):
 	# drop expectations that fused with a preceding single-type indel (cannot happen by construction) and merge adjacent equal ops
 	text = "".join("%d%s" % (n, op) for n, op in ops)
 	return text, expect
+
+
+# --- batches ---------------------------------------------------------------------------------------------------------
+
+_SEQ4 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+
+
+class BatchBuilder:
+	"""Accumulates records into the SoA batch of include/pvc3.h (same dict for the oracle and the HIP path)."""
+
+	def __init__(self):
+		self.src_pos, self.src_entry, self.dst_entry, self.flags = [], [], [], []
+		self.cigar_off, self.cigar = [0], []
+		self.seq_off, self.l_seq, self.seq4 = [0], [], []
+		self.qual_off, self.qual = [0], []
+		self.mate_src_entry, self.mate_dst_entry, self.mate_pos = [], [], []
+
+	def add(self, src_pos, src_entry, dst_entry, cigar, query, qual=None, mate=None, seq_codes=None):
+		cig = cigar_encode(cigar) if isinstance(cigar, str) else np.asarray(cigar, dtype=np.uint32)
+		self.src_pos.append(src_pos); self.src_entry.append(src_entry); self.dst_entry.append(dst_entry)
+		self.cigar.extend(int(x) for x in cig)
+		self.cigar_off.append(len(self.cigar))
+		codes = list(seq_codes) if seq_codes is not None else [_SEQ4.get(c.upper(), 15) for c in query]
+		n = len(codes)
+		if n & 1:
+			codes = codes + [0]
+		self.seq4.extend((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+		self.seq_off.append(len(self.seq4))
+		self.l_seq.append(n)
+		fl = 0
+		if qual is not None:
+			assert len(qual) == n
+			fl |= 1
+			self.qual.extend(int(x) for x in qual)
+		self.qual_off.append(len(self.qual))
+		if mate is not None:
+			fl |= 2
+			self.mate_src_entry.append(mate[0]); self.mate_dst_entry.append(mate[1]); self.mate_pos.append(mate[2])
+		else:
+			self.mate_src_entry.append(0); self.mate_dst_entry.append(0); self.mate_pos.append(0)
+		self.flags.append(fl)
+
+	def build(self):
+		u32, u64, u8 = np.uint32, np.uint64, np.uint8
+		return dict(
+			src_pos=np.array(self.src_pos, dtype=u32), src_entry=np.array(self.src_entry, dtype=u32), dst_entry=np.array(self.dst_entry, dtype=u32),
+			flags=np.array(self.flags, dtype=u32), cigar_off=np.array(self.cigar_off, dtype=u64), cigar=np.array(self.cigar, dtype=u32),
+			seq_off=np.array(self.seq_off, dtype=u64), l_seq=np.array(self.l_seq, dtype=u32), seq4=np.array(self.seq4, dtype=u8),
+			qual_off=np.array(self.qual_off, dtype=u64), qual=np.array(self.qual, dtype=u8),
+			mate_src_entry=np.array(self.mate_src_entry, dtype=u32), mate_dst_entry=np.array(self.mate_dst_entry, dtype=u32),
+			mate_pos=np.array(self.mate_pos, dtype=u32),
+		)
+
+
+def describe_record(batch, res, i):
+	c0, c1 = int(res["out_cigar_off"][i]), int(res["out_cigar_off"][i + 1])
+	r0, r1 = int(res["run_off"][i]), int(res["run_off"][i + 1])
+	return dict(
+		status=int(res["status"][i]), dst_pos=int(res["dst_pos"][i]), mate=int(res["mate_dst_pos"][i]),
+		cigar=cigar_decode(res["out_cigar"][c0:c1]), runs=[tuple(int(x) for x in r) for r in res["runs"][r0:r1]],
+		cigar_in=cigar_decode(batch["cigar"][int(batch["cigar_off"][i]):int(batch["cigar_off"][i + 1])]), src_pos=int(batch["src_pos"][i]),
+	)
+
+
+def assert_results_equal(batch, got, want):
+	"""Byte-equality of every output array (bit-exact parity); on a mismatch shows the first differing record."""
+	n = batch["src_pos"].size
+	keys = ("status", "dst_pos", "mate_dst_pos", "out_cigar_off", "run_off", "out_cigar", "runs")
+	if all(np.array_equal(got[k], want[k]) for k in keys):
+		return
+	for i in range(n):
+		a, b = describe_record(batch, got, i), describe_record(batch, want, i)
+		assert a == b, "record %d differs:\n  hip    %r\n  oracle %r" % (i, a, b)
+	raise AssertionError("arrays differ although every record compares equal")

@@ -1,0 +1,97 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle: bit-exact on every output.
+
+These tests need a real MI355X (pytest -m gpu).  They read like the reference's tests/alignment_projector.cc and
+tests/rewrite_cigar.cc: build a sequence entry pair from two gapped strings, project, compare position + CIGAR.
+"""
+import numpy as np
+import pytest
+
+from helpers import (BatchBuilder, assert_results_equal, cigar_decode, cigar_eq, cigar_items, gen_indel_run_case, gen_rewrite_case,
+					 load_test_msa, rewrite_cases)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pvc3():
+	import panvc3_amd
+	assert panvc3_amd.device_count() > 0, "no GPU visible: the HIP path has no CPU fallback"
+	return panvc3_amd
+
+
+def _setup_pair(pvc3, oracle_mod, src, dst, ctx=None):
+	idx = pvc3.Index()
+	s, d = idx.add_aligned(src), idx.add_aligned(dst)
+	idx.set_reference(d, dst.replace("-", ""))
+	ctx = ctx or pvc3.Context(0)
+	ctx.upload_index(idx)
+	o = oracle_mod.Oracle()
+	os_, od = o.add_aligned(src), o.add_aligned(dst)
+	o.set_reference(od, dst.replace("-", ""))
+	assert (os_, od) == (s, d)
+	return ctx, idx, o, s, d
+
+
+@pytest.mark.parametrize("case", list(rewrite_cases("alignment_projector_inputs.tsv")), ids=lambda c: "line%d" % c[0])
+def test_alignment_projector_fixture(pvc3, oracle_mod, case):
+	"""tests/alignment_projector.cc:157-247 against the HIP path."""
+	ln, src, dst, query, src_pos, exp_pos, cin, cexp = case
+	ctx, idx, o, s, d = _setup_pair(pvc3, oracle_mod, src, dst)
+	qual = [41] * len(query)
+	projector = pvc3.AlignmentProjector(ctx)
+	for mode in (pvc3.SCORE_FP64, pvc3.SCORE_INT32_TRUNC):
+		pos = projector.project_alignment(src_pos, s, d, query, cin, qual, 0, -1, score_mode=mode)
+		opos, ocig, oruns = o.project_alignment(s, d, src_pos, cin, query, qual=qual, score_mode=mode)
+		assert pos == exp_pos == opos
+		assert cigar_decode(projector.alignment()) == cigar_decode(ocig)
+		assert projector.realigned_reference_ranges() == [(int(r["ref_position"]), int(r["ref_length"])) for r in oruns]
+		assert projector.realigned_query_ranges() == [(int(r["query_location"]), int(r["query_length"])) for r in oruns]
+		if ln != 10:	# line 10 contradicts line 9 in the reference itself
+			assert cigar_eq(cexp, projector.alignment(), count_padding=True)
+	# QUAL-less records take the 0 / -1 nucleotide scoring path
+	pos = projector.project_alignment(src_pos, s, d, query, cin, None, 0, -1)
+	opos, ocig, _ = o.project_alignment(s, d, src_pos, cin, query, qual=None)
+	assert (pos, cigar_decode(projector.alignment())) == (opos, cigar_decode(ocig))
+
+
+@pytest.mark.parametrize("case", list(rewrite_cases("rewrite_cigar_inputs.tsv")), ids=lambda c: "line%d" % c[0])
+def test_rewrite_cigar_fixture(pvc3, oracle_mod, case):
+	"""tests/rewrite_cigar.cc:111-191; where the rewritten CIGAR has no I+D run the projector returns it unchanged."""
+	ln, src, dst, query, src_pos, exp_pos, cin, cexp = case
+	ctx, idx, o, s, d = _setup_pair(pvc3, oracle_mod, src, dst)
+	projector = pvc3.AlignmentProjector(ctx)
+	pos = projector.project_alignment(src_pos, s, d, query, cin, [30] * len(query))
+	opos, ocig, oruns = o.project_alignment(s, d, src_pos, cin, query, qual=[30] * len(query))
+	assert pos == exp_pos == opos
+	assert cigar_decode(projector.alignment()) == cigar_decode(ocig)
+	if len(oruns) == 0:
+		assert cigar_eq(cexp, projector.alignment(), count_padding=True)
+
+
+def test_restated_rapidcheck_property_batch(pvc3, oracle_mod):
+	"""The seeded restatement of tests/rewrite_cigar_arbitrary.cc, all cases in one batch over one multi-entry index."""
+	rng = np.random.default_rng(20241016)
+	idx = pvc3.Index()
+	o = oracle_mod.Oracle()
+	bb = BatchBuilder()
+	for it in range(1500):
+		c = gen_rewrite_case(rng, int(rng.integers(0, 60)))
+		if c["src_pos"] >= sum(1 for ch in c["src"] if ch != "-"):
+			continue
+		s, d = idx.add_aligned(c["src"]), idx.add_aligned(c["dst"])
+		assert (o.add_aligned(c["src"]), o.add_aligned(c["dst"])) == (s, d)
+		text = c["dst"].replace("-", "")
+		idx.set_reference(d, text); o.set_reference(d, text)
+		qual = [int(x) for x in rng.integers(0, 45, size=len(c["query"]))] if rng.integers(4) else None
+		bb.add(c["src_pos"], s, d, c["cigar_in"], c["query"], qual=qual, mate=(s, d, int(rng.integers(0, c["src_pos"] + 1))))
+	batch = bb.build()
+	ctx = pvc3.Context(0)
+	ctx.upload_index(idx)
+	for mode in (0, 1):
+		got, stats = pvc3.project_batch(ctx, batch, 0, -1, mode)
+		want = o.batch_project(batch, 0, -1, mode)
+		assert_results_equal(batch, got, want)
+		assert stats["n_failed"] == 0 and stats["n_realigned_records"] > 100
+	for go, ge in ((-3, -1), (-5, -2), (0, -4)):
+		got, _ = pvc3.project_batch(ctx, batch, go, ge, 0)
+		assert_results_equal(batch, got, o.batch_project(batch, go, ge, 0))

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the project_alignments hot path on MI355X (BASELINE.json metric).
+
+A step = one pass of the whole hot path (projection walk, mate projection, indel-run realignment, packing) over one
+device-resident batch of synthetic 2x150 bp records (config C3 of BASELINE.json: 20 M pairs = 40 M records per GPU,
+REF + 8 founders, 1 Gbp in 8 contigs).  Inputs are resident in HBM when the timed region starts.  Multi-GPU: one process
+per GPU, every rank owns its own slice of the read stream (weak scaling), the index is replicated, no data-path collective.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0		# MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def log(msg):
+	if int(os.environ.get("RANK", "0")) == 0:
+		print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=10)
+	ap.add_argument("--warmup", type=int, default=2)
+	ap.add_argument("--config", default="C3", help="BASELINE.json workload: C2, C3 (metric config), C5")
+	ap.add_argument("--scale", type=float, default=1.0, help="shrink genome and read count together (smoke runs only)")
+	ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="target CPU time of the oracle sample; 0 disables")
+	ap.add_argument("--score-mode", type=int, default=0)
+	args = ap.parse_args()
+
+	rank = int(os.environ.get("RANK", "0"))
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+	if world != args.gpus and world > 1:
+		log("warning: WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+	import numpy as np
+	import torch
+	import torch.distributed as dist
+
+	if not torch.cuda.is_available():
+		raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+	torch.cuda.set_device(local_rank)
+	device = torch.device("cuda", local_rank)
+	if world > 1:
+		dist.init_process_group(backend="nccl", device_id=device)
+
+	import panvc3_amd
+	from panvc3_amd import build as pvc3_build
+	from panvc3_amd.shard import reduce_job
+	from tests.synth import synth
+
+	pvc3_build.build()
+	cores = os.cpu_count() or 1
+	threads = max(1, cores // max(1, world))
+
+	# ---- synthetic workload ---------------------------------------------------------------------------------------------
+	gp, rp, desc = synth.config(args.config, scale=args.scale)
+	rp.seed = rp.seed + 1000 * rank			# every rank samples its own reads (weak scaling); the genome is identical
+	t0 = time.time()
+	genome = synth.Genome(gp, n_threads=min(threads, gp.n_contigs))
+	t1 = time.time()
+	reads = synth.Reads(genome, rp, n_threads=threads)
+	batch = reads.batch()
+	n_local = int(reads.n)
+	log("%s; scale %.4g: genome %.1f s, %d records %.1f s (%d host threads)" % (desc, args.scale, t1 - t0, n_local, time.time() - t1, threads))
+
+	index = panvc3_amd.Index()
+	genome.fill_index(index)
+	ctx = panvc3_amd.Context(local_rank)
+	ctx.upload_index(index)
+	ctx.set_timing(True)
+	t2 = time.time()
+	db = panvc3_amd.DeviceBatch(ctx, batch)
+	index_bytes, _ = ctx.hbm_bytes()
+	log("index %.2f GB in HBM; batch uploaded in %.1f s" % (index_bytes / 1e9, time.time() - t2))
+	params = panvc3_amd.api.make_params(0, -1, args.score_mode)
+
+	def barrier():
+		if world > 1:
+			dist.barrier()
+
+	# ---- warm-up (also sizes the workspaces) -------------------------------------------------------------------------------
+	stats = None
+	for _ in range(max(1, args.warmup)):
+		db.project(params)
+		stats = db.finish()
+	if stats["n_failed"]:
+		raise SystemExit("unexpected: %d records failed" % stats["n_failed"])
+
+	# ---- timed region ------------------------------------------------------------------------------------------------------
+	ms = dict(project=0.0, mate=0.0, realign=0.0, pack=0.0)
+	barrier()
+	torch.cuda.synchronize()
+	t_begin = time.perf_counter()
+	for _ in range(args.steps):
+		db.project(params)
+		st = db.finish()		# waits for the step on the kernels' stream and reads the hipEvent timings
+		for k in ms:
+			ms[k] += st["ms_" + k]
+	torch.cuda.synchronize()
+	barrier()
+	elapsed = time.perf_counter() - t_begin
+	checksum = db.checksum(first_record=rank * n_local)
+	elapsed_max, n_total, checksum_total = reduce_job(dist if world > 1 else None, device, elapsed, n_local, checksum)
+
+	result = None
+	if rank == 0:
+		steps = args.steps
+		ms_avg = {k: v / steps for k, v in ms.items()}
+		ms_step = elapsed_max / steps * 1e3
+		value = n_total * steps / elapsed_max
+		project_bytes = stats["algorithmic_bytes_project"]
+		achieved = project_bytes / (ms_avg["project"] * 1e-3) / 1e9 if ms_avg["project"] > 0 else 0.0
+		traffic = None
+		prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+		if os.path.exists(prof):
+			try:
+				pj = json.load(open(prof))
+				key = "%s@%g" % (args.config, args.scale)
+				if key in pj:
+					traffic = pj[key]["k_project_hbm_bytes_per_launch"]
+			except Exception:
+				traffic = None
+		result = {
+			"metric": "projected+realigned alignments/sec, 2x150 bp",
+			"value": value, "unit": "alignments/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+			"ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+			"dtype": "u64 bit-vectors / u32 CIGAR (f64 only in the realign DP)", "data": "synthetic",
+			"config": {
+				"workload": desc, "records_per_gpu": n_local, "read_len": int(rp.read_len), "paired": bool(rp.paired),
+				"founders": int(gp.n_founders), "genome_bp": int(gp.genome_len), "scale": args.scale, "parallelism": "records sharded, index replicated, no collective",
+			},
+			"roofline": {
+				"bound": "hbm", "kernel": "k_project", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+				"traffic": traffic, "algorithmic_bytes_per_launch": project_bytes, "ms_per_launch": ms_avg["project"],
+				"bytes_per_alignment": project_bytes / max(1, n_local),
+				"whole_step": {"algorithmic_bytes": stats["algorithmic_bytes"], "GBps": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9, "frac": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+			},
+			"kernel_ms": ms_avg,
+			"batch": {"realigned_records": stats["n_realigned_records"], "indel_runs": stats["n_runs"], "out_cigar_ops": stats["out_cigar_total"], "checksum": "%016x" % checksum_total},
+		}
+
+		# ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample, same box, rank 0 only ----
+		if world == 1 and args.cpu_baseline_seconds > 0:
+			from oracle import oracle as orc
+			o = orc.Oracle()
+			genome.fill_index(o)
+			probe = min(n_local, 20000)
+			tb = time.perf_counter()
+			o.batch_project(synth.slice_batch(batch, 0, probe), 0, -1, args.score_mode, n_threads=cores)
+			rate = probe / max(1e-6, time.perf_counter() - tb)
+			sample = int(min(n_local, max(probe, rate * args.cpu_baseline_seconds)))
+			sb = synth.slice_batch(batch, 0, sample)
+			tb = time.perf_counter()
+			want = o.batch_project(sb, 0, -1, args.score_mode, n_threads=cores)
+			cpu_s = time.perf_counter() - tb
+			result["cpu_baseline"] = {
+				"value": sample / cpu_s, "unit": "alignments/s", "cores": cores, "kind": "port",
+				"sample": "first %d records of the same batch through oracle/pvc3_oracle.c (plain bit-vectors + binary-search select: faster than the reference's rrr_vector<15> + seqan3 path, which cannot be built here)" % sample,
+			}
+			# parity spot check of the sample against the device results
+			got = db.download()
+			n_c = int(want["out_cigar_off"][sample])
+			same = (
+				np.array_equal(got["dst_pos"][:sample], want["dst_pos"]) and np.array_equal(got["mate_dst_pos"][:sample], want["mate_dst_pos"])
+				and np.array_equal(got["out_cigar_off"][:sample + 1], want["out_cigar_off"]) and np.array_equal(got["out_cigar"][:n_c], want["out_cigar"])
+				and np.array_equal(got["status"][:sample], want["status"])
+				and np.array_equal(got["run_off"][:sample + 1], want["run_off"]) and np.array_equal(got["runs"][:int(want["run_off"][sample])], want["runs"])
+			)
+			result["parity_sample"] = {"records": sample, "bit_identical": bool(same)}
+			if not same:
+				raise SystemExit("parity failure against the oracle on the bench sample")
+		print(json.dumps(result), flush=True)
+
+	db.close()
+	ctx.close()
+	if world > 1:
+		dist.barrier()
+		dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+	main()

@@ -141,6 +141,7 @@ typedef struct pvc3_batch_stats
 	uint64_t n_runs;				/* total realigned indel runs */
 	uint64_t out_cigar_total;		/* total output CIGAR operations (required out_cigar_cap) */
 	uint64_t algorithmic_bytes;		/* SURVEY.md §8(d) bytes of this batch (reads + writes), see DESIGN.md */
+	uint64_t algorithmic_bytes_project;	/* the share of the projection kernel (k_project) alone */
 	float ms_project;				/* last launch durations (hipEvent), 0 if timing is disabled */
 	float ms_mate;
 	float ms_realign;

@@ -887,7 +887,7 @@ static void *batch_worker(void *arg)
 			else if (ORC_D == op || ORC_N == op) ref_consumed += cnt;
 			else if (ORC_I == op || ORC_S == op) query_consumed += cnt;
 		}
-		if (!st && (uint64_t) in->src_pos[r] + (ref_consumed ? ref_consumed : 1) > src->n_zeros) st = ORC_ERR_SRC_RANGE;
+		if (!st && (src->n_cols != dst->n_cols || (uint64_t) in->src_pos[r] + (ref_consumed ? ref_consumed : 1) > src->n_zeros)) st = ORC_ERR_SRC_RANGE;
 		if (!st && query_consumed > l_seq) st = ORC_ERR_QUERY_RANGE;
 
 		uint32_t n_out = 0, n_runs = 0;
@@ -918,7 +918,7 @@ static void *batch_worker(void *arg)
 		{
 			orc_entry const *ms = &t->idx->entries[in->mate_src_entry[r]];
 			orc_entry const *md = &t->idx->entries[in->mate_dst_entry[r]];
-			if (in->mate_pos[r] < ms->n_zeros)
+			if (in->mate_pos[r] < ms->n_zeros && ms->n_cols == md->n_cols)
 				mate = (uint32_t) entry_rank0(md, entry_select0(ms, 1 + (uint64_t) in->mate_pos[r]));
 		}
 		out->mate_dst_pos[r] = mate;

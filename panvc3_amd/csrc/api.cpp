@@ -577,15 +577,23 @@ int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stat
 		stats->out_cigar_total = totals[0];
 		// Algorithmic bytes (DESIGN.md "Algorithmic bytes per alignment"): what one pass must read and write at minimum.
 		uint64_t const n = b->n;
+		// k_project: record fields, input CIGAR, packed SEQ, one select sample + one dst rank word, the src / dst gap-bit
+		// windows, the dst text window; writes dst_pos, status word, arena location + count, and the CIGAR itself.
+		stats->algorithmic_bytes_project =
+			n * (4 + 4 + 4 + 8 + 8 + 4)					// src_pos, src_entry, dst_entry, cigar_off, seq_off, l_seq
+			+ 4 * b->sum_cigar + b->sum_seq_bytes
+			+ n * (4 + 8)
+			+ c.bitvec_bytes + c.ref_bytes
+			+ n * (4 + 4 + 8 + 4)						// dst_pos, flags word, CIGAR location, CIGAR length
+			+ 4 * totals[0];
 		stats->algorithmic_bytes =
-			n * (4 + 4 + 4 + 4 + 8 + 8 + 4)			// src_pos, src_entry, dst_entry, flags, cigar_off, seq_off, l_seq
-			+ 4 * b->sum_cigar + b->sum_seq_bytes		// input CIGAR, packed SEQ
-			+ n * (4 + 8)								// one select sample, one dst rank word
-			+ c.bitvec_bytes + c.ref_bytes				// src + dst gap-bit windows, dst text window
+			stats->algorithmic_bytes_project
+			+ n * 4										// flags (mate / QUAL bits)
 			+ b->n_mates * (12 + 4 + 64 + 64)			// mate fields, select sample, one src and one dst block
+			+ n * 4										// mate_dst_pos
 			+ c.qual_bytes								// QUAL of realigned records only
-			+ n * (4 + 4 + 4 + 8 + 8)					// dst_pos, mate_dst_pos, status, out_cigar_off, run_off
-			+ 4 * totals[0] + sizeof(pvc3_run) * totals[1];
+			+ sizeof(pvc3_run) * totals[1];				// realigned ranges
+		// (The packing pass re-reads and re-writes the CIGARs; that is implementation traffic, not algorithmic bytes.)
 		if (ctx->timing)
 		{
 			(void) hipEventElapsedTime(&stats->ms_project, ctx->ev[0], ctx->ev[1]);

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_project(dev_entry const *__restrict__ e
 		project_record(entries, n_entries, in, W, rec, arena, lane, res);
 		if (0 == lane)
 		{
-			W.dst_pos[rec] = res.dst_pos;
+			W.dst_pos[rec] = res.status ? 0 : res.dst_pos;		// a rejected record has empty outputs
 			W.cig_loc[rec] = res.loc;
 			W.cig_n[rec] = res.status ? 0 : res.n_out;
 			W.run_n[rec] = 0;

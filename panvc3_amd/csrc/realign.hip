@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64) void k_realign(
 			{
 				if (status)
 				{
-					W.cig_n[rec] = 0; W.run_n[rec] = 0;
+					W.cig_n[rec] = 0; W.run_n[rec] = 0; W.dst_pos[rec] = 0;
 					W.rec_flags[rec] = status;
 					atomicAdd(&W.counters->n_failed, 1ull);
 				}

@@ -4,8 +4,10 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-	sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, HERE):
+	if p not in sys.path:
+		sys.path.insert(0, p)
 
 
 def pytest_configure(config):

@@ -15,6 +15,7 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CIGAR_OPS = "MIDNSHP=X"
+CIGAR_OPS_PADDED = "MIDNSHP=X???????"
 
 
 def cigar_encode(text):
@@ -30,7 +31,7 @@ def cigar_encode(text):
 
 
 def cigar_decode(arr):
-	return "".join("%d%s" % (int(v) >> 4, CIGAR_OPS[int(v) & 0xf]) for v in arr)
+	return "".join("%d%s" % (int(v) >> 4, CIGAR_OPS_PADDED[int(v) & 0xf]) for v in arr)
 
 
 def cigar_items(c):

@@ -1,0 +1,301 @@
+"""HIP path vs oracle on the synthetic workloads of BASELINE.json (seeded, tests/synth) and on the edge cases the
+reference's tests and source single out.  Bit-exact comparison of every output array; full-size configurations are
+checked through size-independent properties plus a sampled oracle comparison."""
+import numpy as np
+import pytest
+
+from helpers import BatchBuilder, assert_results_equal, cigar_decode, load_test_msa
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pvc3():
+	import panvc3_amd
+	assert panvc3_amd.device_count() > 0, "no GPU visible: the HIP path has no CPU fallback"
+	return panvc3_amd
+
+
+@pytest.fixture(scope="module")
+def synth():
+	from tests.synth import synth as s
+	s.build()
+	return s
+
+
+def _run_both(pvc3, oracle_mod, genome, batch, ctx=None, score_mode=0, gap=(0, -1), threads=8, with_all_texts=False):
+	index = pvc3.Index()
+	genome.fill_index(index, with_all_texts)
+	ctx = ctx or pvc3.Context(0)
+	ctx.upload_index(index)
+	got, stats = pvc3.project_batch(ctx, batch, gap[0], gap[1], score_mode)
+	o = oracle_mod.Oracle()
+	genome.fill_index(o, with_all_texts)
+	want = o.batch_project(batch, gap[0], gap[1], score_mode, n_threads=threads)
+	assert_results_equal(batch, got, want)
+	return got, stats, ctx, o
+
+
+@pytest.mark.parametrize("name,scale", [("C2", 0.2), ("C3", 0.005), ("C5", 0.005)])
+def test_scaled_configs(pvc3, oracle_mod, synth, name, scale):
+	gp, rp, desc = synth.config(name, scale=scale)
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	batch = reads.batch()
+	for mode in (0, 1):
+		got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, batch, score_mode=mode)
+		assert stats["n_failed"] == 0
+		assert stats["attempts"] == 1
+	if name == "C5":
+		assert stats["n_realigned_records"] > 0.02 * reads.n		# long events: a few percent of the reads are realigned
+	# mate symmetry: both reads of a pair see each other's projected position
+	if rp.paired:
+		a, b = got["dst_pos"][0::2], got["dst_pos"][1::2]
+		assert np.array_equal(got["mate_dst_pos"][0::2][:b.size], b) and np.array_equal(got["mate_dst_pos"][1::2], a[:b.size])
+
+
+def test_c2_full_size_bit_exact(pvc3, oracle_mod, synth):
+	"""BASELINE.json configs[1]: 1 M synthetic 150 bp single-end reads, 2 founders, bit-exact vs the CPU path."""
+	gp, rp, desc = synth.config("C2")
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	assert reads.n == 1_000_000
+	got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, reads.batch(), threads=16)
+	assert stats["n_failed"] == 0 and stats["n_realigned_records"] > 0
+
+
+def test_shipped_msa_reads(pvc3, oracle_mod, synth):
+	"""C1 stand-in: reads sampled from the reference's shipped 5-row test MSA (bowtie2 is not available to make the real input)."""
+	rows = load_test_msa()
+	order = ["REF", "1", "2", "3", "4"]
+	genome = synth.Genome(aligned_rows=[rows[k] for k in order])
+	gp, rp, _ = synth.config("C3", scale=1e-6)
+	rp.n_records = 2000
+	rp.read_len = 100
+	reads = synth.Reads(genome, rp)
+	got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, reads.batch())
+	assert stats["n_failed"] == 0
+
+
+def test_soft_masked_reference_and_n_bases(pvc3, oracle_mod, synth):
+	"""Quirk Q3: the rewrite step compares raw bytes (lower-case reference != upper-case read => X), the realignment
+	compares dna5 ranks (case-insensitive, N == N)."""
+	gp, rp, _ = synth.config("C5", scale=0.002)
+	gp.lowercase_every = 7
+	rp.n_base_rate = 0.01
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, reads.batch())
+	ops = got["out_cigar"] & 0xf
+	assert (ops == 8).sum() > 0.1 * reads.n		# plenty of X from the case mismatch
+
+
+def _edge_index(pvc3, oracle_mod, pairs):
+	"""pairs: list of (src_aligned, dst_aligned, dst_text or None)."""
+	idx, o = pvc3.Index(), oracle_mod.Oracle()
+	ids = []
+	for src, dst, text in pairs:
+		s, d = idx.add_aligned(src), idx.add_aligned(dst)
+		assert (o.add_aligned(src), o.add_aligned(dst)) == (s, d)
+		if text is not None:
+			idx.set_reference(d, text); o.set_reference(d, text)
+		ids.append((s, d))
+	ctx = pvc3.Context(0)
+	ctx.upload_index(idx)
+	return ctx, o, ids
+
+
+def test_edge_cases_and_statuses(pvc3, oracle_mod):
+	rng = np.random.default_rng(1)
+	src = "GATTACA" * 40
+	dst = "GAT-ACA" * 40
+	ctx, o, ids = _edge_index(pvc3, oracle_mod, [
+		(src, dst, dst.replace("-", "")),
+		("ACGT" * 30, "ACGT" * 30, None),							# destination without text
+		("AC-GT", "ACGGT", "ACGGT"),
+	])
+	(s0, d0), (s1, d1), (s2, d2) = ids
+	q = lambda n: "".join("ACGT"[x] for x in rng.integers(0, 4, size=n))
+	bb = BatchBuilder()
+	bb.add(0, s0, d0, "", "")											# empty CIGAR and SEQ
+	bb.add(5, s0, d0, "10S", q(10))										# clipping only
+	bb.add(5, s0, d0, "3H2S5M1P5M3N4M2I4D6=3X2S1H", q(2 + 5 + 5 + 4 + 2 + 6 + 3 + 2), qual=[30] * 29)	# every operation type
+	bb.add(0, s0, d0, "280M", src, qual=[20] * 280)						# whole sequence
+	bb.add(279, s0, d0, "1M", "A")										# last base
+	bb.add(280, s0, d0, "1M", "A")										# src_pos == length        -> status 1
+	bb.add(270, s0, d0, "20M", q(20))									# runs past the end        -> status 1
+	bb.add(0, s0, d0, "5M", q(3))										# CIGAR longer than SEQ    -> status 3
+	bb.add(0, s0, d0, np.array([(5 << 4) | 9], dtype=np.uint32), q(5))	# operation code 9         -> status 2
+	bb.add(0, s0, d0, np.array([(5 << 4) | 15, (5 << 4) | 0], dtype=np.uint32), q(5))
+	bb.add(0, s1, d1, "10M", q(10))										# no destination text      -> status 4
+	bb.add(0, s1, d1, "4S3I", q(7))										# ... but nothing to compare: fine
+	bb.add(0, s0, d2, "3M", q(3))										# column counts differ     -> status 1
+	bb.add(0, s2, d2, "0M2M0I2M", q(4))									# zero-length operations vanish (cigar.cc:65-66)
+	bb.add(3, s0, s0, "50M", src[3:53])									# identity projection needs the text of s0 -> status 4
+	bb.add(0, s0, d0, "5M", q(5), mate=(s0, d0, 279))
+	bb.add(0, s0, d0, "5M", q(5), mate=(s0, d0, 280))					# mate beyond the sequence: PVC3_NO_MATE
+	bb.add(0, s0, d0, "5M", q(5), mate=(s2, d2, 1))
+	batch = bb.build()
+	got, stats = pvc3.project_batch(ctx, batch)
+	want = o.batch_project(batch)
+	assert_results_equal(batch, got, want)
+	assert list(got["status"][5:11]) == [1, 1, 3, 2, 2, 4]
+	assert got["status"][12] == 1 and got["status"][14] == 4
+	assert got["mate_dst_pos"][16] == 0xFFFFFFFF
+	assert stats["n_failed"] == 8
+	# empty batch
+	empty = BatchBuilder().build()
+	got, stats = pvc3.project_batch(ctx, empty)
+	assert got["out_cigar_off"].tolist() == [0] and stats["n_records"] == 0
+
+
+def test_many_operations_spill_and_big_dp(pvc3, oracle_mod):
+	"""More runs than the lane buffers hold (arena spill), more than 64 input operations, and an indel run whose DP needs
+	several 64-row stripes and the global scratch."""
+	rng = np.random.default_rng(2)
+	n = 400
+	base = "".join("ACGT"[x] for x in rng.integers(0, 4, size=n))
+	zig_src = "".join(c + "-" for c in base)		# A-C-G-...
+	zig_dst = "".join("-" + c for c in base)		# -A-C-G...
+	ctx, o, ids = _edge_index(pvc3, oracle_mod, [
+		(base, base, base),
+		(zig_src, zig_dst, base),
+	])
+	(s0, d0), (s1, d1) = ids
+	bb = BatchBuilder()
+	# alternating mismatches: 300 runs of length 1
+	alt = "".join(c if i % 2 == 0 else "ACGT"[("ACGT".index(c) + 1) % 4] for i, c in enumerate(base[:300]))
+	bb.add(0, s0, d0, "300M", alt, qual=[37] * 300)
+	# 150 input operations
+	bb.add(10, s0, d0, "1M1=" * 75, base[10:160])
+	bb.add(10, s0, d0, "1M1I" * 100, "".join(base[10 + i] + "T" for i in range(100)), qual=[30] * 200)
+	# zig-zag MSA: every base becomes 1I1D => one indel run of 300 x 300
+	bb.add(20, s1, d1, "300M", base[20:320], qual=[int(x) for x in rng.integers(2, 42, size=300)])
+	bb.add(0, s1, d1, "70M", base[0:70], qual=None)
+	bb.add(100, s1, d1, "30M5S", base[100:130] + "AAAAA", qual=[41] * 35)
+	batch = bb.build()
+	got, stats = pvc3.project_batch(ctx, batch)
+	want = o.batch_project(batch)
+	assert_results_equal(batch, got, want)
+	assert int(got["out_cigar_off"][1]) == 300
+	assert stats["n_runs"] == 3
+
+
+def test_long_gap_runs(pvc3, oracle_mod):
+	"""Gap runs far longer than the two-block window: select0 gallops over the rank words, the walk crosses them."""
+	rng = np.random.default_rng(3)
+	seg = lambda k: "".join("ACGT"[x] for x in rng.integers(0, 4, size=k))
+	a, b, c = seg(3000), seg(100_000), seg(3000)
+	# src lacks b (100 kbp deletion in the founder); dst lacks an insertion of the founder elsewhere
+	ins = seg(50_000)
+	src = a + "-" * len(b) + c + ins + a
+	dst = a + b + c + "-" * len(ins) + a
+	ctx, o, ids = _edge_index(pvc3, oracle_mod, [(src, dst, dst.replace("-", ""))])
+	s, d = ids[0]
+	stext = src.replace("-", "")
+	bb = BatchBuilder()
+	for p in (2900, 2990, 2999, 3000, 5900, 5990, 6001, 30000, 55990, 56010):
+		bb.add(p, s, d, "150M", stext[p:p + 150], qual=[30] * 150, mate=(s, d, p + 300))
+	bb.add(2500, s, d, "3000M", stext[2500:5500])
+	batch = bb.build()
+	got, stats = pvc3.project_batch(ctx, batch)
+	assert_results_equal(batch, got, o.batch_project(batch))
+	assert "100000D" in cigar_decode(got["out_cigar"][int(got["out_cigar_off"][0]):int(got["out_cigar_off"][1])])
+
+
+def test_workspace_growth_and_scratch_paths(pvc3, oracle_mod, synth):
+	"""Arena / runs / scratch overflow make the library grow the workspace and repeat on the GPU; forcing the DP out of LDS
+	must not change a single byte."""
+	gp, rp, _ = synth.config("C5", scale=0.003)
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	batch = reads.batch()
+	base, stats0, ctx, o = _run_both(pvc3, oracle_mod, genome, batch)
+	index = pvc3.Index()
+	genome.fill_index(index)
+	for opts in (dict(arena_initial=1000), dict(runs_initial=3), dict(realign_lds_bytes=64), dict(realign_lds_bytes=64, scratch_per_wave=512), dict(realign_waves=3)):
+		c2 = pvc3.Context(0)
+		for k, v in opts.items():
+			c2.set_option(k, v)
+		c2.upload_index(index)
+		got, stats = pvc3.project_batch(c2, batch)
+		for k in ("status", "dst_pos", "mate_dst_pos", "out_cigar_off", "out_cigar", "run_off", "runs"):
+			assert np.array_equal(got[k], base[k]), (opts, k)
+		if "arena_initial" in opts or "runs_initial" in opts or "scratch_per_wave" in opts:
+			assert stats["attempts"] > 1, opts
+		c2.close()
+
+
+def test_project_positions(pvc3, oracle_mod, synth):
+	gp, rp, _ = synth.config("C3", scale=0.002)
+	genome = synth.Genome(gp)
+	index = pvc3.Index()
+	genome.fill_index(index)
+	ctx = pvc3.Context(0)
+	ctx.upload_index(index)
+	o = oracle_mod.Oracle()
+	genome.fill_index(o)
+	rng = np.random.default_rng(4)
+	per = 1 + genome.n_founders
+	src = rng.integers(0, genome.n_entries, size=20000).astype(np.uint32)
+	dst = (src // per * per).astype(np.uint32)
+	lens = np.array([o.zeros(int(e)) for e in range(genome.n_entries)])
+	pos = (rng.random(20000) * lens[src]).astype(np.uint32)
+	pos[:50] = lens[src[:50]] - 1
+	pos[50:60] = lens[src[50:60]]			# out of range
+	got = ctx.project_positions(src, dst, pos)
+	want = np.array([o.project_position(int(s), int(d), int(p)) if p < lens[s] else 0xFFFFFFFF for s, d, p in zip(src, dst, pos)], dtype=np.uint32)
+	assert np.array_equal(got, want)
+
+
+def test_c3_full_size_properties(pvc3, oracle_mod, synth):
+	"""BASELINE.json configs[2] at full size (20 M pairs, 8 founders, 1 Gbp): size-independent properties + sampled oracle parity."""
+	gp, rp, desc = synth.config("C3")
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	batch = reads.batch()
+	n = reads.n
+	assert n == 40_000_000
+	index = pvc3.Index()
+	genome.fill_index(index)
+	ctx = pvc3.Context(0)
+	ctx.upload_index(index)
+	db = pvc3.DeviceBatch(ctx, batch)
+	db.project()
+	stats = db.finish()
+	whole = db.checksum(0)
+	got = db.download()
+	db.close()
+	assert stats["n_failed"] == 0
+	# 1. query-length conservation: = X I S counts add up to l_seq for every record
+	ops = got["out_cigar"] & 0xf
+	cnt = (got["out_cigar"] >> 4).astype(np.int64)
+	qlen = np.where((ops == 7) | (ops == 8) | (ops == 1) | (ops == 4), cnt, 0)
+	csum = np.concatenate([[0], np.cumsum(qlen)])
+	per_rec = csum[got["out_cigar_off"][1:].astype(np.int64)] - csum[got["out_cigar_off"][:-1].astype(np.int64)]
+	assert np.array_equal(per_rec, batch["l_seq"].astype(np.int64))
+	# 2. adjacent operations differ (cigar_buffer / collapse merged everything), no zero counts
+	same_as_prev = ops[1:] == ops[:-1]
+	starts = np.zeros(ops.size, dtype=bool)
+	starts[got["out_cigar_off"][:-1].astype(np.int64)[got["out_cigar_off"][:-1] < ops.size]] = True
+	assert not (same_as_prev & ~starts[1:]).any() and (cnt > 0).all()
+	# 3. mate symmetry
+	assert np.array_equal(got["mate_dst_pos"][0::2], got["dst_pos"][1::2]) and np.array_equal(got["mate_dst_pos"][1::2], got["dst_pos"][0::2])
+	# 4. the checksum is additive over shards (what the multi-GPU path relies on): 4 contiguous shards
+	total = 0
+	for k in range(4):
+		lo, hi = n * k // 4, n * (k + 1) // 4
+		sb = synth.slice_batch(batch, lo, hi)
+		d2 = pvc3.DeviceBatch(ctx, sb)
+		d2.project()
+		d2.finish()
+		total = (total + d2.checksum(lo)) & 0xFFFFFFFFFFFFFFFF
+		if k == 2:
+			# 5. sampled oracle parity inside the third shard
+			o = oracle_mod.Oracle()
+			genome.fill_index(o)
+			sample = synth.slice_batch(batch, lo + 12345, lo + 12345 + 300_000)
+			g2, _ = pvc3.project_batch(ctx, sample)
+			assert_results_equal(sample, g2, o.batch_project(sample, n_threads=16))
+		d2.close()
+	assert total == whole

@@ -57,6 +57,7 @@ struct pvc3_context
 	uint64_t scratch_per_wave{256 * 1024};
 	uint64_t arena_initial{};
 	uint64_t runs_initial{};
+	uint32_t fast_path{1};
 	uint8_t *scratch{};
 	uint64_t scratch_alloc{};
 };
@@ -198,9 +199,9 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	b->work.scratch_per_wave = ctx->scratch_per_wave;
 	HIP_TRY(hipMemsetAsync(b->work.counters, 0, sizeof(dev_counters), s));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
-	if (int const e = launch_project(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_project launch: %s", hipGetErrorString((hipError_t) e));
+	if (int const e = launch_project(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s)) return set_error(PVC3_E_HIP, "k_project launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
-	if (int const e = launch_mates(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_mates launch: %s", hipGetErrorString((hipError_t) e));
+	// (mate projection is fused into k_project; the event pair is kept so that ms_mate reads 0)
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	uint32_t const lds = ctx->realign_lds_bytes ? ctx->realign_lds_bytes : realign_lds_bytes();
 	if (int const e = launch_realign(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->d_params, ctx->realign_waves, lds, s)) return set_error(PVC3_E_HIP, "k_realign launch: %s", hipGetErrorString((hipError_t) e));
@@ -369,6 +370,7 @@ int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value)
 	else if ("scratch_per_wave" == k) ctx->scratch_per_wave = (uint64_t) value;
 	else if ("arena_initial" == k) ctx->arena_initial = (uint64_t) value;
 	else if ("runs_initial" == k) ctx->runs_initial = (uint64_t) value;
+	else if ("fast_path" == k) ctx->fast_path = (0 != value);
 	else return set_error(PVC3_E_INVALID, "pvc3_context_set_option: unknown option %s", key);
 	return PVC3_OK;
 }

@@ -159,41 +159,48 @@ __device__ __forceinline__ uint32_t wave_select0(dev_entry const &S, uint64_t co
 	}
 }
 
-// One thread: project_position (msa_index.hh:253-258) = rank0_dst(select0_src(pos + 1)).
-__device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, dev_entry const &D, uint32_t pos)
+// One thread: column of non-gap number pos (0-based); requires pos < n_zeros.
+__device__ __forceinline__ uint32_t thread_select0(uint64_t const *__restrict__ blocks, uint32_t const *__restrict__ sel, uint32_t pos)
 {
-	if (pos >= S.n_zeros || S.n_cols != D.n_cols)
-		return PVC3_NO_MATE;
-	uint32_t const col0 = S.sel[pos >> SELECT_SAMPLE_SHIFT];
+	uint32_t const col0 = sel[pos >> SELECT_SAMPLE_SHIFT];
 	uint32_t rem = pos & (SELECT_SAMPLE - 1);
 	col_pos p = split_col(col0);
-	uint32_t col;
 	for (;;)
 	{
-		uint64_t const z = ~S.blocks[(uint64_t) p.blk * BLOCK_WORDS + 1 + p.w] & (~UINT64_C(0) << p.bit);
+		uint64_t const z = ~blocks[(uint64_t) p.blk * BLOCK_WORDS + 1 + p.w] & (~UINT64_C(0) << p.bit);
 		uint32_t const cnt = popc64(z);
 		if (rem < cnt)
-		{
-			col = p.blk * BLOCK_COLS + p.w * 64 + thread_select_in_word(z, rem);
-			break;
-		}
+			return p.blk * BLOCK_COLS + p.w * 64 + thread_select_in_word(z, rem);
 		rem -= cnt;
 		p.bit = 0;
 		if (++p.w == BLOCK_DATA_WORDS)
 		{
 			p.w = 0; ++p.blk;
-			while ((uint32_t) S.blocks[(uint64_t) (p.blk + 1) * BLOCK_WORDS] <= pos)	// skip blocks that end before zero #pos
+			while ((uint32_t) blocks[(uint64_t) (p.blk + 1) * BLOCK_WORDS] <= pos)	// skip blocks that end before zero #pos
 				++p.blk;
-			rem = pos - (uint32_t) S.blocks[(uint64_t) p.blk * BLOCK_WORDS];
+			rem = pos - (uint32_t) blocks[(uint64_t) p.blk * BLOCK_WORDS];
 		}
 	}
+}
+
+// One thread: rank0 at column col (number of non-gap columns before col).
+__device__ __forceinline__ uint32_t thread_rank0(uint64_t const *__restrict__ blocks, uint32_t col)
+{
 	col_pos const q = split_col(col);
-	uint64_t const *blk = D.blocks + (uint64_t) q.blk * BLOCK_WORDS;
+	uint64_t const *blk = blocks + (uint64_t) q.blk * BLOCK_WORDS;
 	uint32_t r = (uint32_t) blk[0];
 	for (uint32_t i = 0; i < q.w; ++i)
 		r += popc64(~blk[1 + i]);
 	r += popc64(~blk[1 + q.w] & low_mask(q.bit));
 	return r;
+}
+
+// One thread: project_position (msa_index.hh:253-258) = rank0_dst(select0_src(pos + 1)).
+__device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, dev_entry const &D, uint32_t pos)
+{
+	if (pos >= S.n_zeros || S.n_cols != D.n_cols)
+		return PVC3_NO_MATE;
+	return thread_rank0(D.blocks, thread_select0(S.blocks, S.sel, pos));
 }
 
 }

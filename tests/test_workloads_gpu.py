@@ -213,7 +213,7 @@ def test_workspace_growth_and_scratch_paths(pvc3, oracle_mod, synth):
 	base, stats0, ctx, o = _run_both(pvc3, oracle_mod, genome, batch)
 	index = pvc3.Index()
 	genome.fill_index(index)
-	for opts in (dict(arena_initial=1000), dict(runs_initial=3), dict(realign_lds_bytes=64), dict(realign_lds_bytes=64, scratch_per_wave=512), dict(realign_waves=3)):
+	for opts in (dict(arena_initial=1000), dict(runs_initial=3), dict(realign_lds_bytes=64), dict(realign_lds_bytes=64, scratch_per_wave=512), dict(realign_waves=3), dict(fast_path=0)):
 		c2 = pvc3.Context(0)
 		for k, v in opts.items():
 			c2.set_option(k, v)
@@ -223,6 +223,41 @@ def test_workspace_growth_and_scratch_paths(pvc3, oracle_mod, synth):
 			assert np.array_equal(got[k], base[k]), (opts, k)
 		if "arena_initial" in opts or "runs_initial" in opts or "scratch_per_wave" in opts:
 			assert stats["attempts"] > 1, opts
+		c2.close()
+
+
+def test_fast_path_boundaries(pvc3, oracle_mod):
+	"""The lane-parallel fast path (simple CIGAR, no gap column in the window) must agree with the general column walk and
+	the oracle at its boundaries: 256 / 257 bases, clips of either kind, odd query offsets, gaps right next to the window."""
+	rng = np.random.default_rng(9)
+	seg = lambda k: "".join("ACGT"[x] for x in rng.integers(0, 4, size=k))
+	a, b = seg(700), seg(700)
+	src = a + "-" + b			# one dst-only column right after a
+	dst = a + "T" + b
+	pairs = [(src, dst, dst.replace("-", "")), (dst, src, src.replace("-", ""))]
+	ctx, o, ids = _edge_index(pvc3, oracle_mod, pairs)
+	bb = BatchBuilder()
+	mut = lambda t: "".join(c if rng.random() > 0.1 else "ACGTN"[rng.integers(5)] for c in t)
+	for (s, d), text in ((ids[0], src.replace("-", "")), (ids[1], dst)):
+		for L in (1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 65, 150, 255, 256, 257, 300):
+			for p in (0, 1, 699 - L, 700 - L, 701 - L, 702, 705):
+				if p < 0 or p + L > len(text):
+					continue
+				q = mut(text[p:p + L])
+				bb.add(p, s, d, "%dM" % L, q, qual=[30] * L)
+				bb.add(p, s, d, "3S%dM" % L, "ACG" + q)
+				bb.add(p, s, d, "2H%d=4S" % L, q + "ACGT")
+				bb.add(p, s, d, "1S%dX2H" % L, "N" + q)
+				if L > 2:
+					bb.add(p, s, d, "1M%d=1X" % (L - 2), q)
+					bb.add(p, s, d, "1M1I%dM" % (L - 2), q[:1] + "G" + q[1:-1])		# not simple
+	batch = bb.build()
+	want = o.batch_project(batch)
+	for fp in (1, 0):
+		c2, _, _ = _edge_index(pvc3, oracle_mod, pairs)
+		c2.set_option("fast_path", fp)
+		got, stats = pvc3.project_batch(c2, batch)
+		assert_results_equal(batch, got, want)
 		c2.close()
 
 

@@ -97,7 +97,7 @@ def main():
 		raise SystemExit("unexpected: %d records failed" % stats["n_failed"])
 
 	# ---- timed region ------------------------------------------------------------------------------------------------------
-	ms = dict(project=0.0, mate=0.0, realign=0.0, pack=0.0)
+	ms = dict(project=0.0, general=0.0, realign=0.0, pack=0.0)
 	barrier()
 	torch.cuda.synchronize()
 	t_begin = time.perf_counter()

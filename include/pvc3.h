@@ -142,10 +142,11 @@ typedef struct pvc3_batch_stats
 	uint64_t out_cigar_total;		/* total output CIGAR operations (required out_cigar_cap) */
 	uint64_t algorithmic_bytes;		/* SURVEY.md §8(d) bytes of this batch (reads + writes), see DESIGN.md */
 	uint64_t algorithmic_bytes_project;	/* the share of the projection kernel (k_project) alone */
-	float ms_project;				/* last launch durations (hipEvent), 0 if timing is disabled */
-	float ms_mate;
-	float ms_realign;
-	float ms_pack;
+	uint64_t n_fast_path;			/* records finished by the lane-parallel fast path of k_project_fast */
+	float ms_project;				/* k_project_fast: last launch duration (hipEvent), 0 if timing is disabled */
+	float ms_general;				/* k_project_general */
+	float ms_realign;				/* k_realign */
+	float ms_pack;					/* scans + gather */
 	uint32_t attempts;				/* 1 unless a workspace had to grow */
 	uint32_t reserved;
 } pvc3_batch_stats;
@@ -169,7 +170,7 @@ PVC3_API int pvc3_index_set_reference(pvc3_index *idx, uint32_t entry, char cons
 PVC3_API int pvc3_index_entry_count(pvc3_index const *idx, uint32_t *count);
 PVC3_API int pvc3_index_entry_info(pvc3_index const *idx, uint32_t entry, uint64_t *n_cols, uint64_t *n_non_gap);
 /* Host view of the HBM layout of one entry (for inspection and host-logic tests):
- * blocks = n_blocks x 8 uint64 {non-gap columns before the block, 7 x 64 gap bits}; sel[j] = column of non-gap #(64 j). */
+ * blocks = n_blocks x 8 uint64 {non-gap columns before the block, 7 x 64 gap bits}; sel[j] = column of non-gap #(4096 j). */
 PVC3_API int pvc3_index_entry_layout(pvc3_index const *idx, uint32_t entry, uint64_t const **blocks, uint64_t *n_blocks, uint32_t const **sel, uint64_t *n_sel);
 
 /* ---- device context ------------------------------------------------------------------------------------------------ */

@@ -199,9 +199,9 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	b->work.scratch_per_wave = ctx->scratch_per_wave;
 	HIP_TRY(hipMemsetAsync(b->work.counters, 0, sizeof(dev_counters), s));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
-	if (int const e = launch_project(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s)) return set_error(PVC3_E_HIP, "k_project launch: %s", hipGetErrorString((hipError_t) e));
+	if (int const e = launch_project_fast(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s)) return set_error(PVC3_E_HIP, "k_project_fast launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
-	// (mate projection is fused into k_project; the event pair is kept so that ms_mate reads 0)
+	if (int const e = launch_project_general(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_project_general launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	uint32_t const lds = ctx->realign_lds_bytes ? ctx->realign_lds_bytes : realign_lds_bytes();
 	if (int const e = launch_realign(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->d_params, ctx->realign_waves, lds, s)) return set_error(PVC3_E_HIP, "k_realign launch: %s", hipGetErrorString((hipError_t) e));
@@ -398,7 +398,15 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 		PVC3_TRY(dev_upload(&d.sel, e.sel.data(), e.sel.size(), 64, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
 		d.text = nullptr;
 		if (!e.text.empty())
-			PVC3_TRY(dev_upload(&d.text, (uint8_t const *) e.text.data(), e.text.size(), TEXT_PAD, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
+		{
+			// Front and back padding: the kernels read whole 16 / 32-byte pieces around the bases they need.
+			uint8_t *p{};
+			PVC3_TRY(dev_alloc(&p, TEXT_FRONT_PAD + e.text.size() + TEXT_PAD, &ctx->index_allocs, &ctx->index_bytes));
+			HIP_TRY(hipMemsetAsync(p, 0, TEXT_FRONT_PAD, ctx->stream));
+			HIP_TRY(hipMemcpyAsync(p + TEXT_FRONT_PAD, e.text.data(), e.text.size(), hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(hipMemsetAsync(p + TEXT_FRONT_PAD + e.text.size(), 0, TEXT_PAD, ctx->stream));
+			d.text = p + TEXT_FRONT_PAD;
+		}
 		d.n_cols = (uint32_t) e.n_cols;
 		d.n_zeros = (uint32_t) e.n_zeros;
 		d.text_len = (uint32_t) e.text.size();
@@ -575,6 +583,7 @@ int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stat
 		stats->n_records = b->n;
 		stats->n_failed = c.n_failed;
 		stats->n_realigned_records = c.n_realigned_records;
+		stats->n_fast_path = c.n_fast;
 		stats->n_runs = totals[1];
 		stats->out_cigar_total = totals[0];
 		// Algorithmic bytes (DESIGN.md "Algorithmic bytes per alignment"): what one pass must read and write at minimum.
@@ -599,7 +608,7 @@ int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stat
 		if (ctx->timing)
 		{
 			(void) hipEventElapsedTime(&stats->ms_project, ctx->ev[0], ctx->ev[1]);
-			(void) hipEventElapsedTime(&stats->ms_mate, ctx->ev[1], ctx->ev[2]);
+			(void) hipEventElapsedTime(&stats->ms_general, ctx->ev[1], ctx->ev[2]);
 			(void) hipEventElapsedTime(&stats->ms_realign, ctx->ev[2], ctx->ev[3]);
 			(void) hipEventElapsedTime(&stats->ms_pack, ctx->ev[3], ctx->ev[4]);
 		}

@@ -45,7 +45,7 @@ static void finish_entry(host_entry &e)
 		}
 	}
 	e.n_zeros = zeros;
-	e.sel.push_back((uint32_t) e.n_cols);	// sentinel so that sel[n_zeros / 64] is always readable
+	e.sel.push_back((uint32_t) e.n_cols);	// sentinel so that sel[n_zeros / SELECT_SAMPLE] is always readable
 }
 
 static int new_entry(pvc3_index *idx, uint64_t n_cols, host_entry **out)

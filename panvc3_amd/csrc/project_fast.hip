@@ -1,0 +1,362 @@
+// project_fast.hip — k_project_fast: lane = record.  First kernel of the hot path.
+//
+// For 64 records at a time per wavefront (coalesced SoA descriptor loads):
+//   1. validates the CIGAR and the positions (per-record status, same rules as the oracle's batch driver);
+//   2. aligned_position + project_aligned_position (include/panvc3/rewrite_cigar.hh:51-56): one select sample and two
+//      64-byte blocks of the source row give the start column, one block of the destination row the projected position;
+//   3. the mate's project_position (include/panvc3/msa_index.hh:253-258, project_alignments.cc:897-901);
+//   4. FAST PATH.  A record is "simple" when its CIGAR is [S|H] (M|=|X)+ [S|H] with non-zero counts, it consumes at most
+//      256 reference bases and neither row has a gap among the columns it spans (the ranks of both rows advance by exactly
+//      that many bases).  Then rewrite_cigar (rewrite_cigar.hh:80-118) degenerates to a byte compare of the query against the
+//      destination text: the lane builds the mismatch bit-mask with plain loads and emits the = / X runs itself
+//      (cigar_buffer semantics, libpanvc3/cigar.cc:54-95).  Such a record has no indel run, so it is finished.
+//   5. Every other valid record is handed to k_project_general (REC_SLOW; start column, projected position and
+//      reference-consuming length are left in the work arrays).
+#include <hip/hip_runtime.h>
+
+#include "pvc3_internal.hpp"
+#include "wave.hpp"
+#include "device_common.hpp"
+
+namespace pvc3 {
+
+namespace {
+
+constexpr uint32_t FAST_MAX_BASES = 256;
+constexpr uint32_t FAST_WORDS = FAST_MAX_BASES / 32;
+constexpr uint32_t LDS_ENTRIES = 256;
+
+typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
+
+__device__ __forceinline__ u64x2 load_u128_unaligned(uint8_t const *p)
+{
+	u64x2 v;
+	__builtin_memcpy(&v, p, 16);
+	return v;
+}
+
+// Packed BAM bases (high nibble first) -> nibble-linear: nibble n of the byte string at bits [4n, 4n + 4).
+__device__ __forceinline__ uint64_t nibble_linear(uint64_t w)
+{
+	return ((w & UINT64_C(0x0F0F0F0F0F0F0F0F)) << 4) | ((w >> 4) & UINT64_C(0x0F0F0F0F0F0F0F0F));
+}
+
+// Bit k set iff base k of q (8 BAM codes, 4 bits each; read through dna5::to_char) differs from raw text byte k of r (quirk Q3).
+__device__ __forceinline__ uint32_t mismatch8(uint32_t q, uint64_t r)
+{
+	// code -> index into "ACGTN" (1 2 4 8 -> 0 1 2 3, everything else -> 4), then the character itself.
+	constexpr uint64_t IDX = UINT64_C(0x4444444344424104);
+	constexpr uint64_t CHARS = UINT64_C(0x4E54474341);
+	uint32_t m = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < 8; ++k)
+	{
+		uint32_t const code = (q >> (4 * k)) & 0xf;
+		uint32_t const rb = (uint32_t) (r >> (8 * k)) & 0xff;
+		uint32_t const idx = (uint32_t) (IDX >> (4 * code)) & 0xf;
+		uint32_t const ch = (uint32_t) (CHARS >> (8 * idx)) & 0xff;
+		m |= (uint32_t) (ch != rb) << k;
+	}
+	return m;
+}
+
+// Mismatch bits of 32 consecutive query nibbles (16 bytes at q) against 32 text bytes at t.
+__device__ __forceinline__ uint32_t mismatch32(uint8_t const *q, uint8_t const *t)
+{
+	u64x2 const qq = load_u128_unaligned(q);
+	u64x2 const t0 = load_u128_unaligned(t), t1 = load_u128_unaligned(t + 16);
+	uint64_t const q0 = nibble_linear(qq.x), q1 = nibble_linear(qq.y);
+	return mismatch8((uint32_t) q0, t0.x) | (mismatch8((uint32_t) (q0 >> 32), t0.y) << 8)
+		| (mismatch8((uint32_t) q1, t1.x) << 16) | (mismatch8((uint32_t) (q1 >> 32), t1.y) << 24);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+	for (uint32_t off = 1; off < 64; off <<= 1)
+	{
+		uint32_t const t = (uint32_t) __shfl_up((int) v, (int) off);
+		if (lane >= off) v += t;
+	}
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+	for (int off = 32; off; off >>= 1)
+	{
+		uint32_t const o = (uint32_t) __shfl_xor((int) v, off);
+		v = (o > v) ? o : v;
+	}
+	return rfl(v);
+}
+
+__global__ __launch_bounds__(256) void k_project_fast(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W, uint32_t use_fast_path)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const wave = rfl((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	uint32_t const n_waves = (gridDim.x * blockDim.x) >> 6;
+	// Contiguous group range per wave: sequential descriptor reads and a sequentially filled arena chunk.
+	uint64_t const n_groups = (in.n + 63) / 64;
+	uint64_t const g_begin = n_groups * wave / n_waves;
+	uint64_t const g_end = n_groups * (wave + 1) / n_waves;
+	arena_alloc arena{0, 0};
+	uint32_t acc_failed = 0, acc_fast = 0;		// per lane
+
+	// The entry table is read by every lane of every group: keep its head in LDS.
+	__shared__ dev_entry lds_entries[LDS_ENTRIES];
+	for (uint32_t i = threadIdx.x; i < LDS_ENTRIES && i < n_entries; i += blockDim.x)
+		lds_entries[i] = entries[i];
+	__syncthreads();
+	auto get_entry = [&](uint32_t id) -> dev_entry { return (id < LDS_ENTRIES) ? lds_entries[id] : entries[id]; };
+	uint64_t acc_bitvec = 0, acc_ref = 0;
+
+	for (uint64_t g = g_begin; g < g_end; ++g)
+	{
+		uint64_t const rec = g * 64 + lane;
+		bool const valid = rec < in.n;
+		uint64_t const rl = valid ? rec : (in.n - 1);		// clamped index: every lane issues the same loads
+
+		// ---- descriptors (coalesced) -------------------------------------------------------------------------------------------
+		uint32_t const src_pos = in.src_pos[rl];
+		uint32_t const src_e = in.src_entry[rl];
+		uint32_t const dst_e = in.dst_entry[rl];
+		uint32_t const fl = in.flags[rl];
+		uint64_t const cig_begin = in.cigar_off[rl];
+		uint32_t const n_cigar = (uint32_t) (in.cigar_off[rl + 1] - cig_begin);
+		uint64_t const seq_begin = in.seq_off[rl];
+		uint32_t const l_seq = in.l_seq[rl];
+		bool const has_mate = valid && in.mate_pos && (fl & PVC3_FLAG_HAS_MATE);
+		uint32_t const mate_se = has_mate ? in.mate_src_entry[rl] : 0;
+		uint32_t const mate_de = has_mate ? in.mate_dst_entry[rl] : 0;
+		uint32_t const mate_pos = has_mate ? in.mate_pos[rl] : 0;
+
+		bool const e_ok = (src_e < n_entries) && (dst_e < n_entries);
+		dev_entry const S = get_entry(e_ok ? src_e : 0);
+		dev_entry const D = get_entry(e_ok ? dst_e : 0);
+		uint64_t const *s_blocks = S.blocks;
+		uint32_t const *s_sel = S.sel;
+		uint32_t const s_zeros = S.n_zeros, s_cols = S.n_cols;
+		uint64_t const *d_blocks = D.blocks;
+		uint8_t const *d_text = D.text;
+		uint32_t const d_text_len = D.text_len, d_cols = D.n_cols;
+
+		// ---- CIGAR: validation + shape automaton of the fast path (first four operations from one 16-byte load) ----------------
+		uint32_t const *ops = in.cigar + cig_begin;
+		typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+		u32x4 pre4;
+		__builtin_memcpy(&pre4, ops, 16);					// the CIGAR buffer is padded by the host side
+		uint32_t const pre[4] = {pre4.x, pre4.y, pre4.z, pre4.w};
+		uint32_t ref_consumed = 0, query_consumed = 0, shape = 0, lead = 0, trail = 0;
+		bool bad_op = false;
+		auto step = [&](uint32_t c) {
+			uint32_t const op = c & 0xf, n = c >> 4;
+			bool const m_type = (OP_M == op || OP_EQ == op || OP_X == op);
+			bool const clip = (OP_S == op || OP_H == op);
+			bad_op = bad_op || (op > OP_X);					// any bad operation rejects the record, the counts are then unused
+			ref_consumed += (m_type || OP_D == op || OP_N == op) ? n : 0;
+			query_consumed += (m_type || OP_I == op || OP_S == op) ? n : 0;
+			// 0 start, 1 after the leading clip, 2 inside the M-type span, 3 after the trailing clip, 4 not simple
+			uint32_t next = 4;
+			if (0 != n)
+			{
+				if (m_type && shape <= 2) next = 2;
+				else if (clip && 0 == shape) { next = 1; lead = c; }
+				else if (clip && 2 == shape) { next = 3; trail = c; }
+			}
+			shape = next;
+		};
+#pragma unroll
+		for (uint32_t i = 0; i < 4; ++i)
+			if (i < n_cigar) step(pre[i]);
+		for (uint32_t i = 4; i < n_cigar; ++i)
+			step(ops[i]);
+
+		uint32_t status = PVC3_ST_OK;
+		if (!e_ok) status = PVC3_ST_SRC_RANGE;
+		else if (bad_op) status = PVC3_ST_CIGAR_OP;
+		else if (s_cols != d_cols || (uint64_t) src_pos + (ref_consumed ? ref_consumed : 1u) > s_zeros) status = PVC3_ST_SRC_RANGE;
+		else if (query_consumed > l_seq) status = PVC3_ST_QUERY_RANGE;
+		bool const ok = valid && (PVC3_ST_OK == status);
+
+		// ---- start column and projected position (rewrite_cigar.hh:51-56) --------------------------------------------------------
+		uint32_t col = 0, r0 = 0;
+		bool fast = false;
+		uint32_t const lead_q = (OP_S == (lead & 0xf)) ? (lead >> 4) : 0;	// query bases before the M-type span
+		uint32_t const phase = lead_q & 1;
+		if (ok)
+		{
+			block_regs Sc;
+			uint32_t sel_blk;
+			col = thread_select0(s_blocks, s_sel, src_pos, Sc, sel_blk);
+			col_pos const p0 = split_col(col);
+			col_pos const p1 = split_col(col + ref_consumed);
+			block_regs const Dc = load_block(d_blocks, p0.blk);
+			// The end column usually shares the block of the start column: reuse the registers, load only otherwise.
+			block_regs De = Dc, Se = Sc;
+			if (p1.blk != p0.blk)
+			{
+				De = load_block(d_blocks, p1.blk);
+				Se = load_block(s_blocks, p1.blk);
+			}
+			r0 = block_rank(Dc, p0.w, p0.bit);
+			// No gap column in either row over the span <=> both ranks advance by exactly ref_consumed.
+			bool const gapless = (block_rank(Se, p1.w, p1.bit) == src_pos + ref_consumed) && (block_rank(De, p1.w, p1.bit) == r0 + ref_consumed);
+			bool const simple = (2 == shape || 3 == shape);
+			fast = use_fast_path && simple && gapless && (ref_consumed + phase <= FAST_MAX_BASES) && d_text && ((uint64_t) r0 + ref_consumed <= d_text_len);
+		}
+
+		// ---- mate (project_alignments.cc:897-901) -----------------------------------------------------------------------------------
+		// project_position is a pure function of (entries, position).  When the mate is the neighbouring record of the batch
+		// (pairs stored back to back) its projected position has just been computed by the neighbouring lane.
+		uint32_t mate = PVC3_NO_MATE;
+		{
+			uint32_t const n_se = (uint32_t) __shfl_xor((int) src_e, 1), n_de = (uint32_t) __shfl_xor((int) dst_e, 1);
+			uint32_t const n_pos = (uint32_t) __shfl_xor((int) src_pos, 1), n_r0 = (uint32_t) __shfl_xor((int) r0, 1);
+			bool const n_ok = 0 != __shfl_xor((int) ok, 1);
+			bool const from_neighbour = has_mate && n_ok && (mate_se == n_se) && (mate_de == n_de) && (mate_pos == n_pos);
+			if (from_neighbour)
+				mate = n_r0;
+			else if (has_mate && mate_se < n_entries && mate_de < n_entries)
+				mate = thread_project_position(get_entry(mate_se), get_entry(mate_de), mate_pos);
+		}
+
+		// ---- fast path ------------------------------------------------------------------------------------------------------------------
+		uint32_t f_n_out = 0;
+		uint64_t f_loc = 0;
+		if (ballot(fast))
+		{
+			uint32_t const R = fast ? ref_consumed : 0;
+			// Work in query-nibble positions u = t + phase counted from a byte boundary of SEQ, so that 32 positions are exactly
+			// 16 bytes of SEQ and 32 bytes of text; the mask is shifted back by `phase` afterwards.
+			uint32_t const U = fast ? (R + phase) : 0;
+			uint8_t const *qp = in.seq4 + seq_begin + (lead_q >> 1);
+			uint8_t const *tp = d_text + r0 - phase;		// texts have TEXT_FRONT_PAD readable bytes in front
+			uint32_t const n_words = (wave_max(U) + 31) / 32;
+			uint32_t mu[FAST_WORDS + 1];
+#pragma unroll
+			for (uint32_t w = 0; w < FAST_WORDS; ++w)
+			{
+				mu[w] = 0;
+				if (w < n_words)
+				{
+					uint32_t m = 0;
+					if (32 * w < U)		// per lane: loads stay inside the record (+ at most 31 positions of padding)
+						m = mismatch32(qp + 16 * w, tp + 32 * w);
+					uint32_t const left = (U > 32 * w) ? (U - 32 * w) : 0;
+					mu[w] = m & (uint32_t) low_mask(left < 32 ? left : 32);
+				}
+			}
+			mu[FAST_WORDS] = 0;
+			// Back to base positions: drop the `phase` leading positions.
+			uint32_t mm[FAST_WORDS];
+#pragma unroll
+			for (uint32_t w = 0; w < FAST_WORDS; ++w)
+				mm[w] = __builtin_amdgcn_alignbit(mu[w + 1], mu[w], phase);
+			// Number of runs = 1 + number of positions whose bit differs from the previous one.
+			uint32_t runs = fast ? 1 : 0;
+			uint32_t prev_top = mm[0] & 1;		// makes position 0 a non-transition
+#pragma unroll
+			for (uint32_t w = 0; w < FAST_WORDS; ++w)
+			{
+				if (w < n_words)
+				{
+					uint32_t const left = (R > 32 * w) ? (R - 32 * w) : 0;
+					uint32_t const vmask = (uint32_t) low_mask(left < 32 ? left : 32);
+					uint32_t const tr = (mm[w] ^ ((mm[w] << 1) | prev_top)) & vmask;
+					runs += (uint32_t) __builtin_popcount(tr);
+					prev_top = mm[w] >> 31;
+				}
+			}
+			f_n_out = fast ? (runs + (lead ? 1 : 0) + (trail ? 1 : 0)) : 0;
+			uint32_t const scan = wave_inclusive_scan(f_n_out, lane);
+			uint32_t const total = readlane(scan, 63);
+			uint64_t base_loc = 0;
+			bool const have = arena_take(arena, total, W, lane, base_loc);
+			if (!have) f_n_out = 0;		// arena overflow: the host grows it and repeats the batch
+			f_loc = base_loc + (scan - f_n_out);
+			if (have && fast)
+			{
+				uint32_t *dst = W.arena + f_loc;
+				uint32_t k = 0;
+				if (lead) dst[k++] = lead;
+				uint32_t start = 0, type = mm[0] & 1;
+				prev_top = type;
+#pragma unroll
+				for (uint32_t w = 0; w < FAST_WORDS; ++w)
+				{
+					if (w < n_words)
+					{
+						uint32_t const left = (R > 32 * w) ? (R - 32 * w) : 0;
+						uint32_t const vmask = (uint32_t) low_mask(left < 32 ? left : 32);
+						uint32_t tr = (mm[w] ^ ((mm[w] << 1) | prev_top)) & vmask;
+						prev_top = mm[w] >> 31;
+						while (tr)
+						{
+							uint32_t const pos = 32 * w + (uint32_t) __builtin_ctz(tr);
+							dst[k++] = ((pos - start) << 4) | (type ? OP_X : OP_EQ);
+							start = pos; type ^= 1;
+							tr &= tr - 1;
+						}
+					}
+				}
+				dst[k++] = ((R - start) << 4) | (type ? OP_X : OP_EQ);
+				if (trail) dst[k++] = trail;
+				acc_bitvec += 2 * ((R + 8) / 8);
+				acc_ref += R;
+				acc_fast += 1;
+			}
+		}
+
+		// ---- per-record outputs (coalesced) ----------------------------------------------------------------------------------------------
+		if (valid)
+		{
+			bool const slow = ok && !fast;
+			W.mate_dst_pos[rec] = mate;
+			W.dst_pos[rec] = ok ? r0 : 0;		// a rejected record has empty outputs
+			W.rec_flags[rec] = slow ? REC_SLOW : status;
+			W.cig_n[rec] = f_n_out;
+			W.cig_loc[rec] = slow ? ((uint64_t) col | ((uint64_t) ref_consumed << 32)) : f_loc;
+			W.run_n[rec] = 0;
+			acc_failed += (PVC3_ST_OK != status);
+		}
+	}
+
+	// Per-lane accumulators -> wave totals -> one atomic each.
+	for (int off = 32; off; off >>= 1)
+	{
+		acc_bitvec += __shfl_xor(acc_bitvec, off);
+		acc_ref += __shfl_xor(acc_ref, off);
+		acc_failed += __shfl_xor(acc_failed, off);
+		acc_fast += __shfl_xor(acc_fast, off);
+	}
+	if (0 == lane)
+	{
+		if (acc_bitvec) atomicAdd(&W.counters->bitvec_bytes, (unsigned long long) acc_bitvec);
+		if (acc_ref) atomicAdd(&W.counters->ref_bytes, (unsigned long long) acc_ref);
+		if (acc_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) acc_failed);
+		if (acc_fast) atomicAdd(&W.counters->n_fast, (unsigned long long) acc_fast);
+	}
+}
+
+uint32_t grid_blocks(uint64_t n)
+{
+	// Persistent waves: 4 waves per block, at most 8 blocks per CU; at least one group of 64 records per wave.
+	uint64_t const groups = (n + 63) / 64;
+	uint64_t const blocks = (groups + 3) / 4;
+	return (uint32_t) (blocks < 1 ? 1 : (blocks > 256 * 8 ? 256 * 8 : blocks));
+}
+
+}	// anonymous namespace
+
+uint32_t project_wave_count(uint64_t n) { return 4 * grid_blocks(n); }
+
+int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream)
+{
+	if (0 == in.n) return 0;
+	hipLaunchKernelGGL(k_project_fast, dim3(grid_blocks(in.n)), dim3(256), 0, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
+	return (int) hipGetLastError();
+}
+
+}

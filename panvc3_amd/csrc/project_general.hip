@@ -1,0 +1,101 @@
+// project_general.hip — k_project_general: the column walk (walk.hpp) for the records the fast kernel left behind.
+//
+// k_project_fast marks such records with REC_SLOW and leaves their start column, projected position and reference-consuming
+// length in the work arrays.  Every wave scans the flags of 64 consecutive records at a time (coalesced), gathers the
+// descriptors of the marked ones lane-parallel and then walks them one by one, with the loads of the next record in flight.
+#include <hip/hip_runtime.h>
+
+#include "walk.hpp"
+
+namespace pvc3 {
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_project_general(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const wave = rfl((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	uint32_t const n_waves = (gridDim.x * blockDim.x) >> 6;
+	uint64_t const n_groups = (in.n + 63) / 64;
+	uint64_t const g_begin = n_groups * wave / n_waves;
+	uint64_t const g_end = n_groups * (wave + 1) / n_waves;
+	arena_alloc arena{0, 0};
+	group_out G;
+	G.n_failed = 0; G.n_with_runs = 0; G.bitvec_bytes = 0; G.ref_bytes = 0;
+
+	for (uint64_t g = g_begin; g < g_end; ++g)
+	{
+		uint64_t const rec = g * 64 + lane;
+		uint32_t const fl = (rec < in.n) ? W.rec_flags[rec] : 0;
+		bool const mine = 0 != (fl & REC_SLOW);
+		uint64_t todo = ballot(mine);
+		if (!todo)
+			continue;
+
+		lane_state A;
+		A.status = PVC3_ST_OK; A.col = 0; A.r0 = 0; A.ref_consumed = 0; A.n_cigar = 0; A.l_seq = 0; A.src_e = 0; A.dst_e = 0; A.src_pos = 0;
+		A.cig_begin = 0; A.seq_begin = 0;
+		if (mine)
+		{
+			A.src_pos = in.src_pos[rec];
+			A.src_e = in.src_entry[rec];
+			A.dst_e = in.dst_entry[rec];
+			A.cig_begin = in.cigar_off[rec];
+			A.n_cigar = (uint32_t) (in.cigar_off[rec + 1] - A.cig_begin);
+			A.seq_begin = in.seq_off[rec];
+			A.l_seq = in.l_seq[rec];
+			uint64_t const stash = W.cig_loc[rec];		// left by k_project_fast: start column | reference-consuming length << 32
+			A.col = (uint32_t) stash;
+			A.ref_consumed = (uint32_t) (stash >> 32);
+			A.r0 = W.dst_pos[rec];
+		}
+
+		G.flags = 0; G.cig_n = 0; G.loc_lo = 0; G.loc_hi = 0;
+		rec_ctx C0, C1;
+		rec_loads L0, L1;
+		rec_out R;
+		uint32_t i0 = ctz64(todo), i1 = 0;
+		todo &= todo - 1;
+		stage_load(entries, in, A, i0, lane, C0, L0);
+		for (;;)
+		{
+			bool const has1 = (0 != todo);
+			if (has1) { i1 = ctz64(todo); todo &= todo - 1; stage_load(entries, in, A, i1, lane, C1, L1); }
+			walk_record(entries, C0, L0, W, arena, lane, R);
+			G.put(i0, R);
+			if (!has1) break;
+			bool const has0 = (0 != todo);
+			if (has0) { i0 = ctz64(todo); todo &= todo - 1; stage_load(entries, in, A, i0, lane, C0, L0); }
+			walk_record(entries, C1, L1, W, arena, lane, R);
+			G.put(i1, R);
+			if (!has0) break;
+		}
+
+		if (mine)
+		{
+			bool const ok = (0 == (G.flags & REC_STATUS_MASK));
+			if (!ok) W.dst_pos[rec] = 0;		// a rejected record has empty outputs
+			W.rec_flags[rec] = G.flags;
+			W.cig_n[rec] = G.cig_n;
+			W.cig_loc[rec] = ((uint64_t) G.loc_hi << 32) | G.loc_lo;
+		}
+	}
+	if (0 == lane)
+	{
+		if (G.bitvec_bytes) atomicAdd(&W.counters->bitvec_bytes, (unsigned long long) G.bitvec_bytes);
+		if (G.ref_bytes) atomicAdd(&W.counters->ref_bytes, (unsigned long long) G.ref_bytes);
+		if (G.n_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) G.n_failed);
+		if (G.n_with_runs) atomicAdd(&W.counters->n_realigned_records, (unsigned long long) G.n_with_runs);
+	}
+}
+
+}	// anonymous namespace
+
+int launch_project_general(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream)
+{
+	if (0 == in.n) return 0;
+	hipLaunchKernelGGL(k_project_general, dim3(project_wave_count(in.n) / 4), dim3(256), 0, (hipStream_t) stream, entries, n_entries, in, work);
+	return (int) hipGetLastError();
+}
+
+}

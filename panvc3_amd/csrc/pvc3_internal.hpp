@@ -13,15 +13,16 @@ namespace pvc3 {
 // A sequence entry (msa_index::sequence_entry, include/panvc3/msa_index.hh:47-74) is stored as 64-byte blocks:
 //   word 0      number of non-gap columns ("zeros") before the block  -> rank0 in one cache line
 //   words 1..7  448 gap bits (1 = gap), bit (c & 63) of word 1 + ((c % 448) >> 6)
-// plus one select sample per 64 zeros (the column of zero number 64 j).  Two all-gap padding blocks follow the
+// plus one select sample per SELECT_SAMPLE zeros (the column of zero number SELECT_SAMPLE * j).  Two all-gap padding blocks follow the
 // last real block so that a two-block window load never leaves the allocation.
 constexpr uint32_t BLOCK_WORDS = 8;
 constexpr uint32_t BLOCK_DATA_WORDS = 7;
 constexpr uint32_t BLOCK_COLS = 448;
 constexpr uint32_t PAD_BLOCKS = 2;
-constexpr uint32_t SELECT_SAMPLE = 64;
-constexpr uint32_t SELECT_SAMPLE_SHIFT = 6;
+constexpr uint32_t SELECT_SAMPLE = 4096;	// one select sample per 4096 non-gap columns: the table (4 B per 4096 bases) stays cache resident
+constexpr uint32_t SELECT_SAMPLE_SHIFT = 12;
 constexpr uint32_t TEXT_PAD = 512;		// bytes readable past the end of a device text
+constexpr uint32_t TEXT_FRONT_PAD = 16;	// bytes readable before its start
 
 struct host_entry
 {
@@ -79,6 +80,7 @@ struct dev_counters
 	unsigned long long bitvec_bytes;	// sum over records of 2 * ceil(columns walked / 8)
 	unsigned long long ref_bytes;		// sum over records of destination characters spanned
 	unsigned long long qual_bytes;		// sum of l_seq over realigned records
+	unsigned long long n_fast;			// records finished by the lane-parallel fast path
 };
 
 // Per-record results before packing.  flags: bits 0-7 status, bit 8 = has at least one indel run.
@@ -113,6 +115,7 @@ struct dev_batch_packed
 
 constexpr uint32_t REC_STATUS_MASK = 0xffu;
 constexpr uint32_t REC_HAS_RUN = 0x100u;
+constexpr uint32_t REC_SLOW = 0x200u;		// left by k_project_fast for k_project_general
 
 struct dev_params
 {
@@ -125,7 +128,8 @@ struct dev_params
 };
 
 // Launch wrappers (kernels.hip).  All enqueue on `stream` and return a hipError_t as int.
-int launch_project(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream);
+int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream);
+int launch_project_general(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
 int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream);
 int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &packed, uint64_t *scan_tmp, void *stream);
 int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);

@@ -122,13 +122,16 @@ __device__ __forceinline__ uint32_t window_rank_dst(window const &win, col_pos c
 }
 
 // Column of non-gap number k (0-based) of the src vector, i.e. select0(k + 1) in sdsl terms (msa_index.hh:239-243).
-// Requires k < n_zeros.  Leaves `win` covering the block of the result.
+// Requires k < n_zeros.  Leaves `win` covering the block of the result.  (Cooperative form, used by the general walk only
+// on its rare spill path; the per-record start column comes from the lane-parallel thread_select0.)
 __device__ __forceinline__ uint32_t wave_select0(dev_entry const &S, uint64_t const *dst_blocks, uint32_t k, window &win, uint32_t lane)
 {
 	uint32_t const col0 = S.sel[k >> SELECT_SAMPLE_SHIFT];
-	uint32_t rem = k & (SELECT_SAMPLE - 1);
-	col_pos p = split_col(col0);
+	// The target lies at least (k mod SELECT_SAMPLE) columns right of the sample: its block cannot be left of this one.
+	col_pos p;
+	p.blk = (col0 + (k & (SELECT_SAMPLE - 1))) / BLOCK_COLS; p.w = 0; p.bit = 0;
 	window_load(win, S.blocks, dst_blocks, p.blk, lane);
+	uint32_t rem = k - readlane(win.lo, 0);
 	for (;;)
 	{
 		if (p.blk - win.b0 >= 2)
@@ -159,43 +162,96 @@ __device__ __forceinline__ uint32_t wave_select0(dev_entry const &S, uint64_t co
 	}
 }
 
-// One thread: column of non-gap number pos (0-based); requires pos < n_zeros.
-__device__ __forceinline__ uint32_t thread_select0(uint64_t const *__restrict__ blocks, uint32_t const *__restrict__ sel, uint32_t pos)
+// ---- one lane on its own record: whole 64-byte blocks in registers, branch-free inside a block -------------------------
+// (A loop with one dependent load per iteration would serialise HBM round trips; loading the block at once keeps them
+// independent and lets many lanes' misses overlap.)
+struct block_regs
 {
-	uint32_t const col0 = sel[pos >> SELECT_SAMPLE_SHIFT];
-	uint32_t rem = pos & (SELECT_SAMPLE - 1);
-	col_pos p = split_col(col0);
-	for (;;)
-	{
-		uint64_t const z = ~blocks[(uint64_t) p.blk * BLOCK_WORDS + 1 + p.w] & (~UINT64_C(0) << p.bit);
-		uint32_t const cnt = popc64(z);
-		if (rem < cnt)
-			return p.blk * BLOCK_COLS + p.w * 64 + thread_select_in_word(z, rem);
-		rem -= cnt;
-		p.bit = 0;
-		if (++p.w == BLOCK_DATA_WORDS)
-		{
-			p.w = 0; ++p.blk;
-			while ((uint32_t) blocks[(uint64_t) (p.blk + 1) * BLOCK_WORDS] <= pos)	// skip blocks that end before zero #pos
-				++p.blk;
-			rem = pos - (uint32_t) blocks[(uint64_t) p.blk * BLOCK_WORDS];
-		}
-	}
-}
+	uint64_t w[BLOCK_WORDS];	// w[0] = non-gap columns before the block, w[1..7] = gap bits
+};
 
-// One thread: rank0 at column col (number of non-gap columns before col).
-__device__ __forceinline__ uint32_t thread_rank0(uint64_t const *__restrict__ blocks, uint32_t col)
+__device__ __forceinline__ block_regs load_block(uint64_t const *__restrict__ blocks, uint32_t b)
 {
-	col_pos const q = split_col(col);
-	uint64_t const *blk = blocks + (uint64_t) q.blk * BLOCK_WORDS;
-	uint32_t r = (uint32_t) blk[0];
-	for (uint32_t i = 0; i < q.w; ++i)
-		r += popc64(~blk[1 + i]);
-	r += popc64(~blk[1 + q.w] & low_mask(q.bit));
+	typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
+	u64x2 const *p = (u64x2 const *) (blocks + (uint64_t) b * BLOCK_WORDS);
+	u64x2 const a = p[0], c = p[1], d = p[2], e = p[3];
+	block_regs r;
+	r.w[0] = a.x; r.w[1] = a.y; r.w[2] = c.x; r.w[3] = c.y; r.w[4] = d.x; r.w[5] = d.y; r.w[6] = e.x; r.w[7] = e.y;
 	return r;
 }
 
-// One thread: project_position (msa_index.hh:253-258) = rank0_dst(select0_src(pos + 1)).
+// rank0 at (data word w, bit) of a block held in registers.
+__device__ __forceinline__ uint32_t block_rank(block_regs const &B, uint32_t w, uint32_t bit)
+{
+	uint32_t r = (uint32_t) B.w[0];
+#pragma unroll
+	for (uint32_t i = 0; i < BLOCK_DATA_WORDS; ++i)
+	{
+		uint64_t const m = (i < w) ? ~UINT64_C(0) : ((i == w) ? low_mask(bit) : UINT64_C(0));
+		r += popc64(~B.w[1 + i] & m);
+	}
+	return r;
+}
+
+// The rem-th (0-based) non-gap column at or after (w_s, bit_s) inside the block.  Returns true and the column offset
+// inside the block, or false with rem reduced by the non-gap columns seen.
+__device__ __forceinline__ bool block_select(block_regs const &B, uint32_t w_s, uint32_t bit_s, uint32_t &rem, uint32_t &off)
+{
+	bool found = false;
+	uint64_t z_hit = 0;
+	uint32_t w_hit = 0, rem_hit = 0;
+#pragma unroll
+	for (uint32_t i = 0; i < BLOCK_DATA_WORDS; ++i)
+	{
+		uint64_t const m = (i < w_s) ? UINT64_C(0) : ((i == w_s) ? (~UINT64_C(0) << bit_s) : ~UINT64_C(0));
+		uint64_t const z = ~B.w[1 + i] & m;
+		uint32_t const c = popc64(z);
+		bool const hit = !found && (rem < c);
+		z_hit = hit ? z : z_hit;
+		w_hit = hit ? i : w_hit;
+		rem_hit = hit ? rem : rem_hit;
+		found = found || hit;
+		rem = found ? rem : (rem - c);
+	}
+	off = 64 * w_hit + thread_select_in_word(z_hit, rem_hit);
+	return found;
+}
+
+// One lane: column of non-gap number pos (0-based); requires pos < n_zeros.  The select sample is the column of non-gap
+// number SELECT_SAMPLE * (pos / SELECT_SAMPLE); the target lies at least rem = pos % SELECT_SAMPLE columns further, so the
+// block of (sample + rem) cannot be past the target's block and, gaps being rare, nearly always IS the target's block: one
+// 64-byte load.  Its rank word tells how many non-gap columns to skip inside it; if the target is further right (gaps in
+// between), the deficit gives the next lower bound.  The block that holds the result is returned in B / blk for reuse.
+__device__ __forceinline__ uint32_t thread_select0(uint64_t const *__restrict__ blocks, uint32_t const *__restrict__ sel, uint32_t pos, block_regs &B, uint32_t &blk)
+{
+	uint32_t const col0 = sel[pos >> SELECT_SAMPLE_SHIFT];
+	blk = (col0 + (pos & (SELECT_SAMPLE - 1))) / BLOCK_COLS;
+	for (;;)
+	{
+		B = load_block(blocks, blk);
+		uint32_t rem = pos - (uint32_t) B.w[0];		// non-gap columns to skip inside this block (rank word <= pos by construction)
+		uint32_t off = 0;
+		if (block_select(B, 0, 0, rem, off))
+			return blk * BLOCK_COLS + off;
+		blk += 1 + rem / BLOCK_COLS;				// rem = non-gap columns still missing: at least that many columns further
+	}
+}
+
+__device__ __forceinline__ uint32_t thread_select0(uint64_t const *__restrict__ blocks, uint32_t const *__restrict__ sel, uint32_t pos)
+{
+	block_regs B;
+	uint32_t blk;
+	return thread_select0(blocks, sel, pos, B, blk);
+}
+
+// One lane: rank0 at column col (number of non-gap columns before col).
+__device__ __forceinline__ uint32_t thread_rank0(uint64_t const *__restrict__ blocks, uint32_t col)
+{
+	col_pos const q = split_col(col);
+	return block_rank(load_block(blocks, q.blk), q.w, q.bit);
+}
+
+// One lane: project_position (msa_index.hh:253-258) = rank0_dst(select0_src(pos + 1)).
 __device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, dev_entry const &D, uint32_t pos)
 {
 	if (pos >= S.n_zeros || S.n_cols != D.n_cols)

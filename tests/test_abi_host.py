@@ -56,15 +56,15 @@ def _check_layout(idx, e, aligned):
 	zeros_before = np.concatenate([[0], np.cumsum(per_block_zeros)[:-1]])
 	assert np.array_equal(blocks[:, 0], zeros_before.astype(np.uint64))
 	zero_cols = np.flatnonzero(~gaps)
-	assert sel.size == (n_zeros + 63) // 64 + 1
-	assert np.array_equal(sel[:-1], zero_cols[::64].astype(np.uint32))
+	assert sel.size == (n_zeros + 4095) // 4096 + 1		# one select sample per 4096 non-gap columns + sentinel
+	assert np.array_equal(sel[:-1], zero_cols[::4096].astype(np.uint32))
 	assert sel[-1] == n
 
 
 def test_index_layout_small_and_ragged():
 	rng = np.random.default_rng(11)
 	idx = panvc3_amd.Index()
-	for n in (1, 63, 64, 447, 448, 449, 896, 1000, 5000):
+	for n in (1, 63, 64, 447, 448, 449, 896, 1000, 5000, 20000):
 		for p_gap in (0.0, 0.3, 1.0):
 			s = "".join("-" if x else "ACGT"[i & 3] for i, x in enumerate(rng.random(n) < p_gap))
 			_check_layout(idx, idx.add_aligned(s), s)
@@ -90,8 +90,8 @@ def test_index_layout_shipped_msa_matches_oracle(oracle_mod):
 		# rank words and select samples agree with the oracle's rank0 / select0
 		for b in range(0, blocks.shape[0] - 2, 3):
 			assert blocks[b, 0] == o.rank0(oe, b * 448)
-		for j in range(0, sel.size - 1, 7):
-			assert sel[j] == o.select0(oe, 64 * j + 1)
+		for j in range(0, sel.size - 1):
+			assert sel[j] == o.select0(oe, 4096 * j + 1)
 
 
 def test_set_reference_validates_length():

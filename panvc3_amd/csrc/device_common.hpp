@@ -72,8 +72,15 @@ struct sink
 		cur_op = 0xf; cur_cnt = 0; n_out = 0; run_type = 0; has_run = 0; buf0 = buf1 = buf2 = 0; spill = nullptr;
 	}
 
+	__device__ __forceinline__ void make_uniform()
+	{
+		cur_op = rfl(cur_op); cur_cnt = rfl(cur_cnt); n_out = rfl(n_out); run_type = rfl(run_type); has_run = rfl(has_run);
+		spill = rfl_ptr(spill);
+	}
+
 	__device__ __forceinline__ void flush(uint32_t lane)
 	{
+		make_uniform();
 		uint32_t const enc = (cur_cnt << 4) | cur_op;
 		if (spill)
 		{
@@ -92,7 +99,9 @@ struct sink
 	// cigar.cc:61-87 (the first push finds cur_cnt == 0 and an impossible cur_op).
 	__device__ __forceinline__ void push(uint32_t op, uint32_t cnt, uint32_t lane)
 	{
+		op = rfl(op); cnt = rfl(cnt);
 		if (0 == cnt) return;
+		make_uniform();
 		if (cur_op == op) cur_cnt += cnt;
 		else
 		{

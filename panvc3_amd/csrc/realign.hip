@@ -18,7 +18,7 @@ namespace pvc3 {
 
 namespace {
 
-constexpr uint32_t REALIGN_LDS_BYTES = 32768;
+constexpr uint32_t REALIGN_LDS_BYTES = 8192;		// per wave (= per block); larger alignments use the wave's global scratch slot
 constexpr uint32_t TR_DIAG = 0, TR_UP = 1, TR_LEFT = 2, TR_DIR_MASK = 3, TR_V_OPEN = 4, TR_H_OPEN = 8;
 constexpr uint32_t MAX_PHRED = 41;
 
@@ -34,15 +34,25 @@ __device__ __forceinline__ uint32_t dna5_rank_of_seq4(uint32_t code)
 	return (1 == code) ? 0 : (2 == code) ? 1 : (4 == code) ? 2 : (8 == code) ? 4 : 3;
 }
 
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t lane)
+{
+	return ((uint64_t) readlane((uint32_t) (v >> 32), lane) << 32) | readlane((uint32_t) v, lane);
+}
+
 __device__ __forceinline__ uint32_t seq4_at(uint8_t const *seq4, uint32_t i)
 {
 	uint32_t const b = seq4[i >> 1];
 	return (i & 1) ? (b & 0xf) : (b >> 4);
 }
 
+// Lane i receives lane i - 1's value (lane 0 keeps its own): DPP wave_shr:1, no LDS round trip.
 __device__ __forceinline__ double shfl_up_f64(double v)
 {
-	return __shfl_up(v, 1);
+	union { double d; int i[2]; } a, r;
+	a.d = v;
+	r.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], 0x138, 0xf, 0xf, false);
+	r.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], 0x138, 0xf, 0xf, false);
+	return r.d;
 }
 
 struct dp_memory
@@ -52,11 +62,12 @@ struct dp_memory
 	double *bnd_v;		// V(i0, j)
 	uint8_t *trace;		// n * m bytes
 	uint8_t *rev;		// m + n bytes
+	uint8_t *ref_rank;	// m bytes: dna5 ranks of the reference slice
 };
 
 __device__ __forceinline__ uint64_t dp_bytes(uint32_t m, uint32_t n)
 {
-	return 8ull * (n + 1) + 16ull * (m + 1) + (uint64_t) m * n + (m + n) + 8;
+	return 8ull * (n + 1) + 16ull * (m + 1) + (uint64_t) m * n + (m + n) + m + 8;
 }
 
 __device__ __forceinline__ dp_memory dp_carve(uint8_t *base, uint32_t m, uint32_t n)
@@ -67,6 +78,7 @@ __device__ __forceinline__ dp_memory dp_carve(uint8_t *base, uint32_t m, uint32_
 	d.bnd_v = d.bnd_m + (m + 1);
 	d.trace = (uint8_t *) (d.bnd_v + (m + 1));
 	d.rev = d.trace + (uint64_t) m * n;
+	d.ref_rank = d.rev + (m + n);
 	return d;
 }
 
@@ -80,6 +92,10 @@ __device__ __forceinline__ void align_global(
 	double const go = (double) prm->gap_open + (double) prm->gap_ext;	// seqan3's internal gap-open score = open + extension
 	double const ge = (double) prm->gap_ext;
 	double const neg_inf = -__builtin_inf();
+
+	// Reference slice -> dna5 ranks, once (a global load per DP step would put an HBM round trip on the critical path).
+	for (uint32_t j = lane; j < m; j += 64)
+		mem.ref_rank[j] = (uint8_t) dna5_rank_of_char(ref[j]);
 
 	// First column and first row, serially (initialise_first_column_cell / initialise_first_row_cell).
 	if (0 == lane)
@@ -140,7 +156,7 @@ __device__ __forceinline__ void align_global(
 			if (active)
 			{
 				if (0 == lane) { up_m = mem.bnd_m[j]; up_v = mem.bnd_v[j]; }
-				uint32_t const r_rank = dna5_rank_of_char(ref[j - 1]);
+				uint32_t const r_rank = mem.ref_rank[j - 1];
 				double const s = (r_rank == q_rank) ? s_match : s_mismatch;
 				uint32_t tr = 0;
 				double const v_open = up_m + go, v_ext = up_v + ge;
@@ -181,7 +197,7 @@ __device__ __forceinline__ void align_global(
 				uint32_t const dir = t & TR_DIR_MASK;
 				if (TR_DIAG == dir)
 				{
-					uint32_t const eq = dna5_rank_of_char(ref[j - 1]) == dna5_rank_of_seq4(seq4_at(seq4, q0 + i - 1));
+					uint32_t const eq = (uint32_t) mem.ref_rank[j - 1] == dna5_rank_of_seq4(seq4_at(seq4, q0 + i - 1));
 					if (0 == lane) mem.rev[k] = (uint8_t) (rfl(eq) ? OP_EQ : OP_X);
 					++k; --i; --j;
 					continue;
@@ -224,22 +240,46 @@ __global__ __launch_bounds__(64) void k_realign(
 	uint32_t total_runs = 0;
 	uint64_t qual_bytes = 0;
 
-	for (uint64_t base = (uint64_t) wave * 64; base < in.n; base += (uint64_t) n_waves * 64)
+	// Contiguous range of 64-record stripes per wave; the flags of the next stripe are loaded while this one is processed.
+	uint64_t const n_stripes = (in.n + 63) / 64;
+	uint64_t const s_begin = n_stripes * wave / n_waves, s_end = n_stripes * (wave + 1) / n_waves;
+	uint32_t fl_next = (s_begin < s_end && s_begin * 64 + lane < in.n) ? W.rec_flags[s_begin * 64 + lane] : 0;
+	for (uint64_t stripe = s_begin; stripe < s_end; ++stripe)
 	{
-		uint32_t const fl = (base + lane < in.n) ? W.rec_flags[base + lane] : 0;
-		uint64_t todo = ballot(0 != (fl & REC_HAS_RUN));
+		uint64_t const base = stripe * 64;
+		uint32_t const fl = fl_next;
+		fl_next = (stripe + 1 < s_end && base + 64 + lane < in.n) ? W.rec_flags[base + 64 + lane] : 0;
+		bool const mine = 0 != (fl & REC_HAS_RUN);
+		uint64_t todo = ballot(mine);
+		if (!todo)
+			continue;
+
+		// Descriptors of the marked records, lane-parallel.
+		uint64_t v_loc = 0, v_seq_off = 0, v_qual_off = 0;
+		uint32_t v_n = 0, v_dst_pos = 0, v_dst_e = 0, v_l_seq = 0, v_has_qual = 0;
+		if (mine)
+		{
+			uint64_t const r = base + lane;
+			v_loc = W.cig_loc[r]; v_n = W.cig_n[r]; v_dst_pos = W.dst_pos[r]; v_dst_e = in.dst_entry[r];
+			v_seq_off = in.seq_off[r]; v_l_seq = in.l_seq[r];
+			v_has_qual = ((in.flags[r] & PVC3_FLAG_HAS_QUAL) && in.qual) ? 1 : 0;
+			if (v_has_qual) v_qual_off = in.qual_off[r];
+		}
+
 		while (todo)
 		{
-			uint64_t const rec = base + ctz64(todo);
+			uint32_t const ri = ctz64(todo);
+			uint64_t const rec = base + ri;
 			todo &= todo - 1;
 
-			uint32_t const *ops = W.arena + W.cig_loc[rec];
-			uint32_t const n_ops = W.cig_n[rec];
-			uint32_t const dst_pos = W.dst_pos[rec];
-			dev_entry const D = entries[in.dst_entry[rec]];
-			uint8_t const *seq4 = in.seq4 + in.seq_off[rec];
-			uint32_t const l_seq = in.l_seq[rec];
-			uint8_t const *qual = ((in.flags[rec] & PVC3_FLAG_HAS_QUAL) && in.qual) ? (in.qual + in.qual_off[rec]) : nullptr;
+			uint32_t const *ops = W.arena + readlane64(v_loc, ri);
+			uint32_t const n_ops = readlane(v_n, ri);
+			uint32_t const dst_pos = readlane(v_dst_pos, ri);
+			dev_entry const D = entries[readlane(v_dst_e, ri)];
+			uint8_t const *seq4 = in.seq4 + readlane64(v_seq_off, ri);
+			uint32_t const l_seq = readlane(v_l_seq, ri);
+			uint8_t const *qual = readlane(v_has_qual, ri) ? (in.qual + readlane64(v_qual_off, ri)) : nullptr;
+			uint32_t const opv = (lane < n_ops) ? ops[lane] : 0;		// the first 64 operations live in lanes
 
 			// Upper bounds: every run of total length m + n yields at most m + n operations.
 			uint32_t indel_total = 0, n_indel_ops = 0;
@@ -279,7 +319,7 @@ __global__ __launch_bounds__(64) void k_realign(
 				uint32_t op = 0xf, cnt = 0;
 				if (!at_end)
 				{
-					uint32_t const c = rfl(ops[x]);
+					uint32_t const c = (x < 64) ? readlane(opv, x) : rfl(ops[x]);
 					op = c & 0xf; cnt = c >> 4;
 					if (0 == run_type) { run_ref_loc = ref_pos; run_query_loc = query_pos; run_first = x; }	// :45-50
 					if (OP_I == op) { query_pos += cnt; run_type |= 1; continue; }							// :62-65
@@ -331,7 +371,7 @@ __global__ __launch_bounds__(64) void k_realign(
 				{
 					for (uint32_t y = run_first; y < x; ++y)	// single-type run: copied as is (alignment_projector.cc:61-65)
 					{
-						uint32_t const c = rfl(ops[y]);
+						uint32_t const c = (y < 64) ? readlane(opv, y) : rfl(ops[y]);
 						out.push(c & 0xf, c >> 4, lane);
 					}
 				}

@@ -19,6 +19,7 @@ namespace pvc3 {
 // Emits the tokens of one 64-column step in column order (bit i of m? = column i of the step).
 __device__ __forceinline__ void emit_tokens(sink &s, uint64_t mE, uint64_t mX, uint64_t mI, uint64_t mD, uint32_t lane)
 {
+	mE = rfl64(mE); mX = rfl64(mX); mI = rfl64(mI); mD = rfl64(mD);
 	uint64_t valid = mE | mX | mI | mD;
 	if (valid == mE)
 	{
@@ -144,9 +145,10 @@ __device__ __forceinline__ void walk_record(
 			cig_base = ci;
 			cigv = (cig_base + lane < C.n_cigar) ? C.cigar[cig_base + lane] : 0;
 		}
-		uint32_t const c = readlane(cigv, ci - cig_base);
+		uint32_t const c = readlane(cigv, rfl(ci - cig_base));
 		uint32_t const op = c & 0xf;
 		uint32_t n_rem = c >> 4;
+		q = rfl(q);
 
 		if (OP_I == op || OP_S == op)		// rewrite_cigar.hh:69-73
 		{
@@ -163,6 +165,9 @@ __device__ __forceinline__ void walk_record(
 		bool const m_type = !(OP_D == op || OP_N == op);	// M = X (:80-118) vs D N (:121-147)
 		while (n_rem)
 		{
+			// Every value below is wave-uniform by construction; saying so keeps the loop-carried state in SGPRs.
+			col = rfl(col); r = rfl(r); q = rfl(q); n_rem = rfl(n_rem); ref_base = rfl(ref_base); win.b0 = rfl(win.b0);
+			out.make_uniform();
 			// Rare: more runs than the lane buffers hold => reserve an upper bound in the arena and store directly.
 			if (!out.spill && out.n_out > SINK_SPILL_AT)
 			{

@@ -28,6 +28,7 @@ __device__ __forceinline__ bool arena_take_from(
 	arena_alloc &a, uint32_t n, uint32_t chunk, unsigned long long *head, uint64_t cap, unsigned int *overflow, uint32_t lane, uint64_t &off
 )
 {
+	a.ptr = rfl64(a.ptr); a.left = rfl(a.left); n = rfl(n);
 	if (n <= a.left)
 	{
 		off = a.ptr; a.ptr += n; a.left -= n;
@@ -40,7 +41,7 @@ __device__ __forceinline__ bool arena_take_from(
 	off0 = rfl64(off0);
 	if (off0 + grab > cap)
 	{
-		if (0 == lane) *overflow = 1;
+		*overflow = 1;		// every lane stores the same value: a single-lane branch here would make the join look divergent
 		a.left = 0;
 		off = 0;
 		return false;
@@ -84,7 +85,7 @@ struct sink
 		uint32_t const enc = (cur_cnt << 4) | cur_op;
 		if (spill)
 		{
-			if (0 == lane) spill[n_out] = enc;
+			spill[n_out] = enc;		// wave-uniform store (same address, same value in every lane)
 		}
 		else if (n_out < 64) buf0 = writelane(buf0, enc, n_out);
 		else if (n_out < 128) buf1 = writelane(buf1, enc, n_out - 64);

@@ -198,7 +198,7 @@ __device__ __forceinline__ void align_global(
 				if (TR_DIAG == dir)
 				{
 					uint32_t const eq = (uint32_t) mem.ref_rank[j - 1] == dna5_rank_of_seq4(seq4_at(seq4, q0 + i - 1));
-					if (0 == lane) mem.rev[k] = (uint8_t) (rfl(eq) ? OP_EQ : OP_X);
+					mem.rev[k] = (uint8_t) (rfl(eq) ? OP_EQ : OP_X);		// wave-uniform stores
 					++k; --i; --j;
 					continue;
 				}
@@ -206,14 +206,14 @@ __device__ __forceinline__ void align_global(
 			}
 			if (1 == st)
 			{
-				if (0 == lane) mem.rev[k] = (uint8_t) OP_I;
+				mem.rev[k] = (uint8_t) OP_I;
 				++k;
 				if (t & TR_V_OPEN) st = 0;
 				--i;
 			}
 			else
 			{
-				if (0 == lane) mem.rev[k] = (uint8_t) OP_D;
+				mem.rev[k] = (uint8_t) OP_D;
 				++k;
 				if (t & TR_H_OPEN) st = 0;
 				--j;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64) void k_realign(
 	uint32_t const wave = blockIdx.x;
 	uint32_t const n_waves = gridDim.x;
 	arena_alloc arena{0, 0}, runs_alloc{0, 0};
-	uint32_t total_runs = 0;
+	uint32_t total_runs = 0, n_failed = 0;
 	uint64_t qual_bytes = 0;
 
 	// Contiguous range of 64-record stripes per wave; the flags of the next stripe are loaded while this one is processed.
@@ -339,9 +339,8 @@ __global__ __launch_bounds__(64) void k_realign(
 				{
 					uint32_t const m = run_ref_end - run_ref_loc, nq = run_query_end - run_query_loc;
 					// alignment_projector.cc:69-73: reference_position() already includes the terminating operation.
-					if (0 == lane)
 					{
-						pvc3_run rr;
+						pvc3_run rr;		// wave-uniform store
 						rr.query_location = run_query_loc; rr.query_length = nq; rr.ref_position = ref_pos; rr.ref_length = m;
 						runs[n_runs] = rr;
 					}
@@ -355,11 +354,8 @@ __global__ __launch_bounds__(64) void k_realign(
 					{
 						if (need > W.scratch_per_wave)
 						{
-							if (0 == lane)
-							{
-								atomicMax(&W.counters->scratch_needed, (unsigned int) ((need > 0xFFFFFFFFull) ? 0xFFFFFFFFu : need));
-								W.counters->scratch_overflow = 1;
-							}
+							atomicMax(&W.counters->scratch_needed, (unsigned int) ((need > 0xFFFFFFFFull) ? 0xFFFFFFFFu : need));	// idempotent
+							W.counters->scratch_overflow = 1;
 							status = 0xff;	// not a record status: the host grows the scratch and repeats
 							break;
 						}
@@ -382,23 +378,23 @@ __global__ __launch_bounds__(64) void k_realign(
 
 			if (0xff == status)
 				continue;
-			if (0 == lane)
+			// Wave-uniform stores (every lane writes the same values).
+			if (status)
 			{
-				if (status)
-				{
-					W.cig_n[rec] = 0; W.run_n[rec] = 0; W.dst_pos[rec] = 0;
-					W.rec_flags[rec] = status;
-					atomicAdd(&W.counters->n_failed, 1ull);
-				}
-				else
-				{
-					W.cig_loc[rec] = out_loc; W.cig_n[rec] = out.n_out;
-					W.run_loc[rec] = runs_loc; W.run_n[rec] = n_runs;
-				}
+				W.cig_n[rec] = 0; W.run_n[rec] = 0; W.dst_pos[rec] = 0;
+				W.rec_flags[rec] = status;
+				++n_failed;
+			}
+			else
+			{
+				W.cig_loc[rec] = out_loc; W.cig_n[rec] = out.n_out;
+				W.run_loc[rec] = runs_loc; W.run_n[rec] = n_runs;
 			}
 			if (!status) { total_runs += n_runs; qual_bytes += qual ? l_seq : 0; }
 		}
 	}
+	if (0 == lane && n_failed)
+		atomicAdd(&W.counters->n_failed, (unsigned long long) n_failed);
 	if (0 == lane && total_runs)
 	{
 		atomicAdd(&W.counters->n_runs, (unsigned long long) total_runs);

@@ -112,22 +112,32 @@ __device__ __forceinline__ void stage_load(
 	window w;
 	window_load(w, C.s_blocks, C.d_blocks, C.b0, lane);
 	L.win_lo = w.lo; L.win_hi = w.hi;
-	if (8 * lane < C.l_seq)
-		L.seqw = load_u32_unaligned(C.seq4 + 4 * lane);				// the SEQ buffer is padded by the host side
+	// Unconditional 256-byte reads: the SEQ and CIGAR buffers are padded by 256 bytes, device texts by TEXT_PAD bytes.
+	// (No lane-dependent branches here: they would be merged into the wave-uniform control flow around them.)
+	L.seqw = load_u32_unaligned(C.seq4 + 4 * lane);
 	if (C.d_text)
-		L.refw = *(uint32_t const *) (C.d_text + C.ref_base + 4 * lane);	// device texts are padded by TEXT_PAD bytes
-	if (lane < C.n_cigar)
-		L.cigv = C.cigar[lane];
+		L.refw = *(uint32_t const *) (C.d_text + C.ref_base + 4 * lane);
+	L.cigv = C.cigar[lane];
 }
 
 // Phase B for one record: the column walk.  All control flow is wave-uniform.
 __device__ __forceinline__ void walk_record(
-	dev_entry const *__restrict__ entries, rec_ctx const &C, rec_loads const &L, dev_batch_work const &W, arena_alloc &arena, uint32_t lane, rec_out &res
+	dev_entry const *__restrict__ entries, rec_ctx const &C_in, rec_loads const &L, dev_batch_work const &W, arena_alloc &arena, uint32_t lane, rec_out &res
 )
 {
-	res.status = C.status; res.n_out = 0; res.has_run = 0; res.loc = 0; res.cols = 0; res.ref_span = 0;
-	if (C.status)
+	res.status = rfl(C_in.status); res.n_out = 0; res.has_run = 0; res.loc = 0; res.cols = 0; res.ref_span = 0;
+	if (res.status)
 		return;
+
+	// Everything in `C` is wave-uniform by construction (readlane / scalar loads).  Re-asserting it here cuts the cycles
+	// through which a single conservative "divergent" verdict of the compiler would spread to the whole walk.
+	rec_ctx C;
+	C.status = 0;
+	C.col = rfl(C_in.col); C.r0 = rfl(C_in.r0); C.ref_consumed = rfl(C_in.ref_consumed); C.n_cigar = rfl(C_in.n_cigar);
+	C.l_seq = rfl(C_in.l_seq); C.src_e = rfl(C_in.src_e); C.src_pos = rfl(C_in.src_pos); C.d_text_len = rfl(C_in.d_text_len);
+	C.b0 = rfl(C_in.b0); C.ref_base = rfl(C_in.ref_base);
+	C.s_blocks = rfl_ptr(C_in.s_blocks); C.d_blocks = rfl_ptr(C_in.d_blocks); C.d_text = rfl_ptr(C_in.d_text);
+	C.cigar = rfl_ptr(C_in.cigar); C.seq4 = rfl_ptr(C_in.seq4);
 
 	window win;
 	win.lo = L.win_lo; win.hi = L.win_hi; win.b0 = C.b0;
@@ -143,7 +153,7 @@ __device__ __forceinline__ void walk_record(
 		if (ci - cig_base >= 64)	// more than 64 input operations: next slice
 		{
 			cig_base = ci;
-			cigv = (cig_base + lane < C.n_cigar) ? C.cigar[cig_base + lane] : 0;
+			cigv = C.cigar[cig_base + lane];		// padded buffer: unconditional
 		}
 		uint32_t const c = readlane(cigv, rfl(ci - cig_base));
 		uint32_t const op = c & 0xf;
@@ -187,7 +197,10 @@ __device__ __forceinline__ void walk_record(
 
 			col_pos const p = split_col(col);
 			if (p.blk - win.b0 >= 2)
+			{
 				window_load(win, C.s_blocks, C.d_blocks, p.blk, lane);
+				win.b0 = rfl(win.b0);
+			}
 			uint32_t const wi = (p.blk - win.b0) * BLOCK_WORDS + 1 + p.w;
 			uint64_t const sw = window_word(win, wi);
 			uint64_t const dw = window_word(win, 16 + wi);
@@ -250,7 +263,7 @@ __device__ __forceinline__ void walk_record(
 					}
 					uint32_t const rw = (uint32_t) __shfl((int) refw, (int) ((ri >> 2) & 63));
 					uint32_t const rb = (rw >> ((ri & 3) * 8)) & 0xff;
-					mE = ballot(in_c && seq4_to_dna5_char(code) == rb);		// raw byte compare (quirk Q3)
+					mE = ballot(in_c & (seq4_to_dna5_char(code) == rb));		// raw byte compare (quirk Q3)
 					mX = mC & ~mE;
 				}
 				q += consumed;

@@ -50,7 +50,7 @@ __device__ __forceinline__ uint64_t low_mask(uint32_t n) { return (n >= 64) ? ~U
 // Position of the t-th (0-based) set bit of the wave-uniform word z; all 64 lanes cooperate.
 __device__ __forceinline__ uint32_t wave_select_in_word(uint64_t z, uint32_t t, uint32_t lane)
 {
-	bool const mine = ((z >> lane) & 1) && (mbcnt64(z) == t);
+	bool const mine = (0 != ((z >> lane) & 1)) & (mbcnt64(z) == t);		// '&', not '&&': no lane-dependent branch
 	return ctz64(ballot(mine));
 }
 
@@ -79,12 +79,10 @@ struct window
 
 __device__ __forceinline__ void window_load(window &w, uint64_t const *src_blocks, uint64_t const *dst_blocks, uint32_t b0, uint32_t lane)
 {
-	uint64_t v = 0;
-	if (lane < 32)
-	{
-		uint64_t const *p = (lane < 16) ? src_blocks : dst_blocks;
-		v = p[(uint64_t) b0 * BLOCK_WORDS + (lane & 15)];
-	}
+	// Branch-free: lanes 32..63 repeat the addresses of lanes 0..31 (same cache lines, no extra traffic).  A lane-dependent
+	// branch around the load would be merged with the surrounding wave-uniform control flow and make it look divergent.
+	uint64_t const *p = (lane & 16) ? dst_blocks : src_blocks;
+	uint64_t const v = p[(uint64_t) b0 * BLOCK_WORDS + (lane & 15)];
 	w.lo = (uint32_t) v;
 	w.hi = (uint32_t) (v >> 32);
 	w.b0 = b0;

@@ -54,6 +54,25 @@ def test_scaled_configs(pvc3, oracle_mod, synth, name, scale):
 		assert np.array_equal(got["mate_dst_pos"][0::2][:b.size], b) and np.array_equal(got["mate_dst_pos"][1::2], a[:b.size])
 
 
+def test_device_checksum_matches_host_restatement(pvc3, oracle_mod, synth):
+	"""pvc3_dbatch_checksum (used for the additive multi-GPU / full-size checks) against its host restatement."""
+	from test_shard_gloo import _checksum
+	gp, rp, _ = synth.config("C5", scale=0.0005)
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	index = pvc3.Index()
+	genome.fill_index(index)
+	ctx = pvc3.Context(0)
+	ctx.upload_index(index)
+	db = pvc3.DeviceBatch(ctx, reads.batch())
+	db.project()
+	db.finish()
+	got = db.download()
+	for first in (0, 12345678901):
+		assert db.checksum(first) == _checksum(got, first)
+	db.close()
+
+
 def test_c2_full_size_bit_exact(pvc3, oracle_mod, synth):
 	"""BASELINE.json configs[1]: 1 M synthetic 150 bp single-end reads, 2 founders, bit-exact vs the CPU path."""
 	gp, rp, desc = synth.config("C2")

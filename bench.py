@@ -34,6 +34,7 @@ def main():
 	ap.add_argument("--scale", type=float, default=1.0, help="shrink genome and read count together (smoke runs only)")
 	ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="target CPU time of the oracle sample; 0 disables")
 	ap.add_argument("--score-mode", type=int, default=0)
+	ap.add_argument("--sorted", action="store_true", help="sort the records by (source entry, position) like a coordinate-sorted BAM (secondary data point; the default is the unsorted worst case)")
 	args = ap.parse_args()
 
 	rank = int(os.environ.get("RANK", "0"))
@@ -71,6 +72,9 @@ def main():
 	reads = synth.Reads(genome, rp, n_threads=threads)
 	batch = reads.batch()
 	n_local = int(reads.n)
+	if args.sorted:
+		order = np.lexsort((batch["src_pos"], batch["src_entry"]))
+		batch = synth.reorder_batch(batch, order)
 	log("%s; scale %.4g: genome %.1f s, %d records %.1f s (%d host threads)" % (desc, args.scale, t1 - t0, n_local, time.time() - t1, threads))
 
 	index = panvc3_amd.Index()
@@ -137,7 +141,7 @@ def main():
 			"dtype": "u64 bit-vectors / u32 CIGAR (f64 only in the realign DP)", "data": "synthetic",
 			"config": {
 				"workload": desc, "records_per_gpu": n_local, "read_len": int(rp.read_len), "paired": bool(rp.paired),
-				"founders": int(gp.n_founders), "genome_bp": int(gp.genome_len), "scale": args.scale, "parallelism": "records sharded, index replicated, no collective",
+				"founders": int(gp.n_founders), "genome_bp": int(gp.genome_len), "scale": args.scale, "record_order": "coordinate-sorted" if args.sorted else "as sampled (uniformly random positions)", "parallelism": "records sharded, index replicated, no collective",
 			},
 			"roofline": {
 				"bound": "hbm", "kernel": "k_project", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

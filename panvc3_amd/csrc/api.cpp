@@ -52,9 +52,9 @@ struct pvc3_context
 	pvc3_params params{0, 0, -1, 0};
 
 	// Options.
-	uint32_t realign_waves{2048};
+	uint32_t realign_waves{4096};		// one 64-thread block each; 8 KB of LDS per block => up to 20 per CU
 	uint32_t realign_lds_bytes{};
-	uint64_t scratch_per_wave{256 * 1024};
+	uint64_t scratch_per_wave{128 * 1024};
 	uint64_t arena_initial{};
 	uint64_t runs_initial{};
 	uint32_t fast_path{1};

@@ -157,6 +157,24 @@ def slice_batch(batch, lo, hi):
 	return out
 
 
+def reorder_batch(batch, order):
+	"""The batch with its records permuted by `order` (variable-length fields are re-packed)."""
+	order = np.asarray(order, dtype=np.int64)
+	out = {}
+	for name in ("src_pos", "src_entry", "dst_entry", "flags", "l_seq", "mate_src_entry", "mate_dst_entry", "mate_pos"):
+		out[name] = batch[name][order]
+	for off, data in (("cigar_off", "cigar"), ("seq_off", "seq4"), ("qual_off", "qual")):
+		o = batch[off].astype(np.int64)
+		lens = (o[1:] - o[:-1])[order]
+		new_off = np.concatenate([[0], np.cumsum(lens)])
+		# gather: for every output element its source index
+		starts = o[:-1][order]
+		idx = np.repeat(starts - new_off[:-1], lens) + np.arange(new_off[-1])
+		out[off] = new_off.astype(np.uint64)
+		out[data] = batch[data][idx]
+	return out
+
+
 def config(name, scale=1.0, seed=None):
 	"""BASELINE.json configurations.  Returns (GenomeParams, ReadsParams, description)."""
 	name = name.upper()

@@ -131,7 +131,7 @@ def main():
 				pj = json.load(open(prof))
 				key = "%s@%g" % (args.config, args.scale)
 				if key in pj:
-					traffic = pj[key]["k_project_hbm_bytes_per_launch"]
+					traffic = pj[key]["k_project_fast_hbm_bytes_per_launch"]
 			except Exception:
 				traffic = None
 		result = {
@@ -144,13 +144,13 @@ def main():
 				"founders": int(gp.n_founders), "genome_bp": int(gp.genome_len), "scale": args.scale, "record_order": "coordinate-sorted" if args.sorted else "as sampled (uniformly random positions)", "parallelism": "records sharded, index replicated, no collective",
 			},
 			"roofline": {
-				"bound": "hbm", "kernel": "k_project", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+				"bound": "hbm", "kernel": "k_project_fast", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
 				"traffic": traffic, "algorithmic_bytes_per_launch": project_bytes, "ms_per_launch": ms_avg["project"],
 				"bytes_per_alignment": project_bytes / max(1, n_local),
 				"whole_step": {"algorithmic_bytes": stats["algorithmic_bytes"], "GBps": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9, "frac": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
 			},
 			"kernel_ms": ms_avg,
-			"batch": {"realigned_records": stats["n_realigned_records"], "indel_runs": stats["n_runs"], "out_cigar_ops": stats["out_cigar_total"], "checksum": "%016x" % checksum_total},
+			"batch": {"fast_path_records": stats["n_fast_path"], "realigned_records": stats["n_realigned_records"], "indel_runs": stats["n_runs"], "out_cigar_ops": stats["out_cigar_total"], "checksum": "%016x" % checksum_total},
 		}
 
 		# ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample, same box, rank 0 only ----

@@ -141,7 +141,7 @@ typedef struct pvc3_batch_stats
 	uint64_t n_runs;				/* total realigned indel runs */
 	uint64_t out_cigar_total;		/* total output CIGAR operations (required out_cigar_cap) */
 	uint64_t algorithmic_bytes;		/* SURVEY.md §8(d) bytes of this batch (reads + writes), see DESIGN.md */
-	uint64_t algorithmic_bytes_project;	/* the share of the projection kernel (k_project) alone */
+	uint64_t algorithmic_bytes_project;	/* the share of k_project_fast alone (accumulated per record by the kernel) */
 	uint64_t n_fast_path;			/* records finished by the lane-parallel fast path of k_project_fast */
 	float ms_project;				/* k_project_fast: last launch duration (hipEvent), 0 if timing is disabled */
 	float ms_general;				/* k_project_general */

@@ -588,23 +588,14 @@ int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stat
 		stats->out_cigar_total = totals[0];
 		// Algorithmic bytes (DESIGN.md "Algorithmic bytes per alignment"): what one pass must read and write at minimum.
 		uint64_t const n = b->n;
-		// k_project: record fields, input CIGAR, packed SEQ, one select sample + one dst rank word, the src / dst gap-bit
-		// windows, the dst text window; writes dst_pos, status word, arena location + count, and the CIGAR itself.
-		stats->algorithmic_bytes_project =
-			n * (4 + 4 + 4 + 8 + 8 + 4)					// src_pos, src_entry, dst_entry, cigar_off, seq_off, l_seq
-			+ 4 * b->sum_cigar + b->sum_seq_bytes
-			+ n * (4 + 8)
-			+ c.bitvec_bytes + c.ref_bytes
-			+ n * (4 + 4 + 8 + 4)						// dst_pos, flags word, CIGAR location, CIGAR length
-			+ 4 * totals[0];
-		stats->algorithmic_bytes =
-			stats->algorithmic_bytes_project
-			+ n * 4										// flags (mate / QUAL bits)
-			+ b->n_mates * (12 + 4 + 64 + 64)			// mate fields, select sample, one src and one dst block
-			+ n * 4										// mate_dst_pos
-			+ c.qual_bytes								// QUAL of realigned records only
-			+ sizeof(pvc3_run) * totals[1];				// realigned ranges
-		// (The packing pass re-reads and re-writes the CIGARs; that is implementation traffic, not algorithmic bytes.)
+		// Algorithmic bytes are accumulated per record by the kernels themselves: what one pass must read and
+		// write at minimum.  k_project_fast: descriptors, input CIGAR, select sample + rank word, mate fields (+ the mate's
+		// blocks when it is not the neighbouring record), results; for fast-path records also SEQ, gap-bit windows, text and
+		// the output CIGAR.  k_project_general: SEQ, gap bits, text, output CIGAR of the records it walks.
+		// k_realign: QUAL of realigned records.  Realigned ranges: 16 bytes each.  Packing traffic is not algorithmic.
+		stats->algorithmic_bytes_project = c.fast_bytes;
+		stats->algorithmic_bytes = c.fast_bytes + c.general_bytes + c.qual_bytes + sizeof(pvc3_run) * totals[1];
+		(void) n;
 		if (ctx->timing)
 		{
 			(void) hipEventElapsedTime(&stats->ms_project, ctx->ev[0], ctx->ev[1]);

@@ -25,6 +25,9 @@ namespace {
 constexpr uint32_t FAST_MAX_BASES = 256;
 constexpr uint32_t FAST_WORDS = FAST_MAX_BASES / 32;
 constexpr uint32_t LDS_ENTRIES = 256;
+#ifndef PVC3_FAST_MIN_WAVES
+#define PVC3_FAST_MIN_WAVES 4
+#endif
 
 typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
 
@@ -92,7 +95,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 	return rfl(v);
 }
 
-__global__ __launch_bounds__(256) void k_project_fast(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W, uint32_t use_fast_path)
+__global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W, uint32_t use_fast_path)
 {
 	uint32_t const lane = lane_id();
 	uint32_t const wave = rfl((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void k_project_fast(dev_entry const *__restric
 		lds_entries[i] = entries[i];
 	__syncthreads();
 	auto get_entry = [&](uint32_t id) -> dev_entry { return (id < LDS_ENTRIES) ? lds_entries[id] : entries[id]; };
-	uint64_t acc_bitvec = 0, acc_ref = 0;
+	uint64_t acc_bitvec = 0, acc_ref = 0, acc_bytes = 0;
 
 	for (uint64_t g = g_begin; g < g_end; ++g)
 	{
@@ -219,7 +222,10 @@ __global__ __launch_bounds__(256) void k_project_fast(dev_entry const *__restric
 			if (from_neighbour)
 				mate = n_r0;
 			else if (has_mate && mate_se < n_entries && mate_de < n_entries)
+			{
 				mate = thread_project_position(get_entry(mate_se), get_entry(mate_de), mate_pos);
+				acc_bytes += 4 + 64 + 64;		// select sample, one source block, one destination block
+			}
 		}
 
 		// ---- fast path ------------------------------------------------------------------------------------------------------------------
@@ -306,6 +312,8 @@ __global__ __launch_bounds__(256) void k_project_fast(dev_entry const *__restric
 				acc_bitvec += 2 * ((R + 8) / 8);
 				acc_ref += R;
 				acc_fast += 1;
+				// what the fast path itself must read and write for this record: SEQ, gap-bit windows, text, CIGAR out
+				acc_bytes += (l_seq + 1) / 2 + 2 * ((R + 8) / 8) + R + 4 * f_n_out;
 			}
 		}
 
@@ -320,6 +328,8 @@ __global__ __launch_bounds__(256) void k_project_fast(dev_entry const *__restric
 			W.cig_loc[rec] = slow ? ((uint64_t) col | ((uint64_t) ref_consumed << 32)) : f_loc;
 			W.run_n[rec] = 0;
 			acc_failed += (PVC3_ST_OK != status);
+			// every record: 7 descriptor fields (28 + 4 flags), input CIGAR, select sample, destination rank word; 24 bytes of results
+			acc_bytes += 32 + 4 * n_cigar + (ok ? 12 : 0) + 24 + (has_mate ? 12 : 0);
 		}
 	}
 
@@ -330,6 +340,7 @@ __global__ __launch_bounds__(256) void k_project_fast(dev_entry const *__restric
 		acc_ref += __shfl_xor(acc_ref, off);
 		acc_failed += __shfl_xor(acc_failed, off);
 		acc_fast += __shfl_xor(acc_fast, off);
+		acc_bytes += __shfl_xor(acc_bytes, off);
 	}
 	if (0 == lane)
 	{
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(256) void k_project_fast(dev_entry const *__restric
 		if (acc_ref) atomicAdd(&W.counters->ref_bytes, (unsigned long long) acc_ref);
 		if (acc_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) acc_failed);
 		if (acc_fast) atomicAdd(&W.counters->n_fast, (unsigned long long) acc_fast);
+		if (acc_bytes) atomicAdd(&W.counters->fast_bytes, (unsigned long long) acc_bytes);
 	}
 }
 

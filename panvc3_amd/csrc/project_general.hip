@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_project_general(dev_entry const *__rest
 	uint64_t const g_end = n_groups * (wave + 1) / n_waves;
 	arena_alloc arena{0, 0};
 	group_out G;
-	G.n_failed = 0; G.n_with_runs = 0; G.bitvec_bytes = 0; G.ref_bytes = 0;
+	G.n_failed = 0; G.n_with_runs = 0; G.bitvec_bytes = 0; G.ref_bytes = 0; G.bytes = 0;
 
 	for (uint64_t g = g_begin; g < g_end; ++g)
 	{
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k_project_general(dev_entry const *__rest
 	{
 		if (G.bitvec_bytes) atomicAdd(&W.counters->bitvec_bytes, (unsigned long long) G.bitvec_bytes);
 		if (G.ref_bytes) atomicAdd(&W.counters->ref_bytes, (unsigned long long) G.ref_bytes);
+		if (G.bytes) atomicAdd(&W.counters->general_bytes, (unsigned long long) G.bytes);
 		if (G.n_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) G.n_failed);
 		if (G.n_with_runs) atomicAdd(&W.counters->n_realigned_records, (unsigned long long) G.n_with_runs);
 	}

@@ -81,6 +81,8 @@ struct dev_counters
 	unsigned long long ref_bytes;		// sum over records of destination characters spanned
 	unsigned long long qual_bytes;		// sum of l_seq over realigned records
 	unsigned long long n_fast;			// records finished by the lane-parallel fast path
+	unsigned long long fast_bytes;		// algorithmic bytes of k_project_fast
+	unsigned long long general_bytes;	// algorithmic bytes of k_project_general (data the fast kernel had not read yet)
 };
 
 // Per-record results before packing.  flags: bits 0-7 status, bit 8 = has at least one indel run.

@@ -80,7 +80,7 @@ struct rec_ctx
 
 struct rec_out
 {
-	uint32_t status, n_out, has_run, cols, ref_span;
+	uint32_t status, n_out, has_run, cols, ref_span, l_seq;
 	uint64_t loc;
 };
 
@@ -125,7 +125,7 @@ __device__ __forceinline__ void walk_record(
 	dev_entry const *__restrict__ entries, rec_ctx const &C_in, rec_loads const &L, dev_batch_work const &W, arena_alloc &arena, uint32_t lane, rec_out &res
 )
 {
-	res.status = rfl(C_in.status); res.n_out = 0; res.has_run = 0; res.loc = 0; res.cols = 0; res.ref_span = 0;
+	res.status = rfl(C_in.status); res.n_out = 0; res.has_run = 0; res.loc = 0; res.cols = 0; res.ref_span = 0; res.l_seq = 0;
 	if (res.status)
 		return;
 
@@ -283,6 +283,7 @@ __device__ __forceinline__ void walk_record(
 	res.n_out = out.n_out;
 	res.has_run = out.has_run;
 	res.cols = col - C.col;
+	res.l_seq = C.l_seq;
 	res.ref_span = r - C.r0;
 	if (out.spill)
 		res.loc = spill_loc;
@@ -307,7 +308,7 @@ struct group_out
 {
 	uint32_t flags, cig_n, loc_lo, loc_hi;
 	uint32_t n_failed, n_with_runs;		// wave-uniform accumulators
-	uint64_t bitvec_bytes, ref_bytes;
+	uint64_t bitvec_bytes, ref_bytes, bytes;
 
 	__device__ __forceinline__ void put(uint32_t i, rec_out const &r)
 	{
@@ -320,6 +321,7 @@ struct group_out
 		n_with_runs += (ok && r.has_run);
 		bitvec_bytes += ok ? 2 * ((r.cols + 8) / 8) : 0;		// src + dst windows, at least the first column's byte
 		ref_bytes += ok ? r.ref_span : 0;
+		bytes += ok ? (2 * ((r.cols + 8) / 8) + r.ref_span + 4 * r.n_out + (r.l_seq + 1) / 2) : 0;	// gap bits, text, CIGAR out, SEQ
 	}
 };
 

@@ -56,10 +56,14 @@ def main():
 				s["hbm_bytes_raw"] = f + w
 				s["hbm_bytes_corrected"] = 2 * f + w
 	json.dump(summary, open(os.path.join(out_dir, "summary.json"), "w"), indent=1, sort_keys=True)
-	if key and "k_project" in summary and "hbm_bytes_corrected" in summary["k_project"]:
+	if key and "k_project_fast" in summary and "hbm_bytes_corrected" in summary["k_project_fast"]:
 		p = os.path.join(os.path.dirname(os.path.abspath(out_dir)), "pmc_traffic.json")
 		cur = json.load(open(p)) if os.path.exists(p) else {}
-		cur[key] = {"k_project_hbm_bytes_per_launch": summary["k_project"]["hbm_bytes_corrected"], "k_project_hbm_bytes_raw": summary["k_project"]["hbm_bytes_raw"], "source": os.path.basename(os.path.abspath(out_dir))}
+		cur[key] = {
+			"k_project_fast_hbm_bytes_per_launch": summary["k_project_fast"]["hbm_bytes_corrected"],
+			"k_project_fast_hbm_bytes_raw": summary["k_project_fast"]["hbm_bytes_raw"],
+			"source": os.path.basename(os.path.abspath(out_dir)),
+		}
 		json.dump(cur, open(p, "w"), indent=1, sort_keys=True)
 	for k, s in sorted(summary.items(), key=lambda kv: -kv[1].get("avg_ns", 0)):
 		print("%-22s avg %10.3f ms  %5.1f%%  hbm(corrected) %s" % (k, s.get("avg_ns", 0) / 1e6, s.get("pct", 0), ("%.2f GB" % (s["hbm_bytes_corrected"] / 1e9)) if "hbm_bytes_corrected" in s else "-"))

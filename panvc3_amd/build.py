@@ -55,5 +55,33 @@ def build(force=False, verbose=False):
 	return LIB
 
 
+HOST = os.path.join(HERE, "host")
+BIN = os.path.join(HERE, "..", "bin")
+
+
+def build_host(force=False, verbose=False):
+	"""The C++ host pipeline (g++): bin/panvc3_index_msa and bin/panvc3_project_alignments (the latter links libpvc3_hip.so)."""
+	build(force=False, verbose=verbose)
+	os.makedirs(BIN, exist_ok=True)
+	headers = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "pvc3.h")]
+	cxx = os.environ.get("CXX", "g++")
+	flags = ["-O2", "-g", "-std=c++17", "-Wall", "-Wextra"]
+	out = []
+	for name, extra in (
+		("panvc3_index_msa", ["-lz"]),
+		("panvc3_project_alignments", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
+	):
+		src = os.path.join(HOST, name.replace("panvc3_", "") + "_main.cpp")
+		dst = os.path.join(BIN, name)
+		out.append(dst)
+		if force or _newer(dst, [src, LIB] + headers):
+			cmd = [cxx] + flags + ["-o", dst, src] + extra
+			if verbose:
+				print(" ".join(cmd), file=sys.stderr)
+			subprocess.check_call(cmd)
+	return out
+
+
 if __name__ == "__main__":
 	print(build(force="--force" in sys.argv, verbose=True))
+	print(build_host(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,596 @@
+// panvc3_project_alignments — the reference's command line and SAM/BAM-in, SAM/BAM-out surface over the MI355X hot path.
+//
+// Mirrors project-alignments/project_alignments.cc of the reference around the C ABI (include/pvc3.h):
+//   options            project-alignments/cmdline.ggo:10-49
+//   record filters     project_alignments.cc:528-570        (unmapped / QC-fail / duplicate / no RNAME / no POS / no SEQ are dropped)
+//   header rewrite     :1092-1253 (process_headers), :1256-1268 + include/panvc3/utility.hh:92-143 (@PG)
+//   entry lookup       :1271-1316 (fill_sequence_entries)
+//   per record         :700-919: projection (GPU), tag filter :775-802, OA :805-844, XB / YB :848-861, XI :864-869,
+//                      XR / XP :872-877, mate :880-911, POS / CIGAR / RNAME :915-918
+// Differences: records are projected in large batches on the GPU instead of four at a time on one CPU thread (the XI value
+// still follows the four-record chunks); the MSA index is this implementation's own file format; the whole destination FASTA
+// is read up front.  SEQ / QUAL are normalised the way seqan3's default dna5 / phred42 alphabets do.
+#include <getopt.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <regex>
+#include <set>
+
+#include "../../include/pvc3.h"
+#include "msa_index_file.hpp"
+#include "sam_bam.hpp"
+
+using namespace pvc3host;
+
+namespace {
+
+[[noreturn]] void die(std::string const &msg)
+{
+	std::cerr << "ERROR: " << msg << '\n';
+	std::exit(EXIT_FAILURE);
+}
+
+void check(int rc, char const *what)
+{
+	if (rc) die(std::string(what) + ": " + pvc3_last_error());
+}
+
+char const *const PRESERVED_TAGS[] = {	// project_alignments.cc:53-87
+	"AM", "AS", "BC", "BZ", "CB", "CO", "CR", "CS", "CT", "CY", "E2", "FZ", "LB", "MI", "ML", "MM", "OA", "OQ", "OX", "PG", "PU", "QT", "QX", "RX", "TS"};
+
+inline uint16_t tag_key(char const t[2]) { return (uint16_t) ((uint8_t) t[0] * 256 + (uint8_t) t[1]); }	// include/panvc3/sam_tag.hh:34-44
+
+struct options
+{
+	char const *alignments{}, *msa_index{}, *reference{}, *reference_msa_id{}, *ref_order{}, *output_path{}, *realigned_ranges{};
+	std::string separator{"_"};
+	bool bam_input{}, output_bam{}, keep_duplicate_ranges{}, print_invocation{}, print_pid{}, io_only{};
+	std::vector <std::string> preserve_tags;
+	std::string rname_tag{"XR"}, pos_tag{"XP"}, rnext_tag{"YR"}, pnext_tag{"YP"}, query_ranges_tag{"XB"}, ref_ranges_tag{"YB"}, rec_idx_tag;
+	int gap_open{0}, gap_ext{-1}, device{0};
+	uint64_t batch_size{UINT64_C(1) << 21};
+};
+
+void usage()
+{
+	std::cout <<
+		"Usage: panvc3_project_alignments --alignments=alignments.bam --msa-index=msa-index.dat --reference=ref.fa.gz --reference-msa-id=REF > projected.sam\n"
+		"  -a, --alignments=filename            Alignment file path (stdin by default)\n"
+		"  -B, --bam-input                      Read BAM from stdin\n"
+		"  -m, --msa-index=filename             MSA index path (built by panvc3_index_msa of this package)\n"
+		"  -r, --reference=filename             Reference sequences FASTA path (plain, gzip or bgzip)\n"
+		"  -d, --reference-msa-id=STRING        Reference sequence ID in MSA index\n"
+		"  -s, --ref-id-separator=STRING        Reference ID separator in input (default `_')\n"
+		"  -u, --reference-order-input=filename Read output reference order from the given path, one identifier per line\n"
+		"  -o, --output-path=path               Output path (stdout by default)\n"
+		"  -b, --output-bam                     Output BAM instead of SAM\n"
+		"      --status-output-interval=SHORT   accepted, ignored\n"
+		"  -l, --output-realigned-ranges=filename  Output the re-aligned ranges as TSV to the given path\n"
+		"  -t, --preserve-tag=tag               Preserve the given SAM tag (may be repeated)\n"
+		"      --original-rname-tag=XR --original-pos-tag=XP --original-rnext-tag=YR --original-pnext-tag=YP\n"
+		"      --realigned-query-ranges-tag=XB --realigned-ref-ranges-tag=YB --record-index-tag=TAG\n"
+		"  -q, --use-read-base-qualities        accepted, no effect (as in the reference)\n"
+		"  -g, --gap-opening-cost=INT           (default 0)     -e, --gap-extension-cost=INT (default -1)\n"
+		"      --device=INT                     GPU to use (default 0)\n";
+}
+
+// process_headers (project_alignments.cc:1092-1253)
+void process_headers(sam_header const &in, options const &opt, sam_header &out, std::vector <std::size_t> &ref_id_mapping)
+{
+	out.comments = in.comments;
+	out.read_groups = in.read_groups;
+	ref_id_mapping.assign(in.refs.size(), SIZE_MAX);
+
+	std::vector <std::pair <std::string, std::string>> chr_seq;
+	for (auto const &sq : in.refs)
+	{
+		auto const pos = sq.name.find_first_of(opt.separator);		// :1124 (find_first_of, quirk Q13)
+		if (std::string::npos == pos) die("Separator '" + opt.separator + "' not found in reference ID '" + sq.name + "'.");
+		chr_seq.emplace_back(sq.name.substr(0, pos), sq.name.substr(pos + 1));
+	}
+
+	std::map <std::string, std::pair <std::size_t, bool>> order;		// chr id -> (index, used)
+	if (opt.ref_order)
+	{
+		std::set <std::string> unique_chr;
+		for (auto const &cs : chr_seq) unique_chr.insert(cs.first);
+		byte_reader in_order;
+		in_order.open(opt.ref_order);
+		std::string line;
+		std::size_t idx = 0;
+		while (in_order.getline(line))
+		{
+			std::string const id = line.substr(0, line.find('\t'));		// first tabulator: .fai input works
+			if (!unique_chr.count(id)) { std::cerr << "WARNING: Identifier ‘" << id << "’ specified in reference name order but does not appear in the alignments.\n"; continue; }
+			if (!order.emplace(id, std::make_pair(idx, false)).second) { std::cerr << "WARNING: Identifier ‘" << id << "’ specified in reference name order more than once.\n"; continue; }
+			++idx;
+		}
+	}
+
+	std::map <std::string, std::size_t> unique_ref_ids;
+	std::vector <std::size_t> ref_seq_idxs;
+	std::size_t next_idx = order.size();
+	for (std::size_t i = 0; i < chr_seq.size(); ++i)
+	{
+		auto const &[chr_id, seq_id] = chr_seq[i];
+		auto const it = unique_ref_ids.find(chr_id);
+		std::size_t out_idx;
+		if (unique_ref_ids.end() == it)
+		{
+			auto const oit = order.find(chr_id);
+			if (order.end() == oit)
+			{
+				out_idx = next_idx++;
+				if (!order.empty()) std::cerr << "WARNING: Output reference ID ‘" << chr_id << "’ not found in the output order, placing in the end.\n";
+			}
+			else { out_idx = oit->second.first; oit->second.second = true; }
+			unique_ref_ids.emplace(chr_id, out_idx);
+		}
+		else out_idx = it->second;
+		ref_id_mapping[i] = out_idx;
+		if (seq_id == opt.reference_msa_id) ref_seq_idxs.push_back(i);
+	}
+
+	out.refs.assign(unique_ref_ids.size(), {});
+	for (auto const &kv : unique_ref_ids) out.refs[kv.second].name = kv.first;
+	for (auto const i : ref_seq_idxs)		// length + extra info of chr<sep><reference-msa-id> (:1223-1240)
+	{
+		auto &dst = out.refs[ref_id_mapping[i]];
+		dst.length = in.refs[i].length;
+		dst.extra = in.refs[i].extra;
+	}
+	for (auto const &kv : order)
+		if (!kv.second.second) std::cerr << "WARNING: Identifier ‘" << kv.first << "’ was given in the output reference name order but was not found in the input.\n";
+	out.index_refs();
+}
+
+// append_sam_program_info (include/panvc3/utility.hh:92-143)
+void append_program_info(sam_header const &in, sam_header &out, int argc, char **argv)
+{
+	out.programs = in.programs;
+	std::string const prefix = "panvc3.project-alignments.";
+	uint32_t idx = 0;
+	for (auto const &pg : out.programs)
+		if (0 == pg.id.compare(0, prefix.size(), prefix))
+		{
+			char *end{};
+			unsigned long const v = std::strtoul(pg.id.c_str() + prefix.size(), &end, 10);
+			if (end != pg.id.c_str() + prefix.size()) idx = std::max <uint32_t>(idx, (uint32_t) v);
+		}
+	pg_line pg;
+	pg.id = prefix + std::to_string(idx + 1);
+	pg.name = "PanVC 3 project_alignments";
+	for (int i = 0; i < argc; ++i) { if (i) pg.command_line += ' '; pg.command_line += argv[i]; }
+	pg.version = "0.1-mi355x";
+	if (!out.programs.empty()) pg.previous = out.programs.back().id;
+	out.programs.push_back(std::move(pg));
+}
+
+struct pending_record
+{
+	bam_record rec;
+	uint64_t input_index{};		// index among all input records, filtered ones included
+};
+
+}	// anonymous namespace
+
+
+int main(int argc, char **argv)
+{
+	options opt;
+	static option const long_opts[] = {
+		{"alignments", required_argument, nullptr, 'a'}, {"bam-input", no_argument, nullptr, 'B'}, {"msa-index", required_argument, nullptr, 'm'},
+		{"reference", required_argument, nullptr, 'r'}, {"reference-msa-id", required_argument, nullptr, 'd'}, {"ref-id-separator", required_argument, nullptr, 's'},
+		{"reference-order-input", required_argument, nullptr, 'u'}, {"output-path", required_argument, nullptr, 'o'}, {"output-bam", no_argument, nullptr, 'b'},
+		{"status-output-interval", required_argument, nullptr, 1000}, {"output-realigned-ranges", required_argument, nullptr, 'l'},
+		{"keep-duplicate-ranges", no_argument, nullptr, 1001}, {"preserve-tag", required_argument, nullptr, 't'},
+		{"original-rname-tag", required_argument, nullptr, 1002}, {"original-pos-tag", required_argument, nullptr, 1003},
+		{"original-rnext-tag", required_argument, nullptr, 1004}, {"original-pnext-tag", required_argument, nullptr, 1005},
+		{"realigned-query-ranges-tag", required_argument, nullptr, 1006}, {"realigned-ref-ranges-tag", required_argument, nullptr, 1007},
+		{"record-index-tag", required_argument, nullptr, 1008}, {"use-read-base-qualities", no_argument, nullptr, 'q'},
+		{"gap-opening-cost", required_argument, nullptr, 'g'}, {"gap-extension-cost", required_argument, nullptr, 'e'},
+		{"print-invocation", no_argument, nullptr, 1009}, {"print-pid", no_argument, nullptr, 1010}, {"debugging-output", no_argument, nullptr, 1011},
+		{"device", required_argument, nullptr, 1012}, {"batch-size", required_argument, nullptr, 1013}, {"io-only", no_argument, nullptr, 1014},
+		{"help", no_argument, nullptr, 'h'}, {"version", no_argument, nullptr, 'V'}, {nullptr, 0, nullptr, 0}};
+	int c;
+	while (-1 != (c = getopt_long(argc, argv, "a:Bm:r:d:s:u:o:bl:t:qg:e:hV", long_opts, nullptr)))
+	{
+		switch (c)
+		{
+			case 'a': opt.alignments = optarg; break;
+			case 'B': opt.bam_input = true; break;
+			case 'm': opt.msa_index = optarg; break;
+			case 'r': opt.reference = optarg; break;
+			case 'd': opt.reference_msa_id = optarg; break;
+			case 's': opt.separator = optarg; break;
+			case 'u': opt.ref_order = optarg; break;
+			case 'o': opt.output_path = optarg; break;
+			case 'b': opt.output_bam = true; break;
+			case 1000: break;
+			case 'l': opt.realigned_ranges = optarg; break;
+			case 1001: opt.keep_duplicate_ranges = true; break;
+			case 't': opt.preserve_tags.emplace_back(optarg); break;
+			case 1002: opt.rname_tag = optarg; break;
+			case 1003: opt.pos_tag = optarg; break;
+			case 1004: opt.rnext_tag = optarg; break;
+			case 1005: opt.pnext_tag = optarg; break;
+			case 1006: opt.query_ranges_tag = optarg; break;
+			case 1007: opt.ref_ranges_tag = optarg; break;
+			case 1008: opt.rec_idx_tag = optarg; break;
+			case 'q': break;		// stored and never consulted in the reference (quirk Q1)
+			case 'g': opt.gap_open = std::atoi(optarg); break;
+			case 'e': opt.gap_ext = std::atoi(optarg); break;
+			case 1009: opt.print_invocation = true; break;
+			case 1010: opt.print_pid = true; break;
+			case 1011: break;
+			case 1012: opt.device = std::atoi(optarg); break;
+			case 1013: opt.batch_size = std::strtoull(optarg, nullptr, 10); break;
+			case 1014: opt.io_only = true; break;
+			case 'h': usage(); return 0;
+			case 'V': std::cout << "project-alignments 0.1 (panvc3-mi355x)\n"; return 0;
+			default: return EXIT_FAILURE;
+		}
+	}
+	if (opt.print_invocation) { std::cerr << "Invocation:"; for (int i = 0; i < argc; ++i) std::cerr << ' ' << argv[i]; std::cerr << '\n'; }
+	if (opt.print_pid) std::cerr << "PID: " << getpid() << '\n';
+	if (!opt.io_only && (!opt.msa_index || !opt.reference || !opt.reference_msa_id))
+		die("--msa-index, --reference and --reference-msa-id are required");
+
+	// Tag checks (project_alignments.cc:1362-1376).
+	{
+		std::regex const xyz("^[XYZ][A-Za-z0-9]$"), any("^[A-Za-z0-9]{2}$");
+		for (auto const *t : {&opt.rname_tag, &opt.pos_tag, &opt.rnext_tag, &opt.pnext_tag, &opt.query_ranges_tag, &opt.ref_ranges_tag, &opt.rec_idx_tag})
+			if (!t->empty() && !std::regex_match(*t, xyz)) die("The given tag “" + *t + "” does not match the expected format.");
+		for (auto const &t : opt.preserve_tags)
+			if (!std::regex_match(t, any)) die("The given tag “" + t + "” does not match the expected format.");
+	}
+	std::set <uint16_t> preserved;
+	for (auto const *t : PRESERVED_TAGS) preserved.insert(tag_key(t));
+	for (auto const &t : opt.preserve_tags) preserved.insert(tag_key(t.c_str()));
+
+	try
+	{
+		auto const t_start = std::chrono::steady_clock::now();
+		// ---- input + headers -------------------------------------------------------------------------------------------------
+		alignment_reader reader;
+		{
+			bool is_bam = opt.bam_input;
+			if (opt.alignments)
+			{
+				std::string const p(opt.alignments);
+				is_bam = p.size() >= 4 && 0 == p.compare(p.size() - 4, 4, ".bam");
+			}
+			reader.open(opt.alignments, is_bam);
+		}
+		sam_header const &in_header = reader.header;
+		sam_header out_header;
+		std::vector <std::size_t> ref_id_mapping;
+
+		if (opt.io_only)
+		{
+			// Format conversion only (SAM <-> BAM round trips of the I/O layer; no index, no GPU).
+			out_header = in_header;
+			alignment_writer writer;
+			writer.open(opt.output_path, opt.output_bam, out_header);
+			bam_record rec;
+			while (reader.next(rec)) writer.write(rec);
+			writer.close();
+			return 0;
+		}
+
+		process_headers(in_header, opt, out_header, ref_id_mapping);
+		append_program_info(in_header, out_header, argc, argv);
+
+		// ---- index, reference, GPU ---------------------------------------------------------------------------------------------
+		msa_index_file msa;
+		msa.load(opt.msa_index);
+		pvc3_index *index{};
+		check(pvc3_index_create(&index), "pvc3_index_create");
+		std::map <std::pair <std::string, std::string>, uint32_t> entry_ids;
+		auto entry_for = [&](std::string const &chr_id, std::string const &seq_id) -> uint32_t {
+			auto const key = std::make_pair(chr_id, seq_id);
+			auto const it = entry_ids.find(key);
+			if (entry_ids.end() != it) return it->second;
+			auto const *ce = msa.find_chr(chr_id);
+			if (!ce) die("Did not find an entry for chromosome ID “" + chr_id + "” in the MSA index.");
+			auto const *se = msa_index_file::find_seq(*ce, seq_id);
+			if (!se) die("Did not find an entry for sequence ID “" + seq_id + "” in the MSA index.");
+			uint32_t id{};
+			check(pvc3_index_add_bits(index, se->gap_words.data(), se->n_cols, &id), "pvc3_index_add_bits");
+			entry_ids.emplace(key, id);
+			return id;
+		};
+		// fill_sequence_entries (:1271-1316); the separator is matched as a substring here (quirk Q13).
+		std::vector <uint32_t> src_entries(in_header.refs.size()), dst_entries(out_header.refs.size(), UINT32_MAX);
+		for (std::size_t i = 0; i < in_header.refs.size(); ++i)
+		{
+			auto const &name = in_header.refs[i].name;
+			auto const pos = name.find(opt.separator);
+			if (std::string::npos == pos) die("Unable to find the separator “" + opt.separator + "” in the RNAME “" + name + "”.");
+			std::string const chr_id = name.substr(0, pos), seq_id = name.substr(pos + 1);
+			std::size_t const out_idx = ref_id_mapping[i];
+			if (UINT32_MAX == dst_entries[out_idx]) dst_entries[out_idx] = entry_for(chr_id, opt.reference_msa_id);
+			src_entries[i] = entry_for(chr_id, seq_id);
+		}
+		{
+			std::vector <std::pair <std::string, std::vector <char>>> fasta;
+			read_fasta(opt.reference, fasta);
+			for (std::size_t o = 0; o < out_header.refs.size(); ++o)
+			{
+				if (UINT32_MAX == dst_entries[o]) continue;
+				auto const it = std::find_if(fasta.begin(), fasta.end(), [&](auto const &kv) { return kv.first == out_header.refs[o].name; });
+				if (fasta.end() == it) die("Unable to load sequence ‘" + out_header.refs[o].name + "’ from the input FASTA.");
+				check(pvc3_index_set_reference(index, dst_entries[o], it->second.data(), it->second.size()), "pvc3_index_set_reference");
+			}
+		}
+		pvc3_context *ctx{};
+		check(pvc3_context_create(opt.device, &ctx), "pvc3_context_create");
+		check(pvc3_context_upload_index(ctx, index), "pvc3_context_upload_index");
+
+		alignment_writer writer;
+		writer.open(opt.output_path, opt.output_bam, out_header);
+
+		// ---- records ----------------------------------------------------------------------------------------------------------------
+		struct { uint64_t flags_not_matched{}, ref_id_missing{}, seq_missing{}, matched_reads{}; } st;
+		std::map <uint16_t, uint64_t> removed_tag_counts;
+		std::vector <std::pair <uint32_t, uint32_t>> realigned_ranges;
+		uint64_t n_realigned_ranges = 0;
+		pvc3_params const params{opt.gap_open, opt.gap_ext, PVC3_SCORE_FP64, 0};
+
+		std::vector <pending_record> batch;
+		uint64_t input_index = 0;
+		bool eof = false;
+		bam_record rec;
+		std::vector <uint32_t> b_src_pos, b_src_entry, b_dst_entry, b_flags, b_cigar, b_l_seq, b_mate_se, b_mate_de, b_mate_pos;
+		std::vector <uint64_t> b_cigar_off, b_seq_off, b_qual_off;
+		std::vector <uint8_t> b_seq4, b_qual;
+		std::vector <uint32_t> o_dst_pos, o_mate, o_cigar;
+		std::vector <int32_t> o_status;
+		std::vector <uint64_t> o_cigar_off, o_run_off;
+		std::vector <pvc3_run> o_runs;
+		std::string oa;
+		std::map <uint16_t, std::vector <uint8_t>> tags;		// ordered by tag key, as seqan3's sam_tag_dictionary
+
+		while (!eof)
+		{
+			// Fill a batch with records that pass the filters; a multiple of the reference's CHUNK_SIZE (4) unless the input ends.
+			batch.clear();
+			while (batch.size() < opt.batch_size || (batch.size() & 3))
+			{
+				if (!reader.next(rec)) { eof = true; break; }
+				uint64_t const idx = input_index++;
+				uint16_t const fl = rec.flag();
+				if (fl & (0x4 | 0x200 | 0x400)) { ++st.flags_not_matched; continue; }		// unmapped, QC fail, duplicate (:528-537)
+				if (rec.ref_id() < 0) { ++st.ref_id_missing; continue; }						// :546-551
+				if (rec.pos() < 0) { ++st.flags_not_matched; continue; }						// :553-564
+				if (0 == rec.l_seq()) { ++st.seq_missing; continue; }							// :566-570
+				if ((std::size_t) rec.ref_id() >= src_entries.size()) die("record with a reference id outside the header");
+				++st.matched_reads;
+				batch.push_back({rec, idx});
+			}
+			if (batch.empty()) break;
+			uint64_t const n = batch.size();
+
+			// SoA batch (include/pvc3.h).
+			b_src_pos.resize(n); b_src_entry.resize(n); b_dst_entry.resize(n); b_flags.resize(n); b_l_seq.resize(n);
+			b_mate_se.assign(n, 0); b_mate_de.assign(n, 0); b_mate_pos.assign(n, 0);
+			b_cigar_off.assign(1, 0); b_seq_off.assign(1, 0); b_qual_off.assign(1, 0);
+			b_cigar.clear(); b_seq4.clear(); b_qual.clear();
+			for (uint64_t i = 0; i < n; ++i)
+			{
+				bam_record const &r = batch[i].rec;
+				b_src_pos[i] = (uint32_t) r.pos();
+				b_src_entry[i] = src_entries[(std::size_t) r.ref_id()];
+				b_dst_entry[i] = dst_entries[ref_id_mapping[(std::size_t) r.ref_id()]];
+				b_l_seq[i] = r.l_seq();
+				uint32_t fl = r.has_qual() ? PVC3_FLAG_HAS_QUAL : 0;
+				if (r.next_ref_id() >= 0 && r.next_pos() >= 0)
+				{
+					if ((std::size_t) r.next_ref_id() >= src_entries.size()) die("record with a mate reference id outside the header");
+					fl |= PVC3_FLAG_HAS_MATE;
+					b_mate_se[i] = src_entries[(std::size_t) r.next_ref_id()];
+					b_mate_de[i] = dst_entries[ref_id_mapping[(std::size_t) r.next_ref_id()]];
+					b_mate_pos[i] = (uint32_t) r.next_pos();
+				}
+				b_flags[i] = fl;
+				uint8_t const *p = r.data.data();
+				for (uint16_t k = 0; k < r.n_cigar(); ++k) b_cigar.push_back(r.get <uint32_t>(r.cigar_offset() + 4u * k));
+				b_cigar_off.push_back(b_cigar.size());
+				b_seq4.insert(b_seq4.end(), p + r.seq_offset(), p + r.qual_offset());
+				b_seq_off.push_back(b_seq4.size());
+				if (r.has_qual()) b_qual.insert(b_qual.end(), p + r.qual_offset(), p + r.aux_offset());
+				b_qual_off.push_back(b_qual.size());
+			}
+			pvc3_batch_in in{};
+			in.n = n; in.src_pos = b_src_pos.data(); in.src_entry = b_src_entry.data(); in.dst_entry = b_dst_entry.data(); in.flags = b_flags.data();
+			in.cigar_off = b_cigar_off.data(); in.cigar = b_cigar.data(); in.seq_off = b_seq_off.data(); in.l_seq = b_l_seq.data(); in.seq4 = b_seq4.data();
+			in.qual_off = b_qual_off.data(); in.qual = b_qual.data();
+			in.mate_src_entry = b_mate_se.data(); in.mate_dst_entry = b_mate_de.data(); in.mate_pos = b_mate_pos.data();
+
+			pvc3_dbatch *db{};
+			pvc3_batch_stats stats{};
+			check(pvc3_dbatch_create(ctx, &in, &db), "pvc3_dbatch_create");
+			check(pvc3_dbatch_project(ctx, db, &params), "pvc3_dbatch_project");
+			check(pvc3_dbatch_finish(ctx, db, &stats), "pvc3_dbatch_finish");
+			o_dst_pos.resize(n); o_mate.resize(n); o_status.resize(n); o_cigar_off.resize(n + 1); o_run_off.resize(n + 1);
+			o_cigar.resize(stats.out_cigar_total + 1); o_runs.resize(stats.n_runs + 1);
+			pvc3_batch_out out{};
+			out.dst_pos = o_dst_pos.data(); out.mate_dst_pos = o_mate.data(); out.status = o_status.data();
+			out.out_cigar_off = o_cigar_off.data(); out.out_cigar = o_cigar.data(); out.out_cigar_cap = o_cigar.size();
+			out.run_off = o_run_off.data(); out.runs = o_runs.data(); out.run_cap = o_runs.size();
+			check(pvc3_dbatch_download(ctx, db, &out), "pvc3_dbatch_download");
+			pvc3_dbatch_destroy(db);
+
+			// Rewrite and write the records, in input order.
+			for (uint64_t i = 0; i < n; ++i)
+			{
+				bam_record const &r = batch[i].rec;
+				if (o_status[i])
+					die(std::string("record ") + r.read_name() + " (input record " + std::to_string(batch[i].input_index) + ") cannot be projected: status " + std::to_string(o_status[i])
+						+ " (the reference asserts here: position or CIGAR inconsistent with the index)");
+				int32_t const ref_id = r.ref_id();
+				uint32_t const *cig = o_cigar.data() + o_cigar_off[i];
+				uint64_t const n_cig = o_cigar_off[i + 1] - o_cigar_off[i];
+				if (n_cig > 65535) die("more than 65535 CIGAR operations after projection");
+				pvc3_run const *runs = o_runs.data() + o_run_off[i];
+				uint64_t const n_runs = o_run_off[i + 1] - o_run_off[i];
+				n_realigned_ranges += n_runs;
+				if (opt.realigned_ranges)
+					for (uint64_t k = 0; k < n_runs; ++k) realigned_ranges.emplace_back(runs[k].ref_position, runs[k].ref_length);
+
+				// -- tags: keep the preserved ones (:775-802), remember NM
+				tags.clear();
+				bool have_nm = false; int64_t nm = 0;
+				std::string old_oa;
+				for (auto const &f : parse_aux(r.data.data() + r.aux_offset(), r.data.data() + r.data.size()))
+				{
+					uint16_t const key = tag_key(f.tag);
+					if ('N' == f.tag[0] && 'M' == f.tag[1] && aux_scalar_size(f.type) && 'A' != f.type && 'f' != f.type)
+					{
+						have_nm = true;
+						switch (f.type)
+						{
+							case 'c': nm = (int8_t) f.value[0]; break; case 'C': nm = f.value[0]; break;
+							case 's': { int16_t v; std::memcpy(&v, f.value, 2); nm = v; break; } case 'S': { uint16_t v; std::memcpy(&v, f.value, 2); nm = v; break; }
+							case 'i': { int32_t v; std::memcpy(&v, f.value, 4); nm = v; break; } default: { uint32_t v; std::memcpy(&v, f.value, 4); nm = v; break; }
+						}
+					}
+					if (!preserved.count(key)) { ++removed_tag_counts[key]; continue; }
+					if ('O' == f.tag[0] && 'A' == f.tag[1] && 'Z' == f.type) { old_oa.assign((char const *) f.value, f.size - 1); continue; }
+					std::vector <uint8_t> &v = tags[key];
+					v.assign({(uint8_t) f.tag[0], (uint8_t) f.tag[1], (uint8_t) f.type});
+					v.insert(v.end(), f.value, f.value + f.size);
+				}
+				auto put_int = [&](std::string const &name, int64_t v) {
+					if (name.empty()) return;
+					std::vector <uint8_t> &d = tags[tag_key(name.c_str())];
+					d.clear();
+					append_int_aux(d, name.c_str(), v);
+				};
+				auto put_ranges = [&](std::string const &name, bool query) {
+					if (name.empty() || 0 == n_runs) return;
+					std::vector <uint8_t> &d = tags[tag_key(name.c_str())];
+					d.assign({(uint8_t) name[0], (uint8_t) name[1], 'B', 'I'});
+					uint32_t const cnt = (uint32_t) (2 * n_runs); uint8_t b[4]; std::memcpy(b, &cnt, 4); d.insert(d.end(), b, b + 4);
+					for (uint64_t k = 0; k < n_runs; ++k)
+					{
+						uint32_t const lo = query ? runs[k].query_location : runs[k].ref_position;
+						uint32_t const hi = lo + (query ? runs[k].query_length : runs[k].ref_length);
+						std::memcpy(b, &lo, 4); d.insert(d.end(), b, b + 4); std::memcpy(b, &hi, 4); d.insert(d.end(), b, b + 4);
+					}
+				};
+				// -- OA (:805-844): RNAME,POS (0-based as the reference prints it),strand,CIGAR,MAPQ,NM;
+				oa = old_oa;
+				oa += in_header.refs[(std::size_t) ref_id].name; oa += ','; oa += std::to_string(r.pos()); oa += ',';
+				oa += (r.flag() & 0x10) ? '-' : '+'; oa += ',';
+				for (uint16_t k = 0; k < r.n_cigar(); ++k)
+				{
+					uint32_t const cc = r.get <uint32_t>(r.cigar_offset() + 4u * k);
+					oa += std::to_string(cc >> 4); oa += CIGAR_CHARS[(cc & 0xf) < 9 ? (cc & 0xf) : 0];
+				}
+				oa += ','; oa += std::to_string((unsigned) r.mapq()); oa += ',';
+				if (have_nm) oa += std::to_string(nm);
+				oa += ';';
+				{
+					std::vector <uint8_t> &d = tags[tag_key("OA")];
+					d.assign({'O', 'A', 'Z'});
+					d.insert(d.end(), oa.begin(), oa.end()); d.push_back(0);
+				}
+				put_ranges(opt.query_ranges_tag, true);		// :848-861
+				put_ranges(opt.ref_ranges_tag, false);
+				if (!opt.rec_idx_tag.empty())				// :864-869: the same value for the (up to) four records of a chunk
+				{
+					uint64_t const chunk_begin = i & ~UINT64_C(3), chunk_end = std::min <uint64_t>(chunk_begin + 4, n);
+					uint64_t const xi = batch[chunk_end - 1].input_index - (chunk_end - chunk_begin) + 1;
+					if (xi <= INT32_MAX) put_int(opt.rec_idx_tag, (int64_t) xi);
+				}
+				put_int(opt.rname_tag, ref_id);				// :872-877
+				put_int(opt.pos_tag, r.pos());
+
+				// -- mate (:880-911)
+				int32_t new_next_ref = -1, new_next_pos = -1;
+				if (r.next_ref_id() >= 0)
+				{
+					new_next_ref = (int32_t) ref_id_mapping[(std::size_t) r.next_ref_id()];
+					put_int(opt.rnext_tag, r.next_ref_id());
+					if (r.next_pos() >= 0)
+					{
+						if (PVC3_NO_MATE == o_mate[i]) die(std::string("the mate position of ") + r.read_name() + " lies outside its sequence");
+						new_next_pos = (int32_t) o_mate[i];
+						put_int(opt.pnext_tag, r.next_pos());
+					}
+				}
+
+				// -- the new record (:915-918)
+				bam_record w;
+				std::size_t const name_end = 32 + r.l_read_name();
+				w.data.assign(r.data.begin(), r.data.begin() + (std::ptrdiff_t) name_end);
+				w.set <int32_t>(0, (int32_t) ref_id_mapping[(std::size_t) ref_id]);
+				w.set <int32_t>(4, (int32_t) o_dst_pos[i]);
+				w.set <uint16_t>(12, (uint16_t) n_cig);
+				w.set <int32_t>(20, new_next_ref);
+				w.set <int32_t>(24, new_next_pos);
+				int64_t span = 0;
+				for (uint64_t k = 0; k < n_cig; ++k) { uint32_t const op = cig[k] & 0xf; if (0 == op || 2 == op || 3 == op || 7 == op || 8 == op) span += cig[k] >> 4; }
+				w.set <uint16_t>(10, reg2bin(o_dst_pos[i], (int64_t) o_dst_pos[i] + (span ? span : 1)));
+				w.data.insert(w.data.end(), (uint8_t const *) cig, (uint8_t const *) (cig + n_cig));
+				// SEQ through seqan3::dna5 (non-ACGT becomes N), QUAL through phred42 (saturates at 41)
+				std::size_t const seq_at = w.data.size();
+				w.data.insert(w.data.end(), r.seq4(), r.seq4() + (r.l_seq() + 1) / 2);
+				for (uint32_t k = 0; k < r.l_seq(); ++k)
+				{
+					uint8_t &byte = w.data[seq_at + (k >> 1)];
+					unsigned const shift = (~k & 1u) << 2;
+					unsigned const code = (byte >> shift) & 0xf;
+					if (1 != code && 2 != code && 4 != code && 8 != code) byte = (uint8_t) ((byte & ~(0xf << shift)) | (15u << shift));
+				}
+				std::size_t const qual_at = w.data.size();
+				w.data.insert(w.data.end(), r.qual(), r.qual() + r.l_seq());
+				if (r.has_qual()) for (uint32_t k = 0; k < r.l_seq(); ++k) if (w.data[qual_at + k] > 41) w.data[qual_at + k] = 41;
+				for (auto const &kv : tags) w.data.insert(w.data.end(), kv.second.begin(), kv.second.end());
+				writer.write(w);
+			}
+		}
+		writer.close();
+		pvc3_context_destroy(ctx);
+		pvc3_index_destroy(index);
+
+		// ---- finish (:1033-1073) ---------------------------------------------------------------------------------------------------------
+		if (opt.realigned_ranges)
+		{
+			if (!opt.keep_duplicate_ranges)
+			{
+				std::sort(realigned_ranges.begin(), realigned_ranges.end());
+				realigned_ranges.erase(std::unique(realigned_ranges.begin(), realigned_ranges.end()), realigned_ranges.end());
+			}
+			FILE *f = std::fopen(opt.realigned_ranges, "w");
+			if (!f) die(std::string("unable to open ") + opt.realigned_ranges);
+			std::fputs("Location\tLength\n", f);
+			for (auto const &rr : realigned_ranges) std::fprintf(f, "%u\t%u\n", rr.first, rr.second);
+			std::fclose(f);
+		}
+		double const secs = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+		std::cerr << "Done. Time spent: " << secs << " s.\n";
+		std::cerr << "\tMatched reads:         " << st.matched_reads << '\n';
+		std::cerr << "\tReference ID missing:  " << st.ref_id_missing << '\n';
+		std::cerr << "\tFlags not matched:     " << st.flags_not_matched << '\n';
+		std::cerr << "\tSequence missing:      " << st.seq_missing << '\n';
+		std::cerr << "\tRe-aligned ranges:     " << n_realigned_ranges << '\n';
+		if (!removed_tag_counts.empty())
+		{
+			std::cerr << "\tRemoved tags:\n";
+			for (auto const &kv : removed_tag_counts)
+				std::cerr << "\t\t" << (char) (kv.first >> 8) << (char) (kv.first & 0xff) << ": " << kv.second << '\n';
+		}
+	}
+	catch (std::exception const &e)
+	{
+		die(e.what());
+	}
+	return 0;
+}

@@ -1,0 +1,242 @@
+"""The C++ host pipeline: panvc3_index_msa, the SAM/BAM I/O layer and the panvc3_project_alignments
+command line.  The index tool and the I/O layer are tested on the CPU; the projecting command line needs a GPU.
+
+Expected outputs come from oracle/project_records.py, a restatement of the reference's record / header rewriting
+(parity against the real binary is unpinned: the reference has no test and no checked-in output for this layer)."""
+import os
+import shutil
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, ROOT, load_test_msa
+
+import bamio
+
+BIN = os.path.join(ROOT, "bin")
+
+
+@pytest.fixture(scope="module")
+def tools():
+	from panvc3_amd import build
+	build.build_host()
+	return {n: os.path.join(BIN, n) for n in ("panvc3_index_msa", "panvc3_project_alignments")}
+
+
+def _run(cmd, cwd=None, check=True):
+	p = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+	if check and p.returncode != 0:
+		raise AssertionError("%s failed (%d): %s" % (cmd[0], p.returncode, p.stderr.decode()[-2000:]))
+	return p
+
+
+def _read_index_file(path):
+	raw = open(path, "rb").read()
+	assert raw[:8] == b"PVC3IDX\x01"
+	p = 8
+	n_chr, = struct.unpack_from("<I", raw, p); p += 4
+	out = {}
+	for _ in range(n_chr):
+		l, = struct.unpack_from("<I", raw, p); p += 4
+		chr_id = raw[p:p + l].decode(); p += l
+		n_seq, = struct.unpack_from("<I", raw, p); p += 4
+		for _ in range(n_seq):
+			l, = struct.unpack_from("<I", raw, p); p += 4
+			seq_id = raw[p:p + l].decode(); p += l
+			n_cols, = struct.unpack_from("<Q", raw, p); p += 8
+			nw = (n_cols + 63) // 64
+			words = np.frombuffer(raw, dtype="<u8", count=nw, offset=p).copy(); p += 8 * nw
+			out[(chr_id, seq_id)] = (n_cols, words)
+	assert p == len(raw)
+	return out
+
+
+def _setup_msa_dir(tmp_path):
+	d = tmp_path / "index-input" / "sequences"
+	d.mkdir(parents=True)
+	for f in os.listdir(os.path.join(GOLDEN, "test_msa")):
+		if f.endswith(".bz2"):
+			shutil.copy(os.path.join(GOLDEN, "test_msa", f), d / f)
+	shutil.copy(os.path.join(GOLDEN, "test_msa", "input.tsv"), tmp_path / "index-input" / "input.tsv")
+
+
+@pytest.fixture()
+def built_index(tools, tmp_path):
+	"""The test-workflow's build_msa_index rule (test-workflow/Snakefile:36) on the shipped MSA."""
+	_setup_msa_dir(tmp_path)
+	pipe = "bzip2 -d -c" if shutil.which("bzip2") else "%s -c \"import bz2,sys;sys.stdout.buffer.write(bz2.open(sys.argv[1]).read())\"" % sys.executable
+	p = _run([tools["panvc3_index_msa"], "--build-index", "--sequence-inputs=index-input/input.tsv", "--msa-index-output=msa-index.dat", "--output-fasta", "--pipe-input=" + pipe], cwd=tmp_path)
+	return tmp_path, p.stdout.decode()
+
+
+def test_index_msa_on_shipped_msa(tools, built_index):
+	tmp_path, fasta = built_index
+	rows = load_test_msa()
+	# FASTA: ">chr/seq" + the non-gap bytes on one line (index-msa/index_vector_builder.cc:15-58), in input order
+	expect = "".join(">test/%s\n%s\n" % (k, rows[k].replace(b"-", b"").decode()) for k in ("REF", "1", "2", "3", "4"))
+	assert fasta == expect
+	idx = _read_index_file(tmp_path / "msa-index.dat")
+	assert sorted(idx) == [("test", k) for k in sorted(rows)]		# sorted by id like the reference
+	for k, row in rows.items():
+		n_cols, words = idx[("test", k)]
+		assert n_cols == len(row) == 12636
+		gaps = np.frombuffer(row, dtype=np.uint8) == ord("-")
+		bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n_cols].astype(bool)
+		assert np.array_equal(bits, gaps)
+	out = _run([tools["panvc3_index_msa"], "--list-contents", "--msa-index-input=msa-index.dat"], cwd=tmp_path).stdout.decode()
+	assert out == "test (5 sequences of 12636 characters)\n" + "".join("\t%s\n" % k for k in sorted(rows))
+	# --fasta-line-width
+	p = _run([tools["panvc3_index_msa"], "-B", "-i", "index-input/input.tsv", "-m", "x.dat", "-f", "-w", "60", "-p", "bzip2 -d -c" if shutil.which("bzip2") else "bzcat"], cwd=tmp_path, check=False)
+	if p.returncode == 0:
+		lines = p.stdout.decode().split("\n")
+		assert lines[0] == ">test/REF" and all(len(x) == 60 for x in lines[1:167]) and len(lines[167]) == 10000 - 166 * 60
+
+
+def test_index_msa_a2m_and_errors(tools, tmp_path):
+	(tmp_path / "in.a2m").write_text(">chrB s2\nAC-GT\nAC\n>chrA\tREF\nACGT--A\n>chrB REF\nA--GTAC\n")
+	_run([tools["panvc3_index_msa"], "--build-index", "--sequences=in.a2m", "--msa-index-output=o.dat"], cwd=tmp_path)
+	idx = _read_index_file(tmp_path / "o.dat")
+	assert list(idx) == [("chrA", "REF"), ("chrB", "REF"), ("chrB", "s2")]
+	assert idx[("chrB", "s2")][0] == 7 and int(idx[("chrB", "s2")][1][0]) == 0b0000100
+	(tmp_path / "bad.a2m").write_text(">c a\nACGT\n>c b\nAC\n")
+	p = _run([tools["panvc3_index_msa"], "--build-index", "--sequences=bad.a2m", "--msa-index-output=o2.dat"], cwd=tmp_path, check=False)
+	assert p.returncode != 0 and b"expected 4" in p.stderr
+	p = _run([tools["panvc3_project_alignments"], "--alignments=nonexistent.sam", "--msa-index=o.dat", "--reference=x.fa", "--reference-msa-id=REF"], cwd=tmp_path, check=False)
+	assert p.returncode != 0
+	p = _run([tools["panvc3_project_alignments"], "--original-pos-tag=AB", "--alignments=x", "--msa-index=o.dat", "--reference=x.fa", "--reference-msa-id=REF"], cwd=tmp_path, check=False)
+	assert p.returncode != 0 and b"does not match the expected format" in p.stderr
+
+
+def _make_records(synth_mod, rows, n=600, seed=5):
+	"""Reads sampled from the shipped MSA as bowtie2-like SAM records (pairs, tags, a few records that must be dropped)."""
+	order = ["REF", "1", "2", "3", "4"]
+	genome = synth_mod.Genome(aligned_rows=[rows[k] for k in order])
+	gp, rp, _ = synth_mod.config("C3", scale=1e-6)
+	rp.n_records = n; rp.read_len = 100; rp.seed = seed; rp.indel_read_frac = 0.2; rp.clip_read_frac = 0.2
+	reads = synth_mod.Reads(genome, rp)
+	b = reads.batch(copy=True)
+	rng = np.random.default_rng(seed)
+	names = ["test/REF", "test/1", "test/2", "test/3", "test/4"]		# entry e of the genome <-> names[e]
+	recs = []
+	for i in range(reads.n):
+		cig = "".join("%d%s" % (int(c) >> 4, "MIDNSHP=X"[int(c) & 15]) for c in b["cigar"][int(b["cigar_off"][i]):int(b["cigar_off"][i + 1])])
+		s4 = b["seq4"][int(b["seq_off"][i]):int(b["seq_off"][i + 1])]
+		L = int(b["l_seq"][i])
+		seq = "".join("=ACMGRSVTWYHKDBN"[(int(s4[k >> 1]) >> (4 if k % 2 == 0 else 0)) & 15] for k in range(L))
+		qual = "".join(chr(33 + int(q)) for q in b["qual"][int(b["qual_off"][i]):int(b["qual_off"][i + 1])])
+		first = i % 2 == 0
+		flag = (99 if first else 147)
+		tags = [("AS", "i", -int(rng.integers(0, 30))), ("XS", "i", -int(rng.integers(0, 60))), ("NM", "i", int(rng.integers(0, 5))), ("MD", "Z", "100"), ("YS", "i", -3), ("YT", "Z", "CP")]
+		if i % 7 == 0:
+			tags.append(("OA", "Z", "old/1,5,+,3M,2,0;"))
+		if i % 11 == 0:
+			tags.append(("ZB", "B", ("S", [1, 2, 3])))
+		if i % 13 == 0:
+			tags = [t for t in tags if t[0] != "NM"]
+		rec = bamio.Record("read%d" % (i // 2), flag, names[int(b["src_entry"][i])], int(b["src_pos"][i]) + 1, int(rng.integers(0, 43)), cig, "=", int(b["mate_pos"][i]) + 1,
+						   300 if first else -300, seq, qual, tags)
+		if i % 17 == 0:
+			rec.seq = rec.seq[:10] + "R" + rec.seq[11:]			# IUPAC code: N after dna5
+		if i % 19 == 0:
+			rec.qual = "".join(chr(min(126, ord(c) + 20)) for c in rec.qual)	# beyond phred 41: saturates
+		recs.append(rec)
+		if i % 23 == 0:
+			recs.append(bamio.Record("unmapped%d" % i, 77, "*", 0, 0, "*", "*", 0, 0, "ACGT", "IIII", [("YT", "Z", "UP")]))
+		if i % 29 == 0:
+			recs.append(bamio.Record("dup%d" % i, flag | 0x400, rec.rname, rec.pos, rec.mapq, rec.cigar, "=", rec.pnext, rec.tlen, rec.seq, rec.qual, []))
+		if i % 31 == 0:
+			recs.append(bamio.Record("nomate%d" % i, 0, rec.rname, rec.pos, 7, rec.cigar, "*", 0, 0, rec.seq, "*", [("XS", "i", 5)]))
+		if i % 37 == 0:
+			recs.append(bamio.Record("othermate%d" % i, 65, rec.rname, rec.pos, 7, rec.cigar, "test/3", 17, 0, rec.seq, rec.qual, []))
+	return genome, recs, names
+
+
+def test_io_round_trip_sam_bam(tools, tmp_path):
+	from tests.synth import synth
+	rows = load_test_msa()
+	genome, recs, names = _make_records(synth, rows, n=200)
+	header = "@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, 10000 + i) for i, n in enumerate(names)) + "@RG\tID:g1\tSM:s\n@PG\tID:bowtie2\tPN:bowtie2\tVN:2.5.1\tCL:\"bowtie2 -x i\"\n@CO\thello\n"
+	bamio.write_sam(tmp_path / "in.sam", header, recs)
+	_run([tools["panvc3_project_alignments"], "--io-only", "--alignments=in.sam", "--output-bam", "--output-path=x.bam"], cwd=tmp_path)
+	text, refs, got = bamio.read_bam(tmp_path / "x.bam")
+	assert refs == [(n, 10000 + i) for i, n in enumerate(names)]
+	assert len(got) == len(recs)
+	ref_index = {n: i for i, n in enumerate(names)}
+	for g, r in zip(got, recs):
+		assert g["qname"] == r.qname and g["flag"] == r.flag and g["pos"] == r.pos - 1 and g["cigar"] == r.cigar and g["seq"] == r.seq.upper() and g["qual"] == r.qual
+		assert g["ref_id"] == (-1 if r.rname == "*" else ref_index[r.rname])
+		assert [(t[0], t[1], t[2]) for t in g["tags"]] == [tuple(t) for t in r.tags]
+	# BAM -> SAM reproduces the original text (header in seqan3's field order)
+	_run([tools["panvc3_project_alignments"], "--io-only", "--alignments=x.bam", "--output-path=back.sam"], cwd=tmp_path)
+	back = open(tmp_path / "back.sam").read().split("\n")
+	body = [l for l in back if l and not l.startswith("@")]
+	assert body == [r.sam_line() for r in recs]
+	assert [l for l in back if l.startswith("@SQ")] == ["@SQ\tSN:%s\tLN:%d" % (n, 10000 + i) for i, n in enumerate(names)]
+	# python-written BAM is read too (bgzf blocks written by another implementation)
+	bamio.write_bam(tmp_path / "py.bam", header, [(n, 10000 + i) for i, n in enumerate(names)], recs)
+	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "py.bam", "-o", "py.sam"], cwd=tmp_path)
+	assert [l for l in open(tmp_path / "py.sam").read().split("\n") if l and not l.startswith("@")] == [r.sam_line() for r in recs]
+
+
+@pytest.mark.gpu
+def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_mod):
+	"""The workflow's command line (test-workflow/Snakefile:76-86) end to end: BAM in, SAM on stdout; and BAM out, ranges TSV."""
+	from oracle import project_records as pr
+	from tests.synth import synth
+	tmp_path, fasta = built_index
+	rows = load_test_msa()
+	genome, recs, names = _make_records(synth, rows, n=1200)
+	ref_text = rows["REF"].replace(b"-", b"").decode()
+	with open(tmp_path / "genome.fa", "w") as f:
+		f.write(">test some description\n")
+		for i in range(0, len(ref_text), 70):
+			f.write(ref_text[i:i + 70] + "\n")
+	subprocess.check_call(["gzip", "-k", "genome.fa"], cwd=tmp_path)
+	(tmp_path / "order.txt").write_text("nosuch\ntest\t10000\n")
+	lens = {n: len(rows[k].replace(b"-", b"")) for n, k in zip(names, ["REF", "1", "2", "3", "4"])}
+	in_refs = [(n, lens[n], "M5:abc" if n == "test/REF" else "") for n in ["test/2", "test/REF", "test/1", "test/4", "test/3"]]		# header order != entry order
+	header = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d%s\n" % (n, l, ("\t" + e) if e else "") for n, l, e in in_refs)
+	header += "@RG\tID:g1\tSM:s\n@PG\tID:bowtie2\tPN:bowtie2\tVN:2.5.1\tCL:\"bowtie2 -x i\"\n@PG\tID:panvc3.project-alignments.3\tPN:x\tPP:bowtie2\n@CO\thello\n"
+	bamio.write_bam(tmp_path / "alignments.sorted.bam", header, [(n, l) for n, l, e in in_refs], recs)
+	bamio.write_sam(tmp_path / "alignments.sam", header, recs)
+
+	o = oracle_mod.Oracle()
+	seq_of = {"test/REF": "REF", "test/1": "1", "test/2": "2", "test/3": "3", "test/4": "4"}
+	ent = {n: o.add_aligned(rows[seq_of[n]]) for n in names}
+	o.set_reference(ent["test/REF"], ref_text)
+	out_refs, mapping, chr_seq = pr.process_headers(in_refs, "/", "REF", ["nosuch", "test"])
+	assert out_refs == [("test", 10000, "M5:abc")]
+	src_entries = [ent[n] for n, _, _ in in_refs]
+	dst_entries = [ent["test/REF"]]
+	opts = dict(preserve={"XS", "YS"}, rname_tag="XR", pos_tag="XP", rnext_tag="YR", pnext_tag="YP", query_ranges_tag="XB", ref_ranges_tag="YB", rec_idx_tag="XI")
+	expect, ranges = pr.project_records(recs, in_refs, o, src_entries, dst_entries, mapping, out_refs, opts)
+	assert len(expect) > 1000 and any("\tXB:B:I," in l for l in expect)
+
+	cmd = [tools["panvc3_project_alignments"], "--alignments=alignments.sorted.bam", "--msa-index=msa-index.dat", "--reference=genome.fa.gz", "--reference-msa-id=REF",
+		   "--ref-id-separator=/", "--reference-order-input=order.txt", "--record-index-tag=XI", "--preserve-tag=XS", "--preserve-tag=YS",
+		   "--output-realigned-ranges=ranges.tsv", "--batch-size=256"]
+	p = _run(cmd, cwd=tmp_path)
+	out = p.stdout.decode().split("\n")
+	head = [l for l in out if l.startswith("@")]
+	body = [l for l in out if l and not l.startswith("@")]
+	assert body == expect
+	assert head[0] == "@HD\tVN:1.6" and head[1] == "@SQ\tSN:test\tLN:10000\tM5:abc" and head[2] == "@RG\tID:g1\tSM:s"
+	assert head[3:5] == ["@PG\tID:bowtie2\tPN:bowtie2\tCL:\"bowtie2 -x i\"\tVN:2.5.1", "@PG\tID:panvc3.project-alignments.3\tPN:x\tPP:bowtie2"]
+	assert head[5].startswith("@PG\tID:panvc3.project-alignments.4\tPN:PanVC 3 project_alignments\tCL:") and "\tPP:panvc3.project-alignments.3\t" in head[5]
+	assert head[6] == "@CO\thello"
+	assert open(tmp_path / "ranges.tsv").read() == "Location\tLength\n" + "".join("%d\t%d\n" % r for r in ranges)
+	assert b"Matched reads:" in p.stderr
+
+	# SAM in (gz), BAM out, one big batch: same records
+	subprocess.check_call(["gzip", "-k", "alignments.sam"], cwd=tmp_path)
+	_run([tools["panvc3_project_alignments"], "-a", "alignments.sam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-u", "order.txt", "--record-index-tag=XI", "-t", "XS", "-t", "YS", "-b", "-o", "out.bam"], cwd=tmp_path)
+	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "out.bam", "-o", "out.sam"], cwd=tmp_path)
+	assert [l for l in open(tmp_path / "out.sam").read().split("\n") if l and not l.startswith("@")] == expect
+	text, refs, got = bamio.read_bam(tmp_path / "out.bam")
+	assert refs == [("test", 10000)]
+	for g in got[:50]:
+		span = sum(n for n, op in bamio.parse_cigar(g["cigar"]) if op in "MDN=X")
+		assert g["bin"] == bamio.reg2bin(g["pos"], g["pos"] + (span or 1))

@@ -19,7 +19,7 @@ namespace pvc3 {
 namespace {
 
 constexpr uint32_t REALIGN_LDS_BYTES = 8192;		// per wave (= per block); larger alignments use the wave's global scratch slot
-constexpr uint32_t TR_DIAG = 0, TR_UP = 1, TR_LEFT = 2, TR_DIR_MASK = 3, TR_V_OPEN = 4, TR_H_OPEN = 8;
+constexpr uint32_t TR_DIAG = 0, TR_UP = 1, TR_LEFT = 2, TR_DIR_MASK = 3, TR_V_OPEN = 4, TR_H_OPEN = 8, TR_MATCH = 16;
 constexpr uint32_t MAX_PHRED = 41;
 
 // seqan3::dna5 ranks (A C G N T); assign_char is case-insensitive, U -> T, anything else -> N.
@@ -97,27 +97,17 @@ __device__ __forceinline__ void align_global(
 	for (uint32_t j = lane; j < m; j += 64)
 		mem.ref_rank[j] = (uint8_t) dna5_rank_of_char(ref[j]);
 
-	// First column and first row, serially (initialise_first_column_cell / initialise_first_row_cell).
-	if (0 == lane)
+	// First column and first row (initialise_first_column_cell / initialise_first_row_cell).  The recurrence
+	//     x_1 = go,  x_k = max(x_{k-1} + go [open], x_{k-1} + ge [extension, kept on ties])
+	// has the closed forms k * (open + ext) when the opening score is positive and open + k * ext otherwise; all values are
+	// small integers, so the products are exactly the iterated sums of the oracle.
 	{
-		double mm = 0.0, v = neg_inf;
-		mem.col_m[0] = 0.0;
-		for (uint32_t i = 1; i <= n; ++i)
+		double const open = (double) prm->gap_open;
+		for (uint32_t k = lane; k <= (m > n ? m : n); k += 64)
 		{
-			double const open = mm + go, ext = v + ge;
-			v = (ext < open) ? open : ext;
-			mm = v;
-			mem.col_m[i] = mm;
-		}
-		double h = neg_inf;
-		mm = 0.0;
-		mem.bnd_m[0] = 0.0; mem.bnd_v[0] = neg_inf;
-		for (uint32_t j = 1; j <= m; ++j)
-		{
-			double const open = mm + go, ext = h + ge;
-			h = (ext < open) ? open : ext;
-			mm = h;
-			mem.bnd_m[j] = mm; mem.bnd_v[j] = neg_inf;
+			double const x = (0 == k) ? 0.0 : ((open > 0.0) ? (double) k * go : open + (double) k * ge);
+			if (k <= n) mem.col_m[k] = x;
+			if (k <= m) { mem.bnd_m[k] = x; mem.bnd_v[k] = neg_inf; }
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -169,7 +159,7 @@ __device__ __forceinline__ void align_global(
 				uint32_t dir = TR_DIAG;
 				if (best < v) { best = v; dir = TR_UP; }
 				if (best < h) { best = h; dir = TR_LEFT; }
-				mem.trace[(uint64_t) (i - 1) * m + (j - 1)] = (uint8_t) (tr | dir);
+				mem.trace[(uint64_t) (i - 1) * m + (j - 1)] = (uint8_t) (tr | dir | ((r_rank == q_rank) ? TR_MATCH : 0));
 				m_left = best; h_left = h; cur_m = best; cur_v = v; diag = up_m;
 				if (lane == nr - 1) { mem.bnd_m[j] = best; mem.bnd_v[j] = v; }
 			}
@@ -197,8 +187,7 @@ __device__ __forceinline__ void align_global(
 				uint32_t const dir = t & TR_DIR_MASK;
 				if (TR_DIAG == dir)
 				{
-					uint32_t const eq = (uint32_t) mem.ref_rank[j - 1] == dna5_rank_of_seq4(seq4_at(seq4, q0 + i - 1));
-					mem.rev[k] = (uint8_t) (rfl(eq) ? OP_EQ : OP_X);		// wave-uniform stores
+					mem.rev[k] = (uint8_t) ((t & TR_MATCH) ? OP_EQ : OP_X);		// align.hh:103-106; wave-uniform stores
 					++k; --i; --j;
 					continue;
 				}
@@ -349,8 +338,12 @@ __global__ __launch_bounds__(64) void k_realign(
 					if ((uint64_t) run_query_loc + nq > l_seq) { status = PVC3_ST_QUERY_RANGE; break; }
 
 					uint64_t const need = dp_bytes(m, nq);
-					uint8_t *mem_base = lds;
-					if (need > lds_budget)
+					if (need <= lds_budget)
+					{
+						// Separate call site: after inlining every access is provably to LDS (ds_read / ds_write instead of flat_*).
+						align_global(D.text + run_ref_loc, m, seq4, run_query_loc, nq, qual, prm, dp_carve(lds, m, nq), out, lane);
+					}
+					else
 					{
 						if (need > W.scratch_per_wave)
 						{
@@ -359,9 +352,8 @@ __global__ __launch_bounds__(64) void k_realign(
 							status = 0xff;	// not a record status: the host grows the scratch and repeats
 							break;
 						}
-						mem_base = W.scratch + (uint64_t) wave * W.scratch_per_wave;
+						align_global(D.text + run_ref_loc, m, seq4, run_query_loc, nq, qual, prm, dp_carve(W.scratch + (uint64_t) wave * W.scratch_per_wave, m, nq), out, lane);
 					}
-					align_global(D.text + run_ref_loc, m, seq4, run_query_loc, nq, qual, prm, dp_carve(mem_base, m, nq), out, lane);
 				}
 				else if (prev_type)
 				{

@@ -63,11 +63,9 @@ __device__ __forceinline__ uint32_t mismatch8(uint32_t q, uint64_t r)
 	return m;
 }
 
-// Mismatch bits of 32 consecutive query nibbles (16 bytes at q) against 32 text bytes at t.
-__device__ __forceinline__ uint32_t mismatch32(uint8_t const *q, uint8_t const *t)
+// Mismatch bits of 32 consecutive query nibbles (16 bytes of SEQ) against 32 text bytes.
+__device__ __forceinline__ uint32_t mismatch32(u64x2 const &qq, u64x2 const &t0, u64x2 const &t1)
 {
-	u64x2 const qq = load_u128_unaligned(q);
-	u64x2 const t0 = load_u128_unaligned(t), t1 = load_u128_unaligned(t + 16);
 	uint64_t const q0 = nibble_linear(qq.x), q1 = nibble_linear(qq.y);
 	return mismatch8((uint32_t) q0, t0.x) | (mismatch8((uint32_t) (q0 >> 32), t0.y) << 8)
 		| (mismatch8((uint32_t) q1, t1.x) << 16) | (mismatch8((uint32_t) (q1 >> 32), t1.y) << 24);
@@ -82,6 +80,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lan
 		if (lane >= off) v += t;
 	}
 	return v;
+}
+
+// Orders this wave's LDS writes before its later LDS reads (the LDS queue of a wave is in-order; this stops the compiler).
+__device__ __forceinline__ void wave_lds_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ uint32_t wave_max(uint32_t v)
@@ -112,6 +118,12 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	for (uint32_t i = threadIdx.x; i < LDS_ENTRIES && i < n_entries; i += blockDim.x)
 		lds_entries[i] = entries[i];
 	__syncthreads();
+	// Per-wave staging for the cooperative compare: record descriptors out, mismatch words back.
+	__shared__ u64x2 lds_desc[4][64];
+	__shared__ uint32_t lds_mask[4][64 * FAST_WORDS];
+	uint32_t const wave_in_block = rfl(threadIdx.x >> 6);
+	u64x2 *my_desc = lds_desc[wave_in_block];
+	uint32_t *my_mask = lds_mask[wave_in_block];
 	auto get_entry = [&](uint32_t id) -> dev_entry { return (id < LDS_ENTRIES) ? lds_entries[id] : entries[id]; };
 	uint64_t acc_bitvec = 0, acc_ref = 0, acc_bytes = 0;
 
@@ -239,20 +251,61 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			uint32_t const U = fast ? (R + phase) : 0;
 			uint8_t const *qp = in.seq4 + seq_begin + (lead_q >> 1);
 			uint8_t const *tp = d_text + r0 - phase;		// texts have TEXT_FRONT_PAD readable bytes in front
-			uint32_t const n_words = (wave_max(U) + 31) / 32;
-			uint32_t mu[FAST_WORDS + 1];
-#pragma unroll
-			for (uint32_t w = 0; w < FAST_WORDS; ++w)
+			uint32_t const n_words = (wave_max(U) + 31) / 32;		// 1 .. FAST_WORDS
+			// The compare is done by n_words lanes per record, one 32-position word each: a wave instruction then touches the
+			// lines of 64 / n_words records instead of one line per lane, which the memory pipeline serves 2-3x faster
+			// (tools/calib/random_access.hip).  Descriptors go to the lanes through LDS, the masks come back the same way.
 			{
-				mu[w] = 0;
-				if (w < n_words)
-				{
+				u64x2 d;
+				d.x = (uint64_t) qp | ((uint64_t) U << 48);
+				d.y = (uint64_t) tp;
+				my_desc[lane] = d;
+			}
+			wave_lds_sync();
+			{
+				uint32_t const inv = (65536 + n_words - 1) / n_words;
+				uint32_t const per = (64 * inv) >> 16;			// records per pass
+				uint32_t const sr = (lane * inv) >> 16;				// lane / n_words
+				uint32_t const w = lane - sr * n_words;
+				auto fetch = [&](uint32_t rr, bool act, u64x2 &qq, u64x2 &t0, u64x2 &t1, uint32_t &left) {
+					u64x2 const dd = my_desc[act ? rr : lane];
+					uint32_t const Ur = (uint32_t) (dd.x >> 48);
+					left = (act && Ur > 32 * w) ? (Ur - 32 * w) : 0;
+					if (left)		// loads stay inside the record (+ at most 31 positions of padding)
+					{
+						uint8_t const *q = (uint8_t const *) (dd.x & UINT64_C(0xFFFFFFFFFFFF)) + 16 * w;
+						uint8_t const *t = (uint8_t const *) dd.y + 32 * w;
+						qq = load_u128_unaligned(q); t0 = load_u128_unaligned(t); t1 = load_u128_unaligned(t + 16);
+					}
+				};
+				auto finish = [&](uint32_t rr, bool act, u64x2 const &qq, u64x2 const &t0, u64x2 const &t1, uint32_t left) {
 					uint32_t m = 0;
-					if (32 * w < U)		// per lane: loads stay inside the record (+ at most 31 positions of padding)
-						m = mismatch32(qp + 16 * w, tp + 32 * w);
-					uint32_t const left = (U > 32 * w) ? (U - 32 * w) : 0;
-					mu[w] = m & (uint32_t) low_mask(left < 32 ? left : 32);
+					if (left)
+						m = mismatch32(qq, t0, t1) & (uint32_t) low_mask(left < 32 ? left : 32);
+					if (act) my_mask[rr * FAST_WORDS + w] = m;
+				};
+				for (uint32_t base = 0; base < 64; base += 2 * per)
+				{
+					uint32_t const ra = base + sr, rb = base + per + sr;
+					bool const act_a = (sr < per) & (ra < 64), act_b = (sr < per) & (rb < 64);
+					u64x2 qa{}, ta0{}, ta1{}, qb{}, tb0{}, tb1{};
+					uint32_t left_a, left_b;
+					fetch(ra, act_a, qa, ta0, ta1, left_a);
+					fetch(rb, act_b, qb, tb0, tb1, left_b);
+					finish(ra, act_a, qa, ta0, ta1, left_a);
+					finish(rb, act_b, qb, tb0, tb1, left_b);
 				}
+			}
+			wave_lds_sync();
+			uint32_t mu[FAST_WORDS + 1];
+			{
+				typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+				u32x4 const *mp = (u32x4 const *) (my_mask + lane * FAST_WORDS);
+				u32x4 const a = mp[0], b = mp[1];
+				uint32_t const all[FAST_WORDS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+				for (uint32_t w = 0; w < FAST_WORDS; ++w)
+					mu[w] = (fast && w < n_words) ? all[w] : 0;
 			}
 			mu[FAST_WORDS] = 0;
 			// Back to base positions: drop the `phase` leading positions.

@@ -397,6 +397,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 		PVC3_TRY(dev_upload(&d.blocks, e.blocks.data(), e.blocks.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
 		PVC3_TRY(dev_upload(&d.sel, e.sel.data(), e.sel.size(), 64, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
 		d.text = nullptr;
+		d.text4 = nullptr;
 		if (!e.text.empty())
 		{
 			// Front and back padding: the kernels read whole 16 / 32-byte pieces around the bases they need.
@@ -406,6 +407,13 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 			HIP_TRY(hipMemcpyAsync(p + TEXT_FRONT_PAD, e.text.data(), e.text.size(), hipMemcpyHostToDevice, ctx->stream));
 			HIP_TRY(hipMemsetAsync(p + TEXT_FRONT_PAD + e.text.size(), 0, TEXT_PAD, ctx->stream));
 			d.text = p + TEXT_FRONT_PAD;
+			// 4-bit copy for the fast path, made on the device from the bytes just uploaded.
+			uint8_t *p4{};
+			uint64_t const bytes4 = (TEXT4_FRONT + e.text.size() + 1) / 2 + TEXT_PAD;
+			PVC3_TRY(dev_alloc(&p4, bytes4, &ctx->index_allocs, &ctx->index_bytes));
+			HIP_TRY(hipMemsetAsync(p4, 0, bytes4, ctx->stream));
+			HIP_TRY((hipError_t) launch_pack_text4(d.text, e.text.size(), p4, ctx->stream));
+			d.text4 = p4;
 		}
 		d.n_cols = (uint32_t) e.n_cols;
 		d.n_zeros = (uint32_t) e.n_zeros;

@@ -191,6 +191,29 @@ __global__ __launch_bounds__(256) void k_checksum(uint64_t n, uint64_t first_rec
 	if (0 == threadIdx.x) atomicAdd(out, (unsigned long long) acc);
 }
 
+// 4-bit copy of a destination text for k_project_fast.  The fast path compares dna5::to_char of a BAM base code with the
+// raw text byte (rewrite_cigar.hh:96-104, quirk Q3): codes 1 2 4 8 read as A C G T, every other code as N.  With the text
+// encoded as A C G T N -> 1 2 4 8 15 and any other byte (lower case, IUPAC ...) -> 0, the comparison becomes
+// (code in {1,2,4,8} ? code : 15) != nibble.  One thread writes one byte: bases 2b - TEXT4_FRONT and 2b + 1 - TEXT4_FRONT.
+__device__ __forceinline__ uint32_t text_code(uint8_t c)
+{
+	return ('A' == c) ? 1u : ('C' == c) ? 2u : ('G' == c) ? 4u : ('T' == c) ? 8u : ('N' == c) ? 15u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_pack_text4(uint8_t const *__restrict__ text, uint64_t len, uint8_t *__restrict__ out)
+{
+	uint64_t const n_bytes = (TEXT4_FRONT + len + 1) / 2;
+	uint64_t const stride = (uint64_t) gridDim.x * blockDim.x;
+	for (uint64_t b = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; b < n_bytes; b += stride)
+	{
+		uint64_t const n0 = 2 * b;
+		uint32_t v = 0;
+		if (n0 >= TEXT4_FRONT && n0 - TEXT4_FRONT < len) v |= text_code(text[n0 - TEXT4_FRONT]);
+		if (n0 + 1 >= TEXT4_FRONT && n0 + 1 - TEXT4_FRONT < len) v |= text_code(text[n0 + 1 - TEXT4_FRONT]) << 4;
+		out[b] = (uint8_t) v;
+	}
+}
+
 uint32_t grid_for(uint64_t n, uint32_t per_block, uint32_t max_blocks)
 {
 	uint64_t const b = (n + per_block - 1) / per_block;
@@ -199,6 +222,12 @@ uint32_t grid_for(uint64_t n, uint32_t per_block, uint32_t max_blocks)
 
 }	// anonymous namespace
 
+
+int launch_pack_text4(uint8_t const *text, uint64_t len, uint8_t *out, void *stream)
+{
+	hipLaunchKernelGGL(k_pack_text4, dim3(grid_for((TEXT4_FRONT + len + 1) / 2, 256, 256 * 32)), dim3(256), 0, (hipStream_t) stream, text, len, out);
+	return (int) hipGetLastError();
+}
 
 int launch_project_positions(dev_entry const *entries, uint32_t n_entries, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out, void *stream)
 {

@@ -44,31 +44,29 @@ __device__ __forceinline__ uint64_t nibble_linear(uint64_t w)
 	return ((w & UINT64_C(0x0F0F0F0F0F0F0F0F)) << 4) | ((w >> 4) & UINT64_C(0x0F0F0F0F0F0F0F0F));
 }
 
-// Bit k set iff base k of q (8 BAM codes, 4 bits each; read through dna5::to_char) differs from raw text byte k of r (quirk Q3).
-__device__ __forceinline__ uint32_t mismatch8(uint32_t q, uint64_t r)
+// Bit k set iff base k of q (8 BAM codes, 4 bits each, read through dna5::to_char) differs from text base k of t (8 codes of
+// the packed text, kernels.hip k_pack_text4).  to_char maps 1 2 4 8 to A C G T and every other code to N, so the query
+// code is first canonicalised (exactly one bit set ? itself : 15) and then compared nibble-wise, all eight at once.
+__device__ __forceinline__ uint32_t mismatch8(uint32_t q, uint32_t t)
 {
-	// code -> index into "ACGTN" (1 2 4 8 -> 0 1 2 3, everything else -> 4), then the character itself.
-	constexpr uint64_t IDX = UINT64_C(0x4444444344424104);
-	constexpr uint64_t CHARS = UINT64_C(0x4E54474341);
-	uint32_t m = 0;
-#pragma unroll
-	for (uint32_t k = 0; k < 8; ++k)
-	{
-		uint32_t const code = (q >> (4 * k)) & 0xf;
-		uint32_t const rb = (uint32_t) (r >> (8 * k)) & 0xff;
-		uint32_t const idx = (uint32_t) (IDX >> (4 * code)) & 0xf;
-		uint32_t const ch = (uint32_t) (CHARS >> (8 * idx)) & 0xff;
-		m |= (uint32_t) (ch != rb) << k;
-	}
-	return m;
+	uint32_t p = q - ((q >> 1) & 0x55555555u);
+	p = (p & 0x33333333u) + ((p >> 2) & 0x33333333u);		// bits set per nibble
+	uint32_t const z = p ^ 0x11111111u;						// zero nibble <=> a base
+	uint32_t nb = z | (z >> 1);
+	nb = (nb | (nb >> 2)) & 0x11111111u;					// 1 per nibble that is not a base
+	uint32_t const d = (q | (nb * 15u)) ^ t;
+	uint32_t nz = d | (d >> 1);
+	nz = (nz | (nz >> 2)) & 0x11111111u;					// 1 per differing nibble, at bit 4k
+	uint32_t const u = (nz | (nz >> 3)) & 0x03030303u;		// two flags per byte
+	return (u * 0x01041040u) >> 24;
 }
 
-// Mismatch bits of 32 consecutive query nibbles (16 bytes of SEQ) against 32 text bytes.
-__device__ __forceinline__ uint32_t mismatch32(u64x2 const &qq, u64x2 const &t0, u64x2 const &t1)
+// Mismatch bits of 32 consecutive query nibbles (16 bytes of SEQ) against 32 text nibbles (t, nibble-linear).
+__device__ __forceinline__ uint32_t mismatch32(u64x2 const &qq, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3)
 {
 	uint64_t const q0 = nibble_linear(qq.x), q1 = nibble_linear(qq.y);
-	return mismatch8((uint32_t) q0, t0.x) | (mismatch8((uint32_t) (q0 >> 32), t0.y) << 8)
-		| (mismatch8((uint32_t) q1, t1.x) << 16) | (mismatch8((uint32_t) (q1 >> 32), t1.y) << 24);
+	return mismatch8((uint32_t) q0, t0) | (mismatch8((uint32_t) (q0 >> 32), t1) << 8)
+		| (mismatch8((uint32_t) q1, t2) << 16) | (mismatch8((uint32_t) (q1 >> 32), t3) << 24);
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
@@ -154,7 +152,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		uint32_t const *s_sel = S.sel;
 		uint32_t const s_zeros = S.n_zeros, s_cols = S.n_cols;
 		uint64_t const *d_blocks = D.blocks;
-		uint8_t const *d_text = D.text;
+		uint8_t const *d_text4 = D.text4;
 		uint32_t const d_text_len = D.text_len, d_cols = D.n_cols;
 
 		// ---- CIGAR: validation + shape automaton of the fast path (first four operations from one 16-byte load) ----------------
@@ -219,7 +217,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			// No gap column in either row over the span <=> both ranks advance by exactly ref_consumed.
 			bool const gapless = (block_rank(Se, p1.w, p1.bit) == src_pos + ref_consumed) && (block_rank(De, p1.w, p1.bit) == r0 + ref_consumed);
 			bool const simple = (2 == shape || 3 == shape);
-			fast = use_fast_path && simple && gapless && (ref_consumed + phase <= FAST_MAX_BASES) && d_text && ((uint64_t) r0 + ref_consumed <= d_text_len);
+			fast = use_fast_path && simple && gapless && (ref_consumed + phase < FAST_MAX_BASES) && d_text4 && ((uint64_t) r0 + ref_consumed <= d_text_len);
 		}
 
 		// ---- mate (project_alignments.cc:897-901) -----------------------------------------------------------------------------------
@@ -250,15 +248,17 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			// 16 bytes of SEQ and 32 bytes of text; the mask is shifted back by `phase` afterwards.
 			uint32_t const U = fast ? (R + phase) : 0;
 			uint8_t const *qp = in.seq4 + seq_begin + (lead_q >> 1);
-			uint8_t const *tp = d_text + r0 - phase;		// texts have TEXT_FRONT_PAD readable bytes in front
-			uint32_t const n_words = (wave_max(U) + 31) / 32;		// 1 .. FAST_WORDS
+			// Text nibble that lines up with query position u = 0 (base r0 - phase; the packed text has TEXT4_FRONT nibbles in front).
+			uint64_t const tn = (uint64_t) r0 + TEXT4_FRONT - phase;
+			// One more position than needed, so that the lane after a record's last full word exists (see below).
+			uint32_t const n_words = (wave_max(U) + 32) / 32;		// 1 .. FAST_WORDS
 			// The compare is done by n_words lanes per record, one 32-position word each: a wave instruction then touches the
 			// lines of 64 / n_words records instead of one line per lane, which the memory pipeline serves 2-3x faster
 			// (tools/calib/random_access.hip).  Descriptors go to the lanes through LDS, the masks come back the same way.
 			{
 				u64x2 d;
 				d.x = (uint64_t) qp | ((uint64_t) U << 48);
-				d.y = (uint64_t) tp;
+				d.y = (uint64_t) (d_text4 + (tn >> 1)) | ((tn & 1) << 63);
 				my_desc[lane] = d;
 			}
 			wave_lds_sync();
@@ -267,33 +267,45 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				uint32_t const per = (64 * inv) >> 16;			// records per pass
 				uint32_t const sr = (lane * inv) >> 16;				// lane / n_words
 				uint32_t const w = lane - sr * n_words;
-				auto fetch = [&](uint32_t rr, bool act, u64x2 &qq, u64x2 &t0, u64x2 &t1, uint32_t &left) {
+				typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+				auto fetch = [&](uint32_t rr, bool act, u64x2 &qq, u32x4 &tt, uint32_t &left, uint32_t &odd4) {
 					u64x2 const dd = my_desc[act ? rr : lane];
 					uint32_t const Ur = (uint32_t) (dd.x >> 48);
 					left = (act && Ur > 32 * w) ? (Ur - 32 * w) : 0;
-					if (left)		// loads stay inside the record (+ at most 31 positions of padding)
+					odd4 = (uint32_t) (dd.y >> 63) * 4;
+					// When the text starts at an odd nibble a word needs the first nibble of the next 16 bytes: the lane at
+					// position 32 w == Ur loads them although it has nothing to compare.
+					if (act && Ur && 32 * w <= Ur)		// SEQ loads stay inside the record (+ at most 31 positions of padding)
 					{
 						uint8_t const *q = (uint8_t const *) (dd.x & UINT64_C(0xFFFFFFFFFFFF)) + 16 * w;
-						uint8_t const *t = (uint8_t const *) dd.y + 32 * w;
-						qq = load_u128_unaligned(q); t0 = load_u128_unaligned(t); t1 = load_u128_unaligned(t + 16);
+						uint8_t const *t = (uint8_t const *) (dd.y & UINT64_C(0xFFFFFFFFFFFF)) + 16 * w;
+						if (left) qq = load_u128_unaligned(q);
+						__builtin_memcpy(&tt, t, 16);
 					}
 				};
-				auto finish = [&](uint32_t rr, bool act, u64x2 const &qq, u64x2 const &t0, u64x2 const &t1, uint32_t left) {
+				auto finish = [&](uint32_t rr, bool act, u64x2 const &qq, u32x4 const &tt, uint32_t left, uint32_t odd4) {
+					// Shift the 128-bit text window right by one nibble if needed; the top nibble comes from the next lane.
+					uint32_t const next = (uint32_t) __shfl_down((int) tt.x, 1);
 					uint32_t m = 0;
 					if (left)
-						m = mismatch32(qq, t0, t1) & (uint32_t) low_mask(left < 32 ? left : 32);
+					{
+						uint32_t const t0 = __builtin_amdgcn_alignbit(tt.y, tt.x, odd4), t1 = __builtin_amdgcn_alignbit(tt.z, tt.y, odd4);
+						uint32_t const t2 = __builtin_amdgcn_alignbit(tt.w, tt.z, odd4), t3 = __builtin_amdgcn_alignbit(next, tt.w, odd4);
+						m = mismatch32(qq, t0, t1, t2, t3) & (uint32_t) low_mask(left < 32 ? left : 32);
+					}
 					if (act) my_mask[rr * FAST_WORDS + w] = m;
 				};
 				for (uint32_t base = 0; base < 64; base += 2 * per)
 				{
 					uint32_t const ra = base + sr, rb = base + per + sr;
 					bool const act_a = (sr < per) & (ra < 64), act_b = (sr < per) & (rb < 64);
-					u64x2 qa{}, ta0{}, ta1{}, qb{}, tb0{}, tb1{};
-					uint32_t left_a, left_b;
-					fetch(ra, act_a, qa, ta0, ta1, left_a);
-					fetch(rb, act_b, qb, tb0, tb1, left_b);
-					finish(ra, act_a, qa, ta0, ta1, left_a);
-					finish(rb, act_b, qb, tb0, tb1, left_b);
+					u64x2 qa{}, qb{};
+					u32x4 ta{}, tb{};
+					uint32_t left_a, left_b, odd_a, odd_b;
+					fetch(ra, act_a, qa, ta, left_a, odd_a);
+					fetch(rb, act_b, qb, tb, left_b, odd_b);
+					finish(ra, act_a, qa, ta, left_a, odd_a);
+					finish(rb, act_b, qb, tb, left_b, odd_b);
 				}
 			}
 			wave_lds_sync();
@@ -363,10 +375,10 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				dst[k++] = ((R - start) << 4) | (type ? OP_X : OP_EQ);
 				if (trail) dst[k++] = trail;
 				acc_bitvec += 2 * ((R + 8) / 8);
-				acc_ref += R;
+				acc_ref += (R + 1) / 2;
 				acc_fast += 1;
 				// what the fast path itself must read and write for this record: SEQ, gap-bit windows, text, CIGAR out
-				acc_bytes += (l_seq + 1) / 2 + 2 * ((R + 8) / 8) + R + 4 * f_n_out;
+				acc_bytes += (l_seq + 1) / 2 + 2 * ((R + 8) / 8) + (R + 1) / 2 + 4 * f_n_out;
 			}
 		}
 

@@ -23,6 +23,7 @@ constexpr uint32_t SELECT_SAMPLE = 4096;	// one select sample per 4096 non-gap c
 constexpr uint32_t SELECT_SAMPLE_SHIFT = 12;
 constexpr uint32_t TEXT_PAD = 512;		// bytes readable past the end of a device text
 constexpr uint32_t TEXT_FRONT_PAD = 16;	// bytes readable before its start
+constexpr uint32_t TEXT4_FRONT = 16;		// packed text: nibbles in front of base 0 (base i = nibble i + TEXT4_FRONT, low nibble first)
 
 struct host_entry
 {
@@ -39,6 +40,7 @@ struct dev_entry
 	uint64_t const *blocks;
 	uint32_t const *sel;
 	uint8_t const *text;
+	uint8_t const *text4;				// 4-bit copy for the fast path (A C G T N -> 1 2 4 8 15, anything else 0), see k_pack_text4
 	uint32_t n_cols;
 	uint32_t n_zeros;
 	uint32_t text_len;
@@ -135,6 +137,7 @@ int launch_project_general(dev_entry const *entries, uint32_t n_entries, dev_bat
 int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream);
 int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &packed, uint64_t *scan_tmp, void *stream);
 int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);
+int launch_pack_text4(uint8_t const *text, uint64_t len, uint8_t *out, void *stream);
 int launch_project_positions(dev_entry const *entries, uint32_t n_entries, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out, void *stream);
 uint32_t realign_lds_bytes();
 uint32_t project_wave_count(uint64_t n);

@@ -101,7 +101,7 @@ def main():
 		raise SystemExit("unexpected: %d records failed" % stats["n_failed"])
 
 	# ---- timed region ------------------------------------------------------------------------------------------------------
-	ms = dict(project=0.0, general=0.0, realign=0.0, pack=0.0)
+	ms = dict(project=0.0, mid=0.0, general=0.0, realign=0.0, pack=0.0)
 	barrier()
 	torch.cuda.synchronize()
 	t_begin = time.perf_counter()
@@ -150,7 +150,7 @@ def main():
 				"whole_step": {"algorithmic_bytes": stats["algorithmic_bytes"], "GBps": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9, "frac": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
 			},
 			"kernel_ms": ms_avg,
-			"batch": {"fast_path_records": stats["n_fast_path"], "realigned_records": stats["n_realigned_records"], "indel_runs": stats["n_runs"], "out_cigar_ops": stats["out_cigar_total"], "checksum": "%016x" % checksum_total},
+			"batch": {"fast_path_records": stats["n_fast_path"], "mid_path_records": stats["n_mid_path"], "realigned_records": stats["n_realigned_records"], "indel_runs": stats["n_runs"], "out_cigar_ops": stats["out_cigar_total"], "checksum": "%016x" % checksum_total},
 		}
 
 		# ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample, same box, rank 0 only ----

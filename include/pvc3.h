@@ -143,12 +143,13 @@ typedef struct pvc3_batch_stats
 	uint64_t algorithmic_bytes;		/* SURVEY.md §8(d) bytes of this batch (reads + writes), see DESIGN.md */
 	uint64_t algorithmic_bytes_project;	/* the share of k_project_fast alone (accumulated per record by the kernel) */
 	uint64_t n_fast_path;			/* records finished by the lane-parallel fast path of k_project_fast */
+	uint64_t n_mid_path;			/* records finished by k_project_mid (lane-parallel walk of the remaining records) */
 	float ms_project;				/* k_project_fast: last launch duration (hipEvent), 0 if timing is disabled */
+	float ms_mid;					/* k_project_mid */
 	float ms_general;				/* k_project_general */
 	float ms_realign;				/* k_realign */
 	float ms_pack;					/* scans + gather */
 	uint32_t attempts;				/* 1 unless a workspace had to grow */
-	uint32_t reserved;
 } pvc3_batch_stats;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
@@ -181,7 +182,8 @@ PVC3_API int pvc3_context_set_stream(pvc3_context *ctx, void *hip_stream);
 PVC3_API int pvc3_context_set_timing(pvc3_context *ctx, int enabled);	/* hipEvent pairs around each kernel group */
 PVC3_API int pvc3_context_synchronize(pvc3_context *ctx);
 /* Tuning / test knobs: "realign_waves", "realign_lds_bytes", "scratch_per_wave", "arena_initial", "runs_initial",
- * "fast_path" (0 sends every record through the cooperative column walk). */
+ * "fast_path" (0: no lane-parallel compare in k_project_fast), "mid_path" (0: skip k_project_mid; with both at 0 every
+ * record goes through the cooperative column walk of k_project_general). */
 PVC3_API int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value);
 /* Replicates the index (bit-vector blocks, select samples, reference texts) into this context's HBM. */
 PVC3_API int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx);

@@ -45,8 +45,8 @@ class BatchStats(C.Structure):
 	_fields_ = [
 		("n_records", C.c_uint64), ("n_failed", C.c_uint64), ("n_realigned_records", C.c_uint64), ("n_runs", C.c_uint64),
 		("out_cigar_total", C.c_uint64), ("algorithmic_bytes", C.c_uint64), ("algorithmic_bytes_project", C.c_uint64),
-		("n_fast_path", C.c_uint64), ("ms_project", C.c_float), ("ms_general", C.c_float), ("ms_realign", C.c_float), ("ms_pack", C.c_float),
-		("attempts", C.c_uint32), ("reserved", C.c_uint32),
+		("n_fast_path", C.c_uint64), ("n_mid_path", C.c_uint64), ("ms_project", C.c_float), ("ms_mid", C.c_float), ("ms_general", C.c_float),
+		("ms_realign", C.c_float), ("ms_pack", C.c_float), ("attempts", C.c_uint32),
 	]
 
 

@@ -58,6 +58,7 @@ struct pvc3_context
 	uint64_t arena_initial{};
 	uint64_t runs_initial{};
 	uint32_t fast_path{1};
+	uint32_t mid_path{1};
 	uint8_t *scratch{};
 	uint64_t scratch_alloc{};
 };
@@ -201,6 +202,9 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
 	if (int const e = launch_project_fast(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s)) return set_error(PVC3_E_HIP, "k_project_fast launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
+	if (ctx->mid_path)
+		if (int const e = launch_project_mid(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_project_mid launch: %s", hipGetErrorString((hipError_t) e));
+	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[5], s));
 	if (int const e = launch_project_general(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_project_general launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	uint32_t const lds = ctx->realign_lds_bytes ? ctx->realign_lds_bytes : realign_lds_bytes();
@@ -371,6 +375,7 @@ int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value)
 	else if ("arena_initial" == k) ctx->arena_initial = (uint64_t) value;
 	else if ("runs_initial" == k) ctx->runs_initial = (uint64_t) value;
 	else if ("fast_path" == k) ctx->fast_path = (0 != value);
+	else if ("mid_path" == k) ctx->mid_path = (0 != value);
 	else return set_error(PVC3_E_INVALID, "pvc3_context_set_option: unknown option %s", key);
 	return PVC3_OK;
 }
@@ -509,6 +514,8 @@ int pvc3_dbatch_create(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_dbatch *
 	PVC3_TRY(dev_alloc(&w.run_loc, n, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.run_n, n, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.counters, 1, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.slow_list, (n + 63) / 64 * 64 + 64, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.slow_count, project_wave_count(n), &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.out_cigar_off, n + 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.run_off, n + 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.status, n, &b->allocs, &b->bytes));
@@ -592,6 +599,7 @@ int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stat
 		stats->n_failed = c.n_failed;
 		stats->n_realigned_records = c.n_realigned_records;
 		stats->n_fast_path = c.n_fast;
+		stats->n_mid_path = c.n_mid;
 		stats->n_runs = totals[1];
 		stats->out_cigar_total = totals[0];
 		// Algorithmic bytes (DESIGN.md "Algorithmic bytes per alignment"): what one pass must read and write at minimum.
@@ -607,7 +615,8 @@ int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stat
 		if (ctx->timing)
 		{
 			(void) hipEventElapsedTime(&stats->ms_project, ctx->ev[0], ctx->ev[1]);
-			(void) hipEventElapsedTime(&stats->ms_general, ctx->ev[1], ctx->ev[2]);
+			(void) hipEventElapsedTime(&stats->ms_mid, ctx->ev[1], ctx->ev[5]);
+			(void) hipEventElapsedTime(&stats->ms_general, ctx->ev[5], ctx->ev[2]);
 			(void) hipEventElapsedTime(&stats->ms_realign, ctx->ev[2], ctx->ev[3]);
 			(void) hipEventElapsedTime(&stats->ms_pack, ctx->ev[3], ctx->ev[4]);
 		}

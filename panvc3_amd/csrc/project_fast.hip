@@ -17,6 +17,7 @@
 #include "pvc3_internal.hpp"
 #include "wave.hpp"
 #include "device_common.hpp"
+#include "compare.hpp"
 
 namespace pvc3 {
 
@@ -29,55 +30,12 @@ constexpr uint32_t LDS_ENTRIES = 256;
 #define PVC3_FAST_MIN_WAVES 4
 #endif
 
-typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
-
-__device__ __forceinline__ u64x2 load_u128_unaligned(uint8_t const *p)
-{
-	u64x2 v;
-	__builtin_memcpy(&v, p, 16);
-	return v;
-}
-
-// Packed BAM bases (high nibble first) -> nibble-linear: nibble n of the byte string at bits [4n, 4n + 4).
-__device__ __forceinline__ uint64_t nibble_linear(uint64_t w)
-{
-	return ((w & UINT64_C(0x0F0F0F0F0F0F0F0F)) << 4) | ((w >> 4) & UINT64_C(0x0F0F0F0F0F0F0F0F));
-}
-
-// Bit k set iff base k of q (8 BAM codes, 4 bits each, read through dna5::to_char) differs from text base k of t (8 codes of
-// the packed text, kernels.hip k_pack_text4).  to_char maps 1 2 4 8 to A C G T and every other code to N, so the query
-// code is first canonicalised (exactly one bit set ? itself : 15) and then compared nibble-wise, all eight at once.
-__device__ __forceinline__ uint32_t mismatch8(uint32_t q, uint32_t t)
-{
-	uint32_t p = q - ((q >> 1) & 0x55555555u);
-	p = (p & 0x33333333u) + ((p >> 2) & 0x33333333u);		// bits set per nibble
-	uint32_t const z = p ^ 0x11111111u;						// zero nibble <=> a base
-	uint32_t nb = z | (z >> 1);
-	nb = (nb | (nb >> 2)) & 0x11111111u;					// 1 per nibble that is not a base
-	uint32_t const d = (q | (nb * 15u)) ^ t;
-	uint32_t nz = d | (d >> 1);
-	nz = (nz | (nz >> 2)) & 0x11111111u;					// 1 per differing nibble, at bit 4k
-	uint32_t const u = (nz | (nz >> 3)) & 0x03030303u;		// two flags per byte
-	return (u * 0x01041040u) >> 24;
-}
-
 // Mismatch bits of 32 consecutive query nibbles (16 bytes of SEQ) against 32 text nibbles (t, nibble-linear).
 __device__ __forceinline__ uint32_t mismatch32(u64x2 const &qq, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3)
 {
 	uint64_t const q0 = nibble_linear(qq.x), q1 = nibble_linear(qq.y);
 	return mismatch8((uint32_t) q0, t0) | (mismatch8((uint32_t) (q0 >> 32), t1) << 8)
 		| (mismatch8((uint32_t) q1, t2) << 16) | (mismatch8((uint32_t) (q1 >> 32), t3) << 24);
-}
-
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
-{
-#pragma unroll
-	for (uint32_t off = 1; off < 64; off <<= 1)
-	{
-		uint32_t const t = (uint32_t) __shfl_up((int) v, (int) off);
-		if (lane >= off) v += t;
-	}
-	return v;
 }
 
 // Orders this wave's LDS writes before its later LDS reads (the LDS queue of a wave is in-order; this stops the compiler).
@@ -110,6 +68,8 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	uint64_t const g_end = n_groups * (wave + 1) / n_waves;
 	arena_alloc arena{0, 0};
 	uint32_t acc_failed = 0, acc_fast = 0;		// per lane
+	uint32_t n_slow = 0;						// wave-uniform: entries in this wave's work list for k_project_mid
+	uint32_t *slow_list = W.slow_list + 64 * g_begin;
 
 	// The entry table is read by every lane of every group: keep its head in LDS.
 	__shared__ dev_entry lds_entries[LDS_ENTRIES];
@@ -382,6 +342,13 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			}
 		}
 
+		// ---- work list of the records left for k_project_mid --------------------------------------------------------------------------
+		{
+			uint64_t const m = ballot(valid && ok && !fast);
+			if ((m >> lane) & 1) slow_list[n_slow + mbcnt64(m)] = (uint32_t) rec;
+			n_slow += popc64(m);
+		}
+
 		// ---- per-record outputs (coalesced) ----------------------------------------------------------------------------------------------
 		if (valid)
 		{
@@ -398,6 +365,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		}
 	}
 
+	W.slow_count[wave] = n_slow;		// wave-uniform store
 	// Per-lane accumulators -> wave totals -> one atomic each.
 	for (int off = 32; off; off >>= 1)
 	{

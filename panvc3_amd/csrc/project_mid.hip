@@ -1,0 +1,279 @@
+// project_mid.hip — k_project_mid: lane = record for the records the fast path of k_project_fast could not take.
+//
+// k_project_fast leaves such records (CIGAR with insertions / deletions, or a gap column of either row inside the window)
+// in a per-wave work list.  Here 64 of them are walked at a time, one per lane, with exactly the steps of the cooperative
+// column walk (walk.hpp: rewrite_cigar, include/panvc3/rewrite_cigar.hh:18-157; cigar_buffer, libpanvc3/cigar.cc:54-95;
+// run detection, libpanvc3/indel_run_checker.cc:31-121) but on the lane's own registers: the gap words come from plain
+// loads, the = / X split from the packed text (compare.hpp) over the runs of compared columns, the output operations go to
+// a lane-interleaved LDS buffer and are copied to the arena once their number is known.  A record that needs more than
+// MID_TOKENS output operations or more than MID_MAX_STEPS steps stays marked REC_SLOW for k_project_general.
+#include <hip/hip_runtime.h>
+
+#include "pvc3_internal.hpp"
+#include "wave.hpp"
+#include "device_common.hpp"
+#include "compare.hpp"
+
+namespace pvc3 {
+
+namespace {
+
+constexpr uint32_t MID_TOKENS = 32;			// output operations buffered per lane
+constexpr uint32_t MID_MAX_STEPS = 40;		// 64-column steps per record
+
+// cigar_buffer + indel_run_checker state of one lane (device_common.hpp `sink`, without the wave-uniform plumbing).
+struct lane_sink
+{
+	uint32_t cur_op, cur_cnt, n_out, run_type, has_run;
+	uint32_t *tok;		// LDS, operation k at tok[64 * k]
+
+	__device__ __forceinline__ void init(uint32_t *t) { cur_op = 0xf; cur_cnt = 0; n_out = 0; run_type = 0; has_run = 0; tok = t; }
+
+	__device__ __forceinline__ void flush()
+	{
+		if (n_out < MID_TOKENS) tok[64 * n_out] = (cur_cnt << 4) | cur_op;
+		++n_out;		// n_out > MID_TOKENS tells the caller that the record does not fit
+		if (OP_I == cur_op) run_type |= 1;
+		else if (OP_D == cur_op) run_type |= 2;
+		else { has_run |= (3 == run_type); run_type = 0; }
+	}
+
+	__device__ __forceinline__ void push(uint32_t op, uint32_t cnt)
+	{
+		if (0 == cnt) return;
+		if (cur_op == op) cur_cnt += cnt;
+		else
+		{
+			if (cur_cnt) flush();
+			cur_op = op; cur_cnt = cnt;
+		}
+	}
+
+	__device__ __forceinline__ void finish()
+	{
+		if (cur_cnt) flush();
+		has_run |= (3 == run_type);
+	}
+};
+
+// Tokens of one step in column order (walk.hpp emit_tokens).
+__device__ __forceinline__ void emit_tokens_lane(lane_sink &s, uint64_t mE, uint64_t mX, uint64_t mI, uint64_t mD)
+{
+	uint64_t valid = mE | mX | mI | mD;
+	while (valid)
+	{
+		uint64_t const pb = valid & (~valid + 1);
+		uint32_t op; uint64_t mt;
+		if (mE & pb) { op = OP_EQ; mt = mE; }
+		else if (mX & pb) { op = OP_X; mt = mX; }
+		else if (mI & pb) { op = OP_I; mt = mI; }
+		else { op = OP_D; mt = mD; }
+		uint64_t const others = valid & ~mt;
+		uint64_t const below = others ? ((others & (~others + 1)) - 1) : ~UINT64_C(0);
+		s.push(op, popc64(mt & valid & below));
+		valid &= ~below;
+	}
+}
+
+// Mismatch bits of the compared columns mC of one step.  Inside a run of consecutive compared columns the query and the
+// text both advance by one base per column, so a run is a straight comparison of two nibble strings.
+__device__ __forceinline__ uint64_t compare_columns(uint64_t mC, uint64_t Z, uint64_t dz, uint32_t q, uint32_t r, uint8_t const *seq, uint8_t const *text4)
+{
+	uint64_t mX = 0, left = mC;
+	while (left)
+	{
+		uint32_t const c0 = ctz64(left);
+		uint64_t const ones = ~(left >> c0);
+		uint32_t const L = ones ? ctz64(ones) : 64;
+		uint32_t const qi = q + popc64(Z & low_mask(c0)), ri = r + popc64(dz & low_mask(c0));
+		for (uint32_t k = 0; k < L; k += 16)
+		{
+			uint32_t const n = (L - k < 16) ? (L - k) : 16;
+			uint64_t const mm = mismatch16(load_query16(seq, qi + k), load_text16(text4, ri + k)) & (uint32_t) low_mask(n);
+			mX |= mm << (c0 + k);
+		}
+		left &= ~(low_mask(L) << c0);
+	}
+	return mX;
+}
+
+__global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const wave = rfl((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	uint32_t const n_waves = (gridDim.x * blockDim.x) >> 6;
+	// Same partition as k_project_fast (same grid): wave w wrote its list at the start of its own record range.
+	uint64_t const n_groups = (in.n + 63) / 64;
+	uint32_t const *list = W.slow_list + 64 * (n_groups * wave / n_waves);
+	uint32_t const count = W.slow_count[wave];
+	__shared__ uint32_t lds_tok[4][64 * MID_TOKENS];
+	uint32_t *my_tok = lds_tok[rfl(threadIdx.x >> 6)] + lane;
+	arena_alloc arena{0, 0};
+	uint32_t acc_failed = 0, acc_runs = 0, acc_done = 0;
+	uint64_t acc_bitvec = 0, acc_ref = 0, acc_bytes = 0;
+
+	for (uint32_t base = 0; base < count; base += 64)
+	{
+		bool const mine = base + lane < count;
+		uint32_t const rec = mine ? list[base + lane] : 0;
+		uint32_t status = PVC3_ST_OK;
+		bool punt = false;
+		lane_sink out;
+		out.init(my_tok);
+		uint32_t cols = 0, ref_span = 0, l_seq = 0;
+
+		if (mine)
+		{
+			uint32_t const src_pos = in.src_pos[rec];
+			dev_entry const S = entries[in.src_entry[rec]];
+			dev_entry const D = entries[in.dst_entry[rec]];
+			uint64_t const cig_begin = in.cigar_off[rec];
+			uint32_t const n_cigar = (uint32_t) (in.cigar_off[rec + 1] - cig_begin);
+			uint32_t const *ops = in.cigar + cig_begin;
+			uint8_t const *seq = in.seq4 + in.seq_off[rec];
+			l_seq = in.l_seq[rec];
+			uint64_t const stash = W.cig_loc[rec];		// left by k_project_fast: start column | reference-consuming length << 32
+			uint32_t const col0 = (uint32_t) stash;
+			uint32_t const r0 = W.dst_pos[rec];
+			(void) src_pos;
+			uint32_t col = col0, r = r0, q = 0, steps = 0;
+
+			for (uint32_t ci = 0; ci < n_cigar && !punt && PVC3_ST_OK == status; ++ci)
+			{
+				uint32_t const c = ops[ci];
+				uint32_t const op = c & 0xf;
+				uint32_t n_rem = c >> 4;
+				if (OP_I == op || OP_S == op)		// rewrite_cigar.hh:69-73
+				{
+					out.push(op, n_rem);
+					q += n_rem;
+					continue;
+				}
+				if (OP_H == op || OP_P == op)		// :75-78
+				{
+					out.push(op, n_rem);
+					continue;
+				}
+				bool const m_type = !(OP_D == op || OP_N == op);	// M = X (:80-118) vs D N (:121-147)
+				while (n_rem)
+				{
+					if (++steps > MID_MAX_STEPS) { punt = true; break; }
+					col_pos const p = split_col(col);
+					uint64_t const wi = (uint64_t) p.blk * BLOCK_WORDS + 1 + p.w;
+					uint64_t const sw = S.blocks[wi], dw = D.blocks[wi];
+					uint64_t const ge = ~UINT64_C(0) << p.bit;
+					uint64_t const z = ~sw & ge;				// source non-gap columns at or after col
+					uint32_t const nz = popc64(z);
+					uint64_t act;								// columns handled in this step
+					uint32_t consumed;
+					uint32_t const word_col = col - p.bit;
+					if (nz >= n_rem)
+					{
+						uint32_t const e = thread_select_in_word(z, n_rem - 1);	// last base of this operation
+						act = ge & low_mask(e + 1);
+						consumed = n_rem;
+						col = word_col + e + 1;
+					}
+					else
+					{
+						act = ge;
+						consumed = nz;
+						col = word_col + 64;
+					}
+					uint64_t const dz = ~dw & act;				// destination non-gap columns
+					uint64_t const Z = z & act;					// consumed source bases
+					uint64_t const G = sw & act;				// source gaps in between
+					uint32_t const nd = popc64(dz);
+					uint64_t mE = 0, mX = 0, mI, mD;
+					if (m_type)
+					{
+						mI = Z & ~dz;							// dst gap: match becomes insertion (:93-98)
+						mD = G & dz;							// dst characters between source bases: deletion (:90-91)
+						uint64_t const mC = Z & dz;				// compare query with the dst text (:99-113)
+						if (mC)
+						{
+							uint32_t const hi = 63 - (uint32_t) __builtin_clzll(mC);
+							uint32_t const max_ri = r + popc64(dz & low_mask(hi));
+							if (!D.text4 || max_ri >= D.text_len) { status = PVC3_ST_REF_RANGE; break; }
+							mX = compare_columns(mC, Z, dz, q, r, seq, D.text4);
+							mE = mC & ~mX;
+						}
+						q += consumed;
+					}
+					else
+					{
+						mI = 0;
+						mD = dz;								// (:133-137) kept where dst has a character, dropped otherwise
+					}
+					emit_tokens_lane(out, mE, mX, mI, mD);
+					r += nd;
+					n_rem -= consumed;
+				}
+			}
+			out.finish();
+			punt = punt || (out.n_out > MID_TOKENS);
+			cols = col - col0;
+			ref_span = r - r0;
+		}
+
+		// ---- wave level: arena space for the finished records, copy, per-record outputs ------------------------------------------
+		bool const done = mine && !punt;
+		bool const ok = done && (PVC3_ST_OK == status);
+		uint32_t n_tok = ok ? out.n_out : 0;
+		uint32_t const scan = wave_inclusive_scan(n_tok, lane);
+		uint32_t const total = readlane(scan, 63);
+		uint64_t base_loc = 0;
+		if (total && !arena_take(arena, total, W, lane, base_loc))
+			n_tok = 0;		// arena overflow: the host grows it and repeats the batch
+		uint64_t const loc = base_loc + (scan - (ok ? out.n_out : 0));
+		for (uint32_t k = 0; k < n_tok; ++k)
+			W.arena[loc + k] = my_tok[64 * k];
+		if (done)
+		{
+			W.rec_flags[rec] = status | ((ok && out.has_run) ? REC_HAS_RUN : 0);
+			W.cig_n[rec] = n_tok;
+			W.cig_loc[rec] = loc;
+			if (!ok) W.dst_pos[rec] = 0;		// a rejected record has empty outputs
+			acc_done += 1;
+			acc_failed += !ok;
+			acc_runs += (ok && out.has_run);
+			if (ok)
+			{
+				acc_bitvec += 2 * ((cols + 8) / 8);
+				acc_ref += (ref_span + 1) / 2;
+				acc_bytes += 2 * ((cols + 8) / 8) + (ref_span + 1) / 2 + 4 * n_tok + (l_seq + 1) / 2;	// gap bits, text, CIGAR out, SEQ
+			}
+		}
+	}
+
+	for (int off = 32; off; off >>= 1)
+	{
+		acc_bitvec += __shfl_xor(acc_bitvec, off);
+		acc_ref += __shfl_xor(acc_ref, off);
+		acc_bytes += __shfl_xor(acc_bytes, off);
+		acc_failed += __shfl_xor(acc_failed, off);
+		acc_runs += __shfl_xor(acc_runs, off);
+		acc_done += __shfl_xor(acc_done, off);
+	}
+	if (0 == lane)
+	{
+		if (acc_bitvec) atomicAdd(&W.counters->bitvec_bytes, (unsigned long long) acc_bitvec);
+		if (acc_ref) atomicAdd(&W.counters->ref_bytes, (unsigned long long) acc_ref);
+		if (acc_bytes) atomicAdd(&W.counters->general_bytes, (unsigned long long) acc_bytes);
+		if (acc_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) acc_failed);
+		if (acc_runs) atomicAdd(&W.counters->n_realigned_records, (unsigned long long) acc_runs);
+		if (acc_done) atomicAdd(&W.counters->n_mid, (unsigned long long) acc_done);
+	}
+}
+
+}	// anonymous namespace
+
+int launch_project_mid(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream)
+{
+	if (0 == in.n) return 0;
+	// The grid must be that of k_project_fast: the work lists are per wave.
+	hipLaunchKernelGGL(k_project_mid, dim3(project_wave_count(in.n) / 4), dim3(256), 0, (hipStream_t) stream, entries, n_entries, in, work);
+	return (int) hipGetLastError();
+}
+
+}

@@ -84,6 +84,7 @@ struct dev_counters
 	unsigned long long qual_bytes;		// sum of l_seq over realigned records
 	unsigned long long n_fast;			// records finished by the lane-parallel fast path
 	unsigned long long fast_bytes;		// algorithmic bytes of k_project_fast
+	unsigned long long n_mid;			// records finished by k_project_mid
 	unsigned long long general_bytes;	// algorithmic bytes of k_project_general (data the fast kernel had not read yet)
 };
 
@@ -103,6 +104,8 @@ struct dev_batch_work
 	uint64_t runs_cap;
 	uint8_t *scratch;					// DP scratch, scratch_per_wave bytes per realign wave
 	uint64_t scratch_per_wave;
+	uint32_t *slow_list;				// records left by the fast path: wave w of k_project_fast fills [64 * first group of w ...)
+	uint32_t *slow_count;				// [waves of k_project_fast]
 	dev_counters *counters;
 };
 
@@ -133,6 +136,7 @@ struct dev_params
 
 // Launch wrappers (kernels.hip).  All enqueue on `stream` and return a hipError_t as int.
 int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream);
+int launch_project_mid(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
 int launch_project_general(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
 int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream);
 int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &packed, uint64_t *scan_tmp, void *stream);

@@ -47,6 +47,17 @@ __device__ __forceinline__ uint32_t ctz64(uint64_t v) { return (uint32_t) __buil
 // Bits [0, n) set; n in [0, 64].
 __device__ __forceinline__ uint64_t low_mask(uint32_t n) { return (n >= 64) ? ~UINT64_C(0) : ((UINT64_C(1) << n) - 1); }
 
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+	for (uint32_t off = 1; off < 64; off <<= 1)
+	{
+		uint32_t const t = (uint32_t) __shfl_up((int) v, (int) off);
+		if (lane >= off) v += t;
+	}
+	return v;
+}
+
 // Position of the t-th (0-based) set bit of the wave-uniform word z; all 64 lanes cooperate.
 __device__ __forceinline__ uint32_t wave_select_in_word(uint64_t z, uint32_t t, uint32_t lane)
 {

@@ -19,3 +19,28 @@ def oracle_mod():
 	from oracle import oracle as orc
 	orc.build()
 	return orc
+
+
+# Which projection kernels the GPU tests send the records through.  "default" is the product configuration (lane-parallel
+# fast path, then the lane-per-record walk, then the cooperative column walk for what is left); the other two force every
+# record through one of the slower kernels so that each of them is compared with the oracle on every test input.
+PATH_MODES = {"default": {}, "mid_only": {"fast_path": 0}, "walk_only": {"fast_path": 0, "mid_path": 0}}
+
+
+@pytest.fixture(scope="module", params=list(PATH_MODES))
+def pvc3(request):
+	import types
+	import panvc3_amd
+	assert panvc3_amd.device_count() > 0, "no GPU visible: the HIP path has no CPU fallback"
+	options = PATH_MODES[request.param]
+
+	class Context(panvc3_amd.Context):
+		def __init__(self, *a, **kw):
+			super().__init__(*a, **kw)
+			for k, v in options.items():
+				self.set_option(k, v)
+
+	mod = types.SimpleNamespace(**{k: getattr(panvc3_amd, k) for k in dir(panvc3_amd) if not k.startswith("__")})
+	mod.Context = Context
+	mod.paths_mode = request.param
+	return mod

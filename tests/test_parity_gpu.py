@@ -12,13 +12,6 @@ from helpers import (BatchBuilder, assert_results_equal, cigar_decode, cigar_eq,
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def pvc3():
-	import panvc3_amd
-	assert panvc3_amd.device_count() > 0, "no GPU visible: the HIP path has no CPU fallback"
-	return panvc3_amd
-
-
 def _setup_pair(pvc3, oracle_mod, src, dst, ctx=None):
 	idx = pvc3.Index()
 	s, d = idx.add_aligned(src), idx.add_aligned(dst)

@@ -199,6 +199,7 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	b->work.scratch = ctx->scratch;
 	b->work.scratch_per_wave = ctx->scratch_per_wave;
 	HIP_TRY(hipMemsetAsync(b->work.counters, 0, sizeof(dev_counters), s));
+	HIP_TRY(hipMemsetAsync(b->work.wave_stats, 0, 3 * (uint64_t) project_wave_count(b->n) * WAVE_STATS * sizeof(unsigned long long), s));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
 	if (int const e = launch_project_fast(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s)) return set_error(PVC3_E_HIP, "k_project_fast launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
@@ -206,6 +207,7 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 		if (int const e = launch_project_mid(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_project_mid launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[5], s));
 	if (int const e = launch_project_general(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_project_general launch: %s", hipGetErrorString((hipError_t) e));
+	if (int const e = launch_reduce_stats(b->n, b->work, s)) return set_error(PVC3_E_HIP, "k_reduce_stats launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	uint32_t const lds = ctx->realign_lds_bytes ? ctx->realign_lds_bytes : realign_lds_bytes();
 	if (int const e = launch_realign(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->d_params, ctx->realign_waves, lds, s)) return set_error(PVC3_E_HIP, "k_realign launch: %s", hipGetErrorString((hipError_t) e));
@@ -516,6 +518,7 @@ int pvc3_dbatch_create(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_dbatch *
 	PVC3_TRY(dev_alloc(&w.counters, 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.slow_list, (n + 63) / 64 * 64 + 64, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.slow_count, project_wave_count(n), &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.wave_stats, 3 * (uint64_t) project_wave_count(n) * WAVE_STATS, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.out_cigar_off, n + 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.run_off, n + 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.status, n, &b->allocs, &b->bytes));

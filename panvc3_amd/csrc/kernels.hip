@@ -214,6 +214,31 @@ __global__ __launch_bounds__(256) void k_pack_text4(uint8_t const *__restrict__ 
 	}
 }
 
+// Folds the per-wave statistics of k_project_fast / k_project_mid / k_project_general (blockIdx.y) into the counters:
+// one thread per wave row, one atomic per block and counter.
+__global__ __launch_bounds__(256) void k_reduce_stats(uint32_t n_waves, dev_batch_work const W)
+{
+	__shared__ uint64_t lds[8];
+	uint32_t const row = blockIdx.y;
+	uint32_t const w = blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t acc[WAVE_STATS];
+	for (uint32_t k = 0; k < WAVE_STATS; ++k)
+		acc[k] = (w < n_waves) ? W.wave_stats[((uint64_t) row * n_waves + w) * WAVE_STATS + k] : 0;
+	for (uint32_t k = 0; k < WAVE_STATS; ++k)
+		acc[k] = block_reduce_add(acc[k], lds);
+	if (0 == threadIdx.x)
+	{
+		dev_counters *c = W.counters;
+		auto add = [](unsigned long long *p, uint64_t v) { if (v) atomicAdd(p, (unsigned long long) v); };
+		add(&c->bitvec_bytes, acc[WS_BITVEC]);
+		add(&c->ref_bytes, acc[WS_REF]);
+		add(&c->n_failed, acc[WS_FAILED]);
+		add(&c->n_realigned_records, acc[WS_WITH_RUNS]);
+		if (0 == row) { add(&c->n_fast, acc[WS_DONE]); add(&c->fast_bytes, acc[WS_BYTES]); }
+		else { add(&c->general_bytes, acc[WS_BYTES]); if (1 == row) add(&c->n_mid, acc[WS_DONE]); }
+	}
+}
+
 uint32_t grid_for(uint64_t n, uint32_t per_block, uint32_t max_blocks)
 {
 	uint64_t const b = (n + per_block - 1) / per_block;
@@ -222,6 +247,13 @@ uint32_t grid_for(uint64_t n, uint32_t per_block, uint32_t max_blocks)
 
 }	// anonymous namespace
 
+
+int launch_reduce_stats(uint64_t n, dev_batch_work const &work, void *stream)
+{
+	if (n)
+		hipLaunchKernelGGL(k_reduce_stats, dim3((project_wave_count(n) + 255) / 256, 3), dim3(256), 0, (hipStream_t) stream, project_wave_count(n), work);
+	return (int) hipGetLastError();
+}
 
 int launch_pack_text4(uint8_t const *text, uint64_t len, uint8_t *out, void *stream)
 {

@@ -377,11 +377,12 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	}
 	if (0 == lane)
 	{
-		if (acc_bitvec) atomicAdd(&W.counters->bitvec_bytes, (unsigned long long) acc_bitvec);
-		if (acc_ref) atomicAdd(&W.counters->ref_bytes, (unsigned long long) acc_ref);
-		if (acc_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) acc_failed);
-		if (acc_fast) atomicAdd(&W.counters->n_fast, (unsigned long long) acc_fast);
-		if (acc_bytes) atomicAdd(&W.counters->fast_bytes, (unsigned long long) acc_bytes);
+		unsigned long long *ws = W.wave_stats + ((uint64_t) 0 * n_waves + wave) * WAVE_STATS;
+		ws[WS_BITVEC] = acc_bitvec;
+		ws[WS_REF] = acc_ref;
+		ws[WS_FAILED] = acc_failed;
+		ws[WS_DONE] = acc_fast;
+		ws[WS_BYTES] = acc_bytes;
 	}
 }
 

@@ -82,11 +82,12 @@ __global__ __launch_bounds__(256) void k_project_general(dev_entry const *__rest
 	}
 	if (0 == lane)
 	{
-		if (G.bitvec_bytes) atomicAdd(&W.counters->bitvec_bytes, (unsigned long long) G.bitvec_bytes);
-		if (G.ref_bytes) atomicAdd(&W.counters->ref_bytes, (unsigned long long) G.ref_bytes);
-		if (G.bytes) atomicAdd(&W.counters->general_bytes, (unsigned long long) G.bytes);
-		if (G.n_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) G.n_failed);
-		if (G.n_with_runs) atomicAdd(&W.counters->n_realigned_records, (unsigned long long) G.n_with_runs);
+		unsigned long long *ws = W.wave_stats + ((uint64_t) 2 * n_waves + wave) * WAVE_STATS;
+		ws[WS_BITVEC] = G.bitvec_bytes;
+		ws[WS_REF] = G.ref_bytes;
+		ws[WS_FAILED] = G.n_failed;
+		ws[WS_BYTES] = G.bytes;
+		ws[WS_WITH_RUNS] = G.n_with_runs;
 	}
 }
 

@@ -75,8 +75,37 @@ __device__ __forceinline__ void emit_tokens_lane(lane_sink &s, uint64_t mE, uint
 	}
 }
 
+// 64 + 16 consecutive 4-bit codes starting at nibble `first` of a byte string, as five independent 8-byte loads.
+struct nibbles80
+{
+	uint64_t w[5];
+};
+
+template <bool t_query>
+__device__ __forceinline__ nibbles80 load_nibbles80(uint8_t const *bytes, uint64_t first)
+{
+	uint8_t const *p = bytes + (first >> 1);
+	u64x2 const a = load_u128_unaligned(p), b = load_u128_unaligned(p + 16);
+	uint64_t c;
+	__builtin_memcpy(&c, p + 32, 8);
+	nibbles80 n;
+	n.w[0] = a.x; n.w[1] = a.y; n.w[2] = b.x; n.w[3] = b.y; n.w[4] = c;
+	if (t_query)		// SEQ stores the first base of a byte in the high nibble
+	{
+#pragma unroll
+		for (uint32_t i = 0; i < 5; ++i) n.w[i] = nibble_linear(n.w[i]);
+	}
+	if (first & 1)
+	{
+#pragma unroll
+		for (uint32_t i = 0; i < 4; ++i) n.w[i] = (n.w[i] >> 4) | (n.w[i + 1] << 60);
+	}
+	return n;
+}
+
 // Mismatch bits of the compared columns mC of one step.  Inside a run of consecutive compared columns the query and the
-// text both advance by one base per column, so a run is a straight comparison of two nibble strings.
+// text both advance by one base per column, so a run is a straight comparison of two nibble strings; all the bytes a run
+// can need (64 bases of either side) are requested at once, so that a run costs one memory round trip.
 __device__ __forceinline__ uint64_t compare_columns(uint64_t mC, uint64_t Z, uint64_t dz, uint32_t q, uint32_t r, uint8_t const *seq, uint8_t const *text4)
 {
 	uint64_t mX = 0, left = mC;
@@ -86,12 +115,13 @@ __device__ __forceinline__ uint64_t compare_columns(uint64_t mC, uint64_t Z, uin
 		uint64_t const ones = ~(left >> c0);
 		uint32_t const L = ones ? ctz64(ones) : 64;
 		uint32_t const qi = q + popc64(Z & low_mask(c0)), ri = r + popc64(dz & low_mask(c0));
-		for (uint32_t k = 0; k < L; k += 16)
-		{
-			uint32_t const n = (L - k < 16) ? (L - k) : 16;
-			uint64_t const mm = mismatch16(load_query16(seq, qi + k), load_text16(text4, ri + k)) & (uint32_t) low_mask(n);
-			mX |= mm << (c0 + k);
-		}
+		nibbles80 const qn = load_nibbles80 <true>(seq, qi);
+		nibbles80 const tn = load_nibbles80 <false>(text4, (uint64_t) ri + TEXT4_FRONT);
+		uint64_t mm = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k)
+			mm |= (uint64_t) mismatch16(qn.w[k], tn.w[k]) << (16 * k);
+		mX |= (mm & low_mask(L)) << c0;
 		left &= ~(low_mask(L) << c0);
 	}
 	return mX;
@@ -138,9 +168,12 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 			(void) src_pos;
 			uint32_t col = col0, r = r0, q = 0, steps = 0;
 
+			typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+			u32x4 pre;
+			__builtin_memcpy(&pre, ops, 16);			// the CIGAR buffer is padded by the host side
 			for (uint32_t ci = 0; ci < n_cigar && !punt && PVC3_ST_OK == status; ++ci)
 			{
-				uint32_t const c = ops[ci];
+				uint32_t const c = (0 == ci) ? pre.x : (1 == ci) ? pre.y : (2 == ci) ? pre.z : (3 == ci) ? pre.w : ops[ci];
 				uint32_t const op = c & 0xf;
 				uint32_t n_rem = c >> 4;
 				if (OP_I == op || OP_S == op)		// rewrite_cigar.hh:69-73
@@ -257,12 +290,13 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 	}
 	if (0 == lane)
 	{
-		if (acc_bitvec) atomicAdd(&W.counters->bitvec_bytes, (unsigned long long) acc_bitvec);
-		if (acc_ref) atomicAdd(&W.counters->ref_bytes, (unsigned long long) acc_ref);
-		if (acc_bytes) atomicAdd(&W.counters->general_bytes, (unsigned long long) acc_bytes);
-		if (acc_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) acc_failed);
-		if (acc_runs) atomicAdd(&W.counters->n_realigned_records, (unsigned long long) acc_runs);
-		if (acc_done) atomicAdd(&W.counters->n_mid, (unsigned long long) acc_done);
+		unsigned long long *ws = W.wave_stats + ((uint64_t) 1 * n_waves + wave) * WAVE_STATS;
+		ws[WS_BITVEC] = acc_bitvec;
+		ws[WS_REF] = acc_ref;
+		ws[WS_FAILED] = acc_failed;
+		ws[WS_DONE] = acc_done;
+		ws[WS_BYTES] = acc_bytes;
+		ws[WS_WITH_RUNS] = acc_runs;
 	}
 }
 

@@ -106,6 +106,7 @@ struct dev_batch_work
 	uint64_t scratch_per_wave;
 	uint32_t *slow_list;				// records left by the fast path: wave w of k_project_fast fills [64 * first group of w ...)
 	uint32_t *slow_count;				// [waves of k_project_fast]
+	unsigned long long *wave_stats;		// [3 kernels][waves][WAVE_STATS]: per-wave sums, folded into `counters` by k_reduce_stats
 	dev_counters *counters;
 };
 
@@ -119,6 +120,11 @@ struct dev_batch_packed
 	uint64_t run_cap;
 	int32_t *status;					// [n]
 };
+
+// Per-wave statistics of the three projection kernels (plain stores; thousands of same-address atomics at the end of a
+// kernel serialise into a visible tail).  Rows: 0 k_project_fast, 1 k_project_mid, 2 k_project_general.
+constexpr uint32_t WAVE_STATS = 8;
+constexpr uint32_t WS_BITVEC = 0, WS_REF = 1, WS_FAILED = 2, WS_DONE = 3, WS_BYTES = 4, WS_WITH_RUNS = 5;
 
 constexpr uint32_t REC_STATUS_MASK = 0xffu;
 constexpr uint32_t REC_HAS_RUN = 0x100u;
@@ -139,6 +145,7 @@ int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_
 int launch_project_mid(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
 int launch_project_general(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
 int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream);
+int launch_reduce_stats(uint64_t n, dev_batch_work const &work, void *stream);
 int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &packed, uint64_t *scan_tmp, void *stream);
 int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);
 int launch_pack_text4(uint8_t const *text, uint64_t len, uint8_t *out, void *stream);

@@ -3,7 +3,7 @@
 //   k_project            project.hip (projection walk + mate projection)
 //   k_realign            realign.hip
 //   k_project_positions  one thread per position: project_position (msa_index.hh:253-258)
-//   k_scan_* / k_gather   pack the per-record results in record order.
+//   k_scan_* / k_offsets_gather   pack the per-record results in record order.
 //
 // Integer / bit work, HBM- and latency-bound; no MFMA on this path.
 #include <hip/hip_runtime.h>
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_project_positions(
 
 // ---- packing: exclusive scans of the per-record counts, then a gather into record order ------------------------------
 constexpr uint32_t SCAN_THREADS = 256;
-constexpr uint32_t SCAN_ITEMS = 16;
+constexpr uint32_t SCAN_ITEMS = 8;
 constexpr uint32_t SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 __device__ __forceinline__ uint64_t block_reduce_add(uint64_t v, uint64_t *lds)
@@ -97,63 +97,67 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(uint64_t n_tiles, uint6
 	if (0 == threadIdx.x) { totals[0] = carry[0]; totals[1] = carry[1]; }
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(
-	uint64_t n, uint32_t const *__restrict__ a, uint32_t const *__restrict__ b, uint64_t const *__restrict__ tile_sums,
-	uint64_t const *__restrict__ totals, uint64_t *__restrict__ off_a, uint64_t *__restrict__ off_b
-)
+// Exclusive prefix of v over the block's threads (v of thread t counts before those of thread t + 1); `total` = block sum.
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *lds, uint64_t &total)
 {
-	// Each thread owns SCAN_ITEMS consecutive records of the tile.
-	__shared__ uint64_t lds_a[SCAN_THREADS], lds_b[SCAN_THREADS];
-	uint64_t const base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
-	uint32_t ca[SCAN_ITEMS], cb[SCAN_ITEMS];
-	uint64_t sa = 0, sb = 0;
+	uint32_t const lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	uint64_t inc = v;
 #pragma unroll
-	for (uint32_t i = 0; i < SCAN_ITEMS; ++i)
+	for (uint32_t off = 1; off < 64; off <<= 1)
 	{
-		uint64_t const idx = base + i;
-		ca[i] = (idx < n) ? a[idx] : 0; cb[i] = (idx < n) ? b[idx] : 0;
-		sa += ca[i]; sb += cb[i];
+		uint64_t const t = __shfl_up(inc, off);
+		if (lane >= off) inc += t;
 	}
-	lds_a[threadIdx.x] = sa; lds_b[threadIdx.x] = sb;
+	if (63 == lane) lds[w] = inc;
 	__syncthreads();
-	for (uint32_t off = 1; off < SCAN_THREADS; off <<= 1)
+	uint64_t before = 0;
+	total = 0;
+	for (uint32_t i = 0; i < (SCAN_THREADS >> 6); ++i)
 	{
-		uint64_t ta = 0, tb = 0;
-		if (threadIdx.x >= off) { ta = lds_a[threadIdx.x - off]; tb = lds_b[threadIdx.x - off]; }
-		__syncthreads();
-		lds_a[threadIdx.x] += ta; lds_b[threadIdx.x] += tb;
-		__syncthreads();
+		uint64_t const x = lds[i];
+		before += (i < w) ? x : 0;
+		total += x;
 	}
-	uint64_t xa = tile_sums[2 * (uint64_t) blockIdx.x] + lds_a[threadIdx.x] - sa;
-	uint64_t xb = tile_sums[2 * (uint64_t) blockIdx.x + 1] + lds_b[threadIdx.x] - sb;
-#pragma unroll
-	for (uint32_t i = 0; i < SCAN_ITEMS; ++i)
-	{
-		uint64_t const idx = base + i;
-		if (idx < n) { off_a[idx] = xa; off_b[idx] = xb; }
-		xa += ca[i]; xb += cb[i];
-	}
-	if (0 == blockIdx.x && 0 == threadIdx.x) { off_a[n] = totals[0]; off_b[n] = totals[1]; }
+	__syncthreads();
+	return before + inc - v;
 }
 
-__global__ __launch_bounds__(256) void k_gather(uint64_t n, dev_batch_work const W, dev_batch_packed const P)
+// Offsets of every record's operations / runs in the packed arrays (exclusive scan, tile prefix from k_scan_tile_sums) and,
+// in the same pass, the copy of the operations and runs out of the arenas and the status.  Thread t of a tile owns records
+// base + 256 i + t: descriptor loads are coalesced and neighbouring lanes copy neighbouring pieces of the arenas.
+__global__ __launch_bounds__(SCAN_THREADS) void k_offsets_gather(uint64_t n, dev_batch_work const W, dev_batch_packed const P, uint64_t const *__restrict__ tile_sums, uint64_t const *__restrict__ totals)
 {
-	uint64_t const stride = (uint64_t) gridDim.x * blockDim.x;
-	for (uint64_t rec = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; rec < n; rec += stride)
+	__shared__ uint64_t lds[8];
+	uint64_t const base = (uint64_t) blockIdx.x * SCAN_TILE;
+	uint64_t carry_a = tile_sums[2 * (uint64_t) blockIdx.x], carry_b = tile_sums[2 * (uint64_t) blockIdx.x + 1];
+	for (uint32_t i = 0; i < SCAN_ITEMS; ++i)
 	{
-		uint32_t const nc = W.cig_n[rec];
-		uint32_t const *src = W.arena + W.cig_loc[rec];
-		uint32_t *dst = P.out_cigar + P.out_cigar_off[rec];
-		for (uint32_t i = 0; i < nc; ++i) dst[i] = src[i];
-		uint32_t const nr = W.run_n[rec];
-		if (nr)
+		uint64_t const rec = base + (uint64_t) i * SCAN_THREADS + threadIdx.x;
+		bool const valid = rec < n;
+		uint32_t const nc = valid ? W.cig_n[rec] : 0, nr = valid ? W.run_n[rec] : 0;
+		uint64_t const loc = valid ? W.cig_loc[rec] : 0;
+		uint32_t const fl = valid ? W.rec_flags[rec] : 0;
+		uint64_t total_a, total_b;
+		uint64_t const off_a = carry_a + block_exclusive_scan(nc, lds, total_a);
+		uint64_t const off_b = carry_b + block_exclusive_scan(nr, lds, total_b);
+		carry_a += total_a; carry_b += total_b;
+		if (valid)
 		{
-			pvc3_run const *rs = W.runs_arena + W.run_loc[rec];
-			pvc3_run *rd = P.runs + P.run_off[rec];
-			for (uint32_t i = 0; i < nr; ++i) rd[i] = rs[i];
+			P.out_cigar_off[rec] = off_a;
+			P.run_off[rec] = off_b;
+			P.status[rec] = (int32_t) (fl & REC_STATUS_MASK);
+			uint32_t const *src = W.arena + loc;
+			uint32_t *dst = P.out_cigar + off_a;
+			for (uint32_t k = 0; k < nc; ++k) dst[k] = src[k];
+			if (nr)
+			{
+				pvc3_run const *rs = W.runs_arena + W.run_loc[rec];
+				pvc3_run *rd = P.runs + off_b;
+				for (uint32_t k = 0; k < nr; ++k) rd[k] = rs[k];
+			}
 		}
-		P.status[rec] = (int32_t) (W.rec_flags[rec] & REC_STATUS_MASK);
 	}
+	if (0 == blockIdx.x && 0 == threadIdx.x) { P.out_cigar_off[n] = totals[0]; P.run_off[n] = totals[1]; }
 }
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)	// splitmix64 finalizer
@@ -281,9 +285,7 @@ int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &
 	if (n_tiles)
 		hipLaunchKernelGGL(k_scan_tiles, dim3((uint32_t) n_tiles), dim3(SCAN_THREADS), 0, s, n, work.cig_n, work.run_n, scan_tmp);
 	hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, s, n_tiles, scan_tmp, totals);
-	hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t) (n_tiles ? n_tiles : 1)), dim3(SCAN_THREADS), 0, s, n, work.cig_n, work.run_n, scan_tmp, totals, packed.out_cigar_off, packed.run_off);
-	if (n)
-		hipLaunchKernelGGL(k_gather, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, n, work, packed);
+	hipLaunchKernelGGL(k_offsets_gather, dim3((uint32_t) (n_tiles ? n_tiles : 1)), dim3(SCAN_THREADS), 0, s, n, work, packed, scan_tmp, totals);
 	return (int) hipGetLastError();
 }
 

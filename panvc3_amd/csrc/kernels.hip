@@ -1,6 +1,8 @@
 // kernels.hip — gfx950 kernels of the project_alignments hot path.
 //
-//   k_project            project.hip (projection walk + mate projection)
+//   k_project_fast / k_project_mid / k_project_general   project_*.hip (projection + mate projection)
+//   k_pack_text4         4-bit copy of a destination text
+//   k_reduce_stats       per-wave statistics -> counters
 //   k_realign            realign.hip
 //   k_project_positions  one thread per position: project_position (msa_index.hh:253-258)
 //   k_scan_* / k_offsets_gather   pack the per-record results in record order.

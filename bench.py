@@ -153,6 +153,16 @@ def main():
 			"batch": {"fast_path_records": stats["n_fast_path"], "mid_path_records": stats["n_mid_path"], "realigned_records": stats["n_realigned_records"], "indel_runs": stats["n_runs"], "out_cigar_ops": stats["out_cigar_total"], "checksum": "%016x" % checksum_total},
 		}
 
+		# ---- host-buffer entry point (PCIe-inclusive; never `value`): upload + kernels + download of a slice, no overlap ----
+		if world == 1:
+			k = int(min(n_local, 4_000_000))
+			sb = synth.slice_batch(batch, 0, k)
+			panvc3_amd.project_batch(ctx, synth.slice_batch(batch, 0, min(k, 100_000)))		# first-use allocations
+			tb = time.perf_counter()
+			panvc3_amd.project_batch(ctx, sb)
+			dt = time.perf_counter() - tb
+			result["host_buffers"] = {"value": k / dt, "unit": "alignments/s", "records": k, "what": "pvc3_batch_project: pageable host arrays in, host arrays out (H2D + kernels + D2H, no overlap between batches)"}
+
 		# ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample, same box, rank 0 only ----
 		if world == 1 and args.cpu_baseline_seconds > 0:
 			from oracle import oracle as orc

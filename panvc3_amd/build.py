@@ -65,7 +65,7 @@ def build_host(force=False, verbose=False):
 	os.makedirs(BIN, exist_ok=True)
 	headers = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "pvc3.h")]
 	cxx = os.environ.get("CXX", "g++")
-	flags = ["-O2", "-g", "-std=c++17", "-Wall", "-Wextra"]
+	flags = ["-O2", "-g", "-std=c++17", "-Wall", "-Wextra", "-pthread"]
 	out = []
 	for name, extra in (
 		("panvc3_index_msa", ["-lz"]),

@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <algorithm>
+#include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace pvc3host {
@@ -18,34 +21,178 @@ struct io_error : public std::runtime_error
 	using std::runtime_error::runtime_error;
 };
 
-// Sequential byte source: a file or stdin, transparently inflating gzip / BGZF (zlib handles multi-member gzip).
+// Runs fn(i) for i in [0, n) on up to n_threads threads (fork / join; the pieces are tens of kilobytes of zlib work each).
+template <typename t_fn>
+inline void parallel_for(std::size_t n, unsigned n_threads, t_fn &&fn)
+{
+	if (n_threads <= 1 || n <= 1)
+	{
+		for (std::size_t i = 0; i < n; ++i) fn(i);
+		return;
+	}
+	unsigned const k = (unsigned) std::min <std::size_t>(n_threads, n);
+	std::vector <std::thread> pool;
+	std::vector <std::exception_ptr> errors(k);
+	for (unsigned t = 0; t < k; ++t)
+		pool.emplace_back([&, t]() {
+			try { for (std::size_t i = t; i < n; i += k) fn(i); }
+			catch (...) { errors[t] = std::current_exception(); }
+		});
+	for (auto &th : pool) th.join();
+	for (auto &e : errors) if (e) std::rethrow_exception(e);
+}
+
+inline unsigned default_io_threads()
+{
+	unsigned const hc = std::thread::hardware_concurrency();
+	return hc ? std::min(hc, 16u) : 4u;
+}
+
+// Sequential byte source: a file or stdin.  BGZF input (BAM, bgzip'ed SAM) is inflated block-parallel; plain gzip and
+// uncompressed input go through zlib's gz* interface.
 class byte_reader
 {
 	gzFile m_file{};
+	// BGZF path
+	FILE *m_raw{};
+	unsigned m_threads{1};
+	std::vector <uint8_t> m_cbuf;		// compressed bytes not yet inflated (whole blocks + a partial tail)
+	std::size_t m_clen{};
+	std::vector <uint8_t> m_dbuf;		// inflated bytes
+	std::size_t m_dpos{};
+	bool m_eof{};
+
+	static constexpr std::size_t CHUNK = 32u << 20;
+
+	struct block { std::size_t in_off, in_len, out_off, out_len; uint32_t crc; };
+
+	// Length of the BGZF block at p (n bytes available) or 0 if incomplete; throws if p is not a BGZF block.
+	static std::size_t block_size(uint8_t const *p, std::size_t n, std::size_t &data_off)
+	{
+		if (n < 18) return 0;
+		if (!(0x1f == p[0] && 0x8b == p[1] && 8 == p[2] && (p[3] & 4))) throw io_error("corrupt BGZF stream (bad block header)");
+		std::size_t const xlen = p[10] | ((std::size_t) p[11] << 8);
+		if (n < 12 + xlen) return 0;
+		for (std::size_t o = 12; o + 4 <= 12 + xlen; )
+		{
+			std::size_t const slen = p[o + 2] | ((std::size_t) p[o + 3] << 8);
+			if ('B' == p[o] && 'C' == p[o + 1] && 2 == slen)
+			{
+				data_off = 12 + xlen;
+				return (std::size_t) (p[o + 4] | ((std::size_t) p[o + 5] << 8)) + 1;
+			}
+			o += 4 + slen;
+		}
+		throw io_error("corrupt BGZF stream (no BC field)");
+	}
+
+	bool refill()
+	{
+		m_dbuf.clear(); m_dpos = 0;
+		while (m_dbuf.empty())
+		{
+			if (!m_eof)
+			{
+				m_cbuf.resize(std::max(m_cbuf.size(), m_clen + CHUNK));
+				std::size_t const got = std::fread(m_cbuf.data() + m_clen, 1, CHUNK, m_raw);
+				if (got < CHUNK) { if (std::ferror(m_raw)) throw io_error("read error"); m_eof = true; }
+				m_clen += got;
+			}
+			std::vector <block> blocks;
+			std::size_t off = 0, out = 0;
+			for (;;)
+			{
+				std::size_t data_off = 0;
+				std::size_t const bs = block_size(m_cbuf.data() + off, m_clen - off, data_off);
+				if (0 == bs || off + bs > m_clen) break;
+				if (bs < data_off + 8) throw io_error("corrupt BGZF stream (short block)");
+				uint32_t crc, isize;
+				std::memcpy(&crc, m_cbuf.data() + off + bs - 8, 4);
+				std::memcpy(&isize, m_cbuf.data() + off + bs - 4, 4);
+				blocks.push_back(block{off + data_off, bs - data_off - 8, out, isize, crc});
+				out += isize; off += bs;
+			}
+			if (blocks.empty())
+			{
+				if (m_eof) { if (m_clen) throw io_error("truncated BGZF stream"); return false; }
+				continue;
+			}
+			m_dbuf.resize(out);
+			parallel_for(blocks.size(), m_threads, [&](std::size_t i) {
+				block const &b = blocks[i];
+				if (0 == b.out_len) return;
+				z_stream zs{};
+				if (Z_OK != inflateInit2(&zs, -15)) throw io_error("inflateInit2 failed");
+				zs.next_in = m_cbuf.data() + b.in_off; zs.avail_in = (uInt) b.in_len;
+				zs.next_out = m_dbuf.data() + b.out_off; zs.avail_out = (uInt) b.out_len;
+				int const rc = inflate(&zs, Z_FINISH);
+				inflateEnd(&zs);
+				if (Z_STREAM_END != rc || zs.total_out != b.out_len) throw io_error("corrupt BGZF block");
+				if ((uint32_t) crc32(crc32(0L, Z_NULL, 0), m_dbuf.data() + b.out_off, (uInt) b.out_len) != b.crc) throw io_error("BGZF block checksum mismatch");
+			});
+			std::memmove(m_cbuf.data(), m_cbuf.data() + off, m_clen - off);
+			m_clen -= off;
+			if (m_dbuf.empty() && m_eof && 0 == m_clen) return false;		// only the EOF marker was left
+		}
+		return true;
+	}
 
 public:
 	byte_reader() = default;
 	byte_reader(byte_reader const &) = delete;
 	~byte_reader() { close(); }
 
+	void set_threads(unsigned n) { m_threads = n ? n : 1; }
+
 	void open(char const *path)		// nullptr or "-" = stdin
 	{
 		close();
-		if (!path || 0 == std::strcmp(path, "-"))
-			m_file = gzdopen(0, "rb");
-		else
-			m_file = gzopen(path, "rb");
+		bool const is_stdin = !path || 0 == std::strcmp(path, "-");
+		if (!is_stdin)
+		{
+			// BGZF?  Then inflate the blocks ourselves, several at a time.
+			FILE *f = std::fopen(path, "rb");
+			if (!f) throw io_error(std::string("unable to open ") + path);
+			uint8_t head[18];
+			std::size_t const got = std::fread(head, 1, sizeof(head), f);
+			// The usual layout (htslib, this writer): BC is the only extra field.  Anything else is left to zlib.
+			bool const bgzf = 18 == got && 0x1f == head[0] && 0x8b == head[1] && 8 == head[2] && 4 == head[3] && 6 == head[10] && 0 == head[11]
+				&& 'B' == head[12] && 'C' == head[13] && 2 == head[14] && 0 == head[15];
+			if (bgzf)
+			{
+				std::rewind(f);
+				m_raw = f; m_clen = 0; m_eof = false; m_dbuf.clear(); m_dpos = 0;
+				return;
+			}
+			std::fclose(f);
+		}
+		m_file = is_stdin ? gzdopen(0, "rb") : gzopen(path, "rb");
 		if (!m_file)
 			throw io_error(std::string("unable to open ") + (path ? path : "stdin"));
 		gzbuffer(m_file, 1 << 20);
 	}
 
-	void close() { if (m_file) { gzclose(m_file); m_file = nullptr; } }
+	void close()
+	{
+		if (m_file) { gzclose(m_file); m_file = nullptr; }
+		if (m_raw) { std::fclose(m_raw); m_raw = nullptr; }
+	}
 
 	// Reads exactly n bytes unless the stream ends; returns the number read.
 	std::size_t read(void *dst, std::size_t n)
 	{
 		std::size_t got = 0;
+		if (m_raw)
+		{
+			while (got < n)
+			{
+				if (m_dpos == m_dbuf.size() && !refill()) break;
+				std::size_t const take = std::min(n - got, m_dbuf.size() - m_dpos);
+				std::memcpy((char *) dst + got, m_dbuf.data() + m_dpos, take);
+				m_dpos += take; got += take;
+			}
+			return got;
+		}
 		while (got < n)
 		{
 			unsigned const chunk = (unsigned) std::min <std::size_t>(n - got, 1u << 30);
@@ -61,6 +208,28 @@ public:
 	bool getline(std::string &line)
 	{
 		line.clear();
+		if (m_raw)
+		{
+			bool any = false;
+			for (;;)
+			{
+				if (m_dpos == m_dbuf.size() && !refill()) break;
+				any = true;
+				uint8_t const *b = m_dbuf.data() + m_dpos;
+				std::size_t const left = m_dbuf.size() - m_dpos;
+				uint8_t const *nl = (uint8_t const *) std::memchr(b, '\n', left);
+				if (nl)
+				{
+					line.append((char const *) b, (std::size_t) (nl - b));
+					m_dpos += (std::size_t) (nl - b) + 1;
+					if (!line.empty() && '\r' == line.back()) line.pop_back();
+					return true;
+				}
+				line.append((char const *) b, left);
+				m_dpos += left;
+			}
+			return any && !line.empty();
+		}
 		char buf[1 << 16];
 		for (;;)
 		{
@@ -79,21 +248,28 @@ public:
 
 	int peek()
 	{
+		if (m_raw)
+		{
+			if (m_dpos == m_dbuf.size() && !refill()) return -1;
+			return m_dbuf[m_dpos];
+		}
 		int const c = gzgetc(m_file);
 		if (c >= 0) gzungetc(c, m_file);
 		return c;
 	}
 };
 
-// Sequential byte sink: plain (SAM text) or BGZF blocks (BAM).
+// Sequential byte sink: plain (SAM text) or BGZF blocks (BAM).  Blocks are cut every 0xff00 bytes whatever the number of
+// threads, so the file does not depend on it; they are deflated a group at a time, in parallel.
 class byte_writer
 {
 	FILE *m_file{};
 	bool m_owns{};
 	bool m_bgzf{};
 	int m_level{6};
-	std::vector <uint8_t> m_block;		// pending uncompressed bytes of the current BGZF block
-	std::vector <uint8_t> m_out;
+	unsigned m_threads{1};
+	std::vector <uint8_t> m_pending;	// uncompressed bytes not yet written
+	std::vector <std::vector <uint8_t>> m_out;
 
 	static constexpr std::size_t BLOCK_DATA = 0xff00;	// uncompressed bytes per block (as htslib)
 
@@ -103,34 +279,58 @@ class byte_writer
 			throw io_error("write error");
 	}
 
-	void flush_block()
+	// BGZF block = gzip member with the BC extra field (SAMv1 §4.1.1).
+	void deflate_block(uint8_t const *src, std::size_t len, std::vector <uint8_t> &out) const
 	{
-		// BGZF block = gzip member with the BC extra field (SAMv1 §4.1.1).
-		m_out.resize(18 + compressBound((uLong) m_block.size()) + 8);
+		out.resize(18 + compressBound((uLong) len) + 8);
 		z_stream zs{};
 		if (Z_OK != deflateInit2(&zs, m_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY))
 			throw io_error("deflateInit2 failed");
-		zs.next_in = m_block.data(); zs.avail_in = (uInt) m_block.size();
-		zs.next_out = m_out.data() + 18; zs.avail_out = (uInt) (m_out.size() - 18 - 8);
+		zs.next_in = const_cast <uint8_t *>(src); zs.avail_in = (uInt) len;
+		zs.next_out = out.data() + 18; zs.avail_out = (uInt) (out.size() - 18 - 8);
 		if (Z_STREAM_END != deflate(&zs, Z_FINISH)) { deflateEnd(&zs); throw io_error("deflate failed"); }
 		std::size_t const clen = zs.total_out;
 		deflateEnd(&zs);
 		std::size_t const bsize = 18 + clen + 8;
 		static uint8_t const head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-		std::memcpy(m_out.data(), head, 16);
-		m_out[16] = (uint8_t) ((bsize - 1) & 0xff); m_out[17] = (uint8_t) ((bsize - 1) >> 8);
-		uint32_t const crc = (uint32_t) crc32(crc32(0L, Z_NULL, 0), m_block.data(), (uInt) m_block.size());
-		uint32_t const isize = (uint32_t) m_block.size();
-		std::memcpy(m_out.data() + 18 + clen, &crc, 4);
-		std::memcpy(m_out.data() + 18 + clen + 4, &isize, 4);
-		write_raw(m_out.data(), bsize);
-		m_block.clear();
+		std::memcpy(out.data(), head, 16);
+		out[16] = (uint8_t) ((bsize - 1) & 0xff); out[17] = (uint8_t) ((bsize - 1) >> 8);
+		uint32_t const crc = (uint32_t) crc32(crc32(0L, Z_NULL, 0), src, (uInt) len);
+		uint32_t const isize = (uint32_t) len;
+		std::memcpy(out.data() + 18 + clen, &crc, 4);
+		std::memcpy(out.data() + 18 + clen + 4, &isize, 4);
+		out.resize(bsize);
+	}
+
+	// Writes all whole blocks of m_pending (and the partial last one if `all`).
+	void flush_blocks(bool all)
+	{
+		std::size_t const n_full = m_pending.size() / BLOCK_DATA;
+		std::size_t const tail = m_pending.size() - n_full * BLOCK_DATA;
+		std::size_t const n = n_full + ((all && tail) ? 1 : 0);
+		if (0 == n) return;
+		if (m_out.size() < n) m_out.resize(n);
+		parallel_for(n, m_threads, [&](std::size_t i) {
+			std::size_t const len = (i < n_full) ? BLOCK_DATA : tail;
+			deflate_block(m_pending.data() + i * BLOCK_DATA, len, m_out[i]);
+		});
+		for (std::size_t i = 0; i < n; ++i)
+			write_raw(m_out[i].data(), m_out[i].size());
+		if (n == n_full && tail)
+		{
+			std::memmove(m_pending.data(), m_pending.data() + n_full * BLOCK_DATA, tail);
+			m_pending.resize(tail);
+		}
+		else
+			m_pending.clear();
 	}
 
 public:
 	byte_writer() = default;
 	byte_writer(byte_writer const &) = delete;
 	~byte_writer() { try { close(); } catch (...) {} }
+
+	void set_threads(unsigned n) { m_threads = n ? n : 1; }
 
 	void open(char const *path, bool bgzf, int level = 6)		// nullptr or "-" = stdout
 	{
@@ -144,20 +344,15 @@ public:
 			m_owns = true;
 		}
 		static_cast <void>(std::setvbuf(m_file, nullptr, _IOFBF, 1 << 20));
-		m_block.reserve(BLOCK_DATA);
 	}
 
 	void write(void const *p, std::size_t n)
 	{
 		if (!m_bgzf) { write_raw(p, n); return; }
 		uint8_t const *src = (uint8_t const *) p;
-		while (n)
-		{
-			std::size_t const take = std::min(n, BLOCK_DATA - m_block.size());
-			m_block.insert(m_block.end(), src, src + take);
-			src += take; n -= take;
-			if (m_block.size() == BLOCK_DATA) flush_block();
-		}
+		m_pending.insert(m_pending.end(), src, src + n);
+		if (m_pending.size() >= BLOCK_DATA * 16 * (std::size_t) m_threads)
+			flush_blocks(false);
 	}
 
 	void write(std::string const &s) { write(s.data(), s.size()); }
@@ -167,7 +362,7 @@ public:
 		if (!m_file) return;
 		if (m_bgzf)
 		{
-			if (!m_block.empty()) flush_block();
+			flush_blocks(true);
 			// The empty EOF marker block.
 			static uint8_t const eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 			write_raw(eof, sizeof(eof));

@@ -54,6 +54,7 @@ struct options
 	std::string rname_tag{"XR"}, pos_tag{"XP"}, rnext_tag{"YR"}, pnext_tag{"YP"}, query_ranges_tag{"XB"}, ref_ranges_tag{"YB"}, rec_idx_tag;
 	int gap_open{0}, gap_ext{-1}, device{0};
 	uint64_t batch_size{UINT64_C(1) << 21};
+	unsigned threads{default_io_threads()};		// BGZF inflate / deflate
 };
 
 void usage()
@@ -195,7 +196,7 @@ int main(int argc, char **argv)
 		{"record-index-tag", required_argument, nullptr, 1008}, {"use-read-base-qualities", no_argument, nullptr, 'q'},
 		{"gap-opening-cost", required_argument, nullptr, 'g'}, {"gap-extension-cost", required_argument, nullptr, 'e'},
 		{"print-invocation", no_argument, nullptr, 1009}, {"print-pid", no_argument, nullptr, 1010}, {"debugging-output", no_argument, nullptr, 1011},
-		{"device", required_argument, nullptr, 1012}, {"batch-size", required_argument, nullptr, 1013}, {"io-only", no_argument, nullptr, 1014},
+		{"device", required_argument, nullptr, 1012}, {"batch-size", required_argument, nullptr, 1013}, {"io-only", no_argument, nullptr, 1014}, {"threads", required_argument, nullptr, 1015},
 		{"help", no_argument, nullptr, 'h'}, {"version", no_argument, nullptr, 'V'}, {nullptr, 0, nullptr, 0}};
 	int c;
 	while (-1 != (c = getopt_long(argc, argv, "a:Bm:r:d:s:u:o:bl:t:qg:e:hV", long_opts, nullptr)))
@@ -231,6 +232,7 @@ int main(int argc, char **argv)
 			case 1012: opt.device = std::atoi(optarg); break;
 			case 1013: opt.batch_size = std::strtoull(optarg, nullptr, 10); break;
 			case 1014: opt.io_only = true; break;
+			case 1015: opt.threads = (unsigned) std::max(1, std::atoi(optarg)); break;
 			case 'h': usage(); return 0;
 			case 'V': std::cout << "project-alignments 0.1 (panvc3-mi355x)\n"; return 0;
 			default: return EXIT_FAILURE;
@@ -258,6 +260,7 @@ int main(int argc, char **argv)
 		auto const t_start = std::chrono::steady_clock::now();
 		// ---- input + headers -------------------------------------------------------------------------------------------------
 		alignment_reader reader;
+		reader.set_threads(opt.threads);
 		{
 			bool is_bam = opt.bam_input;
 			if (opt.alignments)
@@ -276,6 +279,7 @@ int main(int argc, char **argv)
 			// Format conversion only (SAM <-> BAM round trips of the I/O layer; no index, no GPU).
 			out_header = in_header;
 			alignment_writer writer;
+			writer.set_threads(opt.threads);
 			writer.open(opt.output_path, opt.output_bam, out_header);
 			bam_record rec;
 			while (reader.next(rec)) writer.write(rec);
@@ -333,6 +337,7 @@ int main(int argc, char **argv)
 		check(pvc3_context_upload_index(ctx, index), "pvc3_context_upload_index");
 
 		alignment_writer writer;
+		writer.set_threads(opt.threads);
 		writer.open(opt.output_path, opt.output_bam, out_header);
 
 		// ---- records ----------------------------------------------------------------------------------------------------------------
@@ -353,8 +358,15 @@ int main(int argc, char **argv)
 		std::vector <int32_t> o_status;
 		std::vector <uint64_t> o_cigar_off, o_run_off;
 		std::vector <pvc3_run> o_runs;
-		std::string oa;
-		std::map <uint16_t, std::vector <uint8_t>> tags;		// ordered by tag key, as seqan3's sam_tag_dictionary
+		struct slice_state		// per-thread scratch and results of one slice of a batch
+		{
+			std::string bytes, oa;
+			std::map <uint16_t, std::vector <uint8_t>> tags;		// ordered by tag key, as seqan3's sam_tag_dictionary
+			std::vector <std::pair <uint32_t, uint32_t>> ranges;
+			std::map <uint16_t, uint64_t> removed;
+			uint64_t n_ranges{};
+		};
+		std::vector <slice_state> slices;
 
 		while (!eof)
 		{
@@ -426,22 +438,30 @@ int main(int argc, char **argv)
 			check(pvc3_dbatch_download(ctx, db, &out), "pvc3_dbatch_download");
 			pvc3_dbatch_destroy(db);
 
-			// Rewrite and write the records, in input order.
-			for (uint64_t i = 0; i < n; ++i)
+			// Rewrite the records: contiguous slices of the batch on separate threads, each into its own byte string; the strings
+			// are written in slice order, so the output does not depend on the number of threads.
+			std::size_t const n_slices = std::min <std::size_t>(n, 4 * (std::size_t) opt.threads);
+			if (slices.size() < n_slices) slices.resize(n_slices);
+			parallel_for(n_slices, opt.threads, [&](std::size_t si) {
+			slice_state &S = slices[si];
+			S.bytes.clear(); S.ranges.clear(); S.removed.clear(); S.n_ranges = 0;
+			std::map <uint16_t, std::vector <uint8_t>> &tags = S.tags;
+			std::string &oa = S.oa;
+			for (uint64_t i = n * si / n_slices; i < n * (si + 1) / n_slices; ++i)
 			{
 				bam_record const &r = batch[i].rec;
 				if (o_status[i])
-					die(std::string("record ") + r.read_name() + " (input record " + std::to_string(batch[i].input_index) + ") cannot be projected: status " + std::to_string(o_status[i])
+					throw std::runtime_error(std::string("record ") + r.read_name() + " (input record " + std::to_string(batch[i].input_index) + ") cannot be projected: status " + std::to_string(o_status[i])
 						+ " (the reference asserts here: position or CIGAR inconsistent with the index)");
 				int32_t const ref_id = r.ref_id();
 				uint32_t const *cig = o_cigar.data() + o_cigar_off[i];
 				uint64_t const n_cig = o_cigar_off[i + 1] - o_cigar_off[i];
-				if (n_cig > 65535) die("more than 65535 CIGAR operations after projection");
+				if (n_cig > 65535) throw std::runtime_error("more than 65535 CIGAR operations after projection");
 				pvc3_run const *runs = o_runs.data() + o_run_off[i];
 				uint64_t const n_runs = o_run_off[i + 1] - o_run_off[i];
-				n_realigned_ranges += n_runs;
+				S.n_ranges += n_runs;
 				if (opt.realigned_ranges)
-					for (uint64_t k = 0; k < n_runs; ++k) realigned_ranges.emplace_back(runs[k].ref_position, runs[k].ref_length);
+					for (uint64_t k = 0; k < n_runs; ++k) S.ranges.emplace_back(runs[k].ref_position, runs[k].ref_length);
 
 				// -- tags: keep the preserved ones (:775-802), remember NM
 				tags.clear();
@@ -460,7 +480,7 @@ int main(int argc, char **argv)
 							case 'i': { int32_t v; std::memcpy(&v, f.value, 4); nm = v; break; } default: { uint32_t v; std::memcpy(&v, f.value, 4); nm = v; break; }
 						}
 					}
-					if (!preserved.count(key)) { ++removed_tag_counts[key]; continue; }
+					if (!preserved.count(key)) { ++S.removed[key]; continue; }
 					if ('O' == f.tag[0] && 'A' == f.tag[1] && 'Z' == f.type) { old_oa.assign((char const *) f.value, f.size - 1); continue; }
 					std::vector <uint8_t> &v = tags[key];
 					v.assign({(uint8_t) f.tag[0], (uint8_t) f.tag[1], (uint8_t) f.type});
@@ -520,7 +540,7 @@ int main(int argc, char **argv)
 					put_int(opt.rnext_tag, r.next_ref_id());
 					if (r.next_pos() >= 0)
 					{
-						if (PVC3_NO_MATE == o_mate[i]) die(std::string("the mate position of ") + r.read_name() + " lies outside its sequence");
+						if (PVC3_NO_MATE == o_mate[i]) throw std::runtime_error(std::string("the mate position of ") + r.read_name() + " lies outside its sequence");
 						new_next_pos = (int32_t) o_mate[i];
 						put_int(opt.pnext_tag, r.next_pos());
 					}
@@ -553,7 +573,16 @@ int main(int argc, char **argv)
 				w.data.insert(w.data.end(), r.qual(), r.qual() + r.l_seq());
 				if (r.has_qual()) for (uint32_t k = 0; k < r.l_seq(); ++k) if (w.data[qual_at + k] > 41) w.data[qual_at + k] = 41;
 				for (auto const &kv : tags) w.data.insert(w.data.end(), kv.second.begin(), kv.second.end());
-				writer.write(w);
+				writer.format(w, S.bytes);
+			}
+			});
+			for (std::size_t si = 0; si < n_slices; ++si)
+			{
+				slice_state &S = slices[si];
+				writer.write_formatted(S.bytes.data(), S.bytes.size());
+				n_realigned_ranges += S.n_ranges;
+				realigned_ranges.insert(realigned_ranges.end(), S.ranges.begin(), S.ranges.end());
+				for (auto const &kv : S.removed) removed_tag_counts[kv.first] += kv.second;
 			}
 		}
 		writer.close();

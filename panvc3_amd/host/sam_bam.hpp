@@ -468,6 +468,8 @@ class alignment_reader
 public:
 	sam_header header;
 
+	void set_threads(unsigned n) { m_in.set_threads(n); }
+
 	void open(char const *path, bool bam)
 	{
 		m_in.open(path);
@@ -542,6 +544,8 @@ class alignment_writer
 	sam_header const *m_header{};
 
 public:
+	void set_threads(unsigned n) { m_out.set_threads(n); }
+
 	void open(char const *path, bool bam, sam_header const &hdr)
 	{
 		m_is_bam = bam; m_header = &hdr;
@@ -578,6 +582,24 @@ public:
 			m_out.write(m_buf);
 		}
 	}
+
+	// Appends to `out` exactly the bytes write(r) would emit (callable from several threads at once).
+	void format(bam_record const &r, std::string &out) const
+	{
+		if (m_is_bam)
+		{
+			int32_t const bs = (int32_t) r.data.size();
+			out.append((char const *) &bs, 4);
+			out.append((char const *) r.data.data(), r.data.size());
+		}
+		else
+		{
+			format_sam_record(out, r, *m_header);
+			out += '\n';
+		}
+	}
+
+	void write_formatted(char const *p, std::size_t n) { m_out.write(p, n); }
 
 	void close() { m_out.close(); }
 };

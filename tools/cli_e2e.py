@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the command line tools (SURVEY.md §8 d iii): synthetic MSA -> panvc3_index_msa, synthetic BAM ->
+panvc3_project_alignments -> BAM, wall clock.  usage: tools/cli_e2e.py [--scale 0.2] [--workdir DIR]
+The reads are config C2 of BASELINE.json scaled (REF + 2 founders, 150 bp single-end)."""
+import argparse
+import os
+import struct
+import subprocess
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from tests.synth import synth		# noqa: E402
+import bamio						# noqa: E402
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--scale", type=float, default=0.2)
+	ap.add_argument("--workdir", default="/tmp/pvc3_e2e")
+	args = ap.parse_args()
+	os.makedirs(args.workdir, exist_ok=True)
+	os.chdir(args.workdir)
+	from panvc3_amd import build
+	build.build()
+	tools = build.build_host()
+	index_msa = [t for t in tools if t.endswith("panvc3_index_msa")][0]
+	project = [t for t in tools if t.endswith("panvc3_project_alignments")][0]
+
+	gp, rp, desc = synth.config("C2", scale=args.scale)
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	b = reads.batch()
+	n = int(reads.n)
+	names = ["chr1/REF"] + ["chr1/%d" % k for k in range(1, genome.n_entries)]
+	lens = []
+	with open("input.tsv", "w") as tsv:
+		for e in range(genome.n_entries):
+			words, n_cols, text = genome.entry(e)
+			bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n_cols]
+			row = np.full(n_cols, ord("-"), dtype=np.uint8)
+			row[bits == 0] = text
+			row.tofile("row%d.txt" % e)
+			lens.append(len(text))
+			tsv.write("chr1\t%s\t%s\n" % (names[e].split("/")[1], os.path.abspath("row%d.txt" % e)))
+			if 0 == e:
+				with open("genome.fa", "wb") as f:
+					f.write(b">chr1\n")
+					t = text.tobytes()
+					for i in range(0, len(t), 1 << 20):
+						f.write(t[i:i + (1 << 20)])		# one long line per MiB is fine for the reader
+						f.write(b"\n")
+	t0 = time.perf_counter()
+	subprocess.check_call([index_msa, "--build-index", "--sequence-inputs=input.tsv", "--msa-index-output=msa-index.dat"], stdout=subprocess.DEVNULL)
+	t_index = time.perf_counter() - t0
+
+	# ---- BAM straight from the SoA batch (CIGAR and SEQ are already in BAM encoding) --------------------------------------
+	header = "@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (nm, ln) for nm, ln in zip(names, lens)) + "@PG\tID:bowtie2\tPN:bowtie2\tVN:2.5.1\n"
+	raw = [b"BAM\1", struct.pack("<i", len(header)), header.encode(), struct.pack("<i", len(names))]
+	for nm, ln in zip(names, lens):
+		raw += [struct.pack("<i", len(nm) + 1), nm.encode(), b"\0", struct.pack("<i", ln)]
+	cig_off, seq_off, qual_off = b["cigar_off"].astype(np.int64), b["seq_off"].astype(np.int64), b["qual_off"].astype(np.int64)
+	cig_bytes, seq_bytes, qual_bytes = b["cigar"].tobytes(), b["seq4"].tobytes(), b["qual"].tobytes()
+	src_pos, src_entry, l_seq = b["src_pos"], b["src_entry"], b["l_seq"]
+	tags = b"ASc\xfbXSc\xecYTZUU\0"
+	for i in range(n):
+		qname = b"r%d\0" % i
+		n_cig = int(cig_off[i + 1] - cig_off[i])
+		body = struct.pack("<iiBBHHHIiii", int(src_entry[i]), int(src_pos[i]), len(qname), 30, 4680, n_cig, 0, int(l_seq[i]), -1, -1, 0)
+		rec = body + qname + cig_bytes[4 * cig_off[i]:4 * cig_off[i + 1]] + seq_bytes[seq_off[i]:seq_off[i + 1]] + qual_bytes[qual_off[i]:qual_off[i + 1]] + tags
+		raw.append(struct.pack("<i", len(rec)))
+		raw.append(rec)
+	blob = b"".join(raw)
+	with open("in.bam", "wb") as f:
+		for i in range(0, len(blob), 0xff00):
+			f.write(bamio._bgzf_block(blob[i:i + 0xff00]))
+		f.write(bamio._bgzf_block(b""))
+	in_size = os.path.getsize("in.bam")
+
+	def run(cmd):
+		t = time.perf_counter()
+		p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+		if p.returncode:
+			sys.stderr.write(p.stderr.decode())
+			raise SystemExit("command failed: " + " ".join(cmd))
+		return time.perf_counter() - t
+
+	t_io = run([project, "--io-only", "-a", "in.bam", "-b", "-o", "io.bam"])
+	full = [project, "-a", "in.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-b", "-o", "out.bam"]
+	run(full)		# first run pays the page cache and the GPU start-up
+	t_full = run(full)
+	t_sam = run([project, "-a", "in.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-o", "out.sam"])
+	print("records %d, genome %d bp x %d rows, in.bam %.1f MB" % (n, lens[0], genome.n_entries, in_size / 1e6))
+	print("index_msa --build-index: %.2f s" % t_index)
+	print("project_alignments --io-only BAM->BAM: %.2f s = %.2f M records/s" % (t_io, n / t_io / 1e6))
+	print("project_alignments BAM->BAM: %.2f s = %.2f M records/s" % (t_full, n / t_full / 1e6))
+	print("project_alignments BAM->SAM: %.2f s = %.2f M records/s" % (t_sam, n / t_sam / 1e6))
+
+
+if __name__ == "__main__":
+	main()

@@ -175,6 +175,15 @@ def test_io_round_trip_sam_bam(tools, tmp_path):
 	body = [l for l in back if l and not l.startswith("@")]
 	assert body == [r.sam_line() for r in recs]
 	assert [l for l in back if l.startswith("@SQ")] == ["@SQ\tSN:%s\tLN:%d" % (n, 10000 + i) for i, n in enumerate(names)]
+	# the BGZF layer cuts blocks at fixed offsets: the file does not depend on the number of deflate threads
+	_run([tools["panvc3_project_alignments"], "--io-only", "--threads=1", "-a", "in.sam", "-b", "-o", "t1.bam"], cwd=tmp_path)
+	_run([tools["panvc3_project_alignments"], "--io-only", "--threads=7", "-a", "t1.bam", "-b", "-o", "t7.bam"], cwd=tmp_path)
+	assert open(tmp_path / "t1.bam", "rb").read() == open(tmp_path / "t7.bam", "rb").read() == open(tmp_path / "x.bam", "rb").read()
+	# a truncated BGZF file is an error, not a short read
+	raw = open(tmp_path / "x.bam", "rb").read()
+	open(tmp_path / "cut.bam", "wb").write(raw[:len(raw) // 2])
+	p = _run([tools["panvc3_project_alignments"], "--io-only", "-a", "cut.bam", "-o", "cut.sam"], cwd=tmp_path, check=False)
+	assert p.returncode != 0 and b"ERROR" in p.stderr
 	# python-written BAM is read too (bgzf blocks written by another implementation)
 	bamio.write_bam(tmp_path / "py.bam", header, [(n, 10000 + i) for i, n in enumerate(names)], recs)
 	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "py.bam", "-o", "py.sam"], cwd=tmp_path)

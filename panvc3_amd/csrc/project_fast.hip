@@ -26,6 +26,7 @@ namespace {
 constexpr uint32_t FAST_MAX_BASES = 256;
 constexpr uint32_t FAST_WORDS = FAST_MAX_BASES / 32;
 constexpr uint32_t LDS_ENTRIES = 256;
+constexpr uint32_t STAGE_TOKENS = 64 * FAST_WORDS;		// uint32 in a wave's LDS area (mismatch words, then output operations)
 #ifndef PVC3_FAST_MIN_WAVES
 #define PVC3_FAST_MIN_WAVES 4
 #endif
@@ -38,10 +39,14 @@ __device__ __forceinline__ uint32_t mismatch32(u64x2 const &qq, uint32_t t0, uin
 		| (mismatch8((uint32_t) q1, t2) << 16) | (mismatch8((uint32_t) (q1 >> 32), t3) << 24);
 }
 
-// Orders this wave's LDS writes before its later LDS reads (the LDS queue of a wave is in-order; this stops the compiler).
+// Orders this wave's LDS accesses before its later ones.  The LDS queue of a wave is in-order, so only the compiler has to
+// be stopped: the staging area is accessed through several types (16-byte pieces, mismatch words, operations), type-based
+// alias analysis would let the machine scheduler move a load past a store of another type, and a wavefront-scope fence
+// emits no instruction that could stop it.  The asm statement is a barrier for both the optimiser and the scheduler.
 __device__ __forceinline__ void wave_lds_sync()
 {
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	__syncthreads();
 	// Per-wave staging for the cooperative compare: record descriptors out, mismatch words back.
 	__shared__ u64x2 lds_desc[4][64];
-	__shared__ uint32_t lds_mask[4][64 * FAST_WORDS];
+	__shared__ uint32_t lds_mask[4][STAGE_TOKENS];
 	uint32_t const wave_in_block = rfl(threadIdx.x >> 6);
 	u64x2 *my_desc = lds_desc[wave_in_block];
 	uint32_t *my_mask = lds_mask[wave_in_block];
@@ -307,11 +312,13 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			bool const have = arena_take(arena, total, W, lane, base_loc);
 			if (!have) f_n_out = 0;		// arena overflow: the host grows it and repeats the batch
 			f_loc = base_loc + (scan - f_n_out);
-			if (have && fast)
-			{
-				uint32_t *dst = W.arena + f_loc;
+			// The group's operations are contiguous in the arena.  Each lane stores its own few; through LDS (then one coalesced
+			// copy by the whole wave) when the group's operations fit there, directly otherwise.
+			bool const staged = total <= STAGE_TOKENS;
+			wave_lds_sync();		// the mismatch words in this LDS area have been read
+			auto emit = [&](auto put) {
 				uint32_t k = 0;
-				if (lead) dst[k++] = lead;
+				if (lead) put(k++, lead);
 				uint32_t start = 0, type = mm[0] & 1;
 				prev_top = type;
 #pragma unroll
@@ -326,14 +333,31 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 						while (tr)
 						{
 							uint32_t const pos = 32 * w + (uint32_t) __builtin_ctz(tr);
-							dst[k++] = ((pos - start) << 4) | (type ? OP_X : OP_EQ);
+							put(k++, ((pos - start) << 4) | (type ? OP_X : OP_EQ));
 							start = pos; type ^= 1;
 							tr &= tr - 1;
 						}
 					}
 				}
-				dst[k++] = ((R - start) << 4) | (type ? OP_X : OP_EQ);
-				if (trail) dst[k++] = trail;
+				put(k++, ((R - start) << 4) | (type ? OP_X : OP_EQ));
+				if (trail) put(k++, trail);
+			};
+			if (staged)
+			{
+				uint32_t *dst = my_mask + (scan - f_n_out);
+				if (have && fast) emit([&](uint32_t k, uint32_t v) { dst[k] = v; });
+				wave_lds_sync();
+				if (have)
+					for (uint32_t j = lane; j < total; j += 64)
+						W.arena[base_loc + j] = my_mask[j];
+			}
+			else if (have && fast)
+			{
+				uint32_t *dst = W.arena + f_loc;
+				emit([&](uint32_t k, uint32_t v) { dst[k] = v; });
+			}
+			if (have && fast)
+			{
 				acc_bitvec += 2 * ((R + 8) / 8);
 				acc_ref += (R + 1) / 2;
 				acc_fast += 1;

@@ -84,14 +84,40 @@ __device__ __forceinline__ dp_memory dp_carve(uint8_t *base, uint32_t m, uint32_
 
 // Global affine alignment of ref[0, m) (horizontal) against query bases [q0, q0 + n) (vertical); pushes the resulting
 // operations into `out`.  All control flow is wave-uniform.
+struct dp_scores
+{
+	double open, ext;			// pvc3_params gap costs
+	double const *match;		// LDS copies of dev_params::s_match / s_mismatch
+	double const *mismatch;
+};
+
 __device__ __forceinline__ void align_global(
 	uint8_t const *ref, uint32_t m, uint8_t const *seq4, uint32_t q0, uint32_t n, uint8_t const *qual /* or nullptr */,
-	dev_params const *__restrict__ prm, dp_memory const mem, sink &out, uint32_t lane
+	dp_scores const &sc, dp_memory const mem, sink &out, uint32_t lane
 )
 {
-	double const go = (double) prm->gap_open + (double) prm->gap_ext;	// seqan3's internal gap-open score = open + extension
-	double const ge = (double) prm->gap_ext;
+	double const go = sc.open + sc.ext;	// seqan3's internal gap-open score = open + extension
+	double const ge = sc.ext;
 	double const neg_inf = -__builtin_inf();
+
+	// Query base and scores of a lane's row in the stripe starting at i0.  Called for the first stripe before the reference
+	// slice is fetched, so that the two global round trips overlap.
+	auto load_row = [&](uint32_t i0, uint32_t &q_rank, double &s_match, double &s_mismatch) {
+		q_rank = 3; s_match = 0.0; s_mismatch = -1.0;			// nucleotide_scoring_scheme<> default: 0 / -1
+		if (i0 + lane < n)
+		{
+			q_rank = dna5_rank_of_seq4(seq4_at(seq4, q0 + i0 + lane));
+			if (qual)
+			{
+				uint32_t qq = qual[q0 + i0 + lane];
+				qq = (qq > MAX_PHRED) ? MAX_PHRED : qq;			// phred42 saturates
+				s_match = sc.match[qq];
+				s_mismatch = sc.mismatch[qq];
+			}
+		}
+	};
+	uint32_t q_rank0; double s_match0, s_mismatch0;
+	load_row(0, q_rank0, s_match0, s_mismatch0);
 
 	// Reference slice -> dna5 ranks, once (a global load per DP step would put an HBM round trip on the critical path).
 	for (uint32_t j = lane; j < m; j += 64)
@@ -102,7 +128,7 @@ __device__ __forceinline__ void align_global(
 	// has the closed forms k * (open + ext) when the opening score is positive and open + k * ext otherwise; all values are
 	// small integers, so the products are exactly the iterated sums of the oracle.
 	{
-		double const open = (double) prm->gap_open;
+		double const open = sc.open;
 		for (uint32_t k = lane; k <= (m > n ? m : n); k += 64)
 		{
 			double const x = (0 == k) ? 0.0 : ((open > 0.0) ? (double) k * go : open + (double) k * ge);
@@ -119,19 +145,12 @@ __device__ __forceinline__ void align_global(
 		uint32_t const nr = (n - i0 < 64) ? (n - i0) : 64;		// rows in this stripe
 		bool const row_ok = lane < nr;
 		uint32_t const i = i0 + lane + 1;						// this lane's row (1-based)
-		uint32_t q_rank = 3;
-		double s_match = 0.0, s_mismatch = -1.0;				// nucleotide_scoring_scheme<> default: 0 / -1
+		uint32_t q_rank = q_rank0;
+		double s_match = s_match0, s_mismatch = s_mismatch0;
+		if (i0) load_row(i0, q_rank, s_match, s_mismatch);
 		double m_left = 0.0, h_left = neg_inf, diag = 0.0;
 		if (row_ok)
 		{
-			q_rank = dna5_rank_of_seq4(seq4_at(seq4, q0 + i - 1));
-			if (qual)
-			{
-				uint32_t qq = qual[q0 + i - 1];
-				qq = (qq > MAX_PHRED) ? MAX_PHRED : qq;			// phred42 saturates
-				s_match = prm->s_match[qq];
-				s_mismatch = prm->s_mismatch[qq];
-			}
 			m_left = mem.col_m[i];
 			diag = mem.col_m[i - 1];
 		}
@@ -222,7 +241,15 @@ __global__ __launch_bounds__(64) void k_realign(
 )
 {
 	__shared__ __attribute__((aligned(16))) uint8_t lds[REALIGN_LDS_BYTES];
+	__shared__ double lds_scores[2 * (MAX_PHRED + 1)];
 	uint32_t const lane = lane_id();
+	if (lane <= MAX_PHRED) { lds_scores[lane] = prm->s_match[lane]; lds_scores[MAX_PHRED + 1 + lane] = prm->s_mismatch[lane]; }
+	dp_scores sc;
+	sc.open = (double) prm->gap_open; sc.ext = (double) prm->gap_ext;
+	sc.match = lds_scores; sc.mismatch = lds_scores + (MAX_PHRED + 1);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	uint32_t const wave = blockIdx.x;
 	uint32_t const n_waves = gridDim.x;
 	arena_alloc arena{0, 0}, runs_alloc{0, 0};
@@ -244,37 +271,44 @@ __global__ __launch_bounds__(64) void k_realign(
 			continue;
 
 		// Descriptors of the marked records, lane-parallel.
-		uint64_t v_loc = 0, v_seq_off = 0, v_qual_off = 0;
-		uint32_t v_n = 0, v_dst_pos = 0, v_dst_e = 0, v_l_seq = 0, v_has_qual = 0;
+		uint64_t v_loc = 0, v_seq_off = 0, v_qual_off = 0, v_text = 0;
+		uint32_t v_n = 0, v_dst_pos = 0, v_text_len = 0, v_l_seq = 0, v_has_qual = 0;
 		if (mine)
 		{
 			uint64_t const r = base + lane;
-			v_loc = W.cig_loc[r]; v_n = W.cig_n[r]; v_dst_pos = W.dst_pos[r]; v_dst_e = in.dst_entry[r];
+			v_loc = W.cig_loc[r]; v_n = W.cig_n[r]; v_dst_pos = W.dst_pos[r];
+			dev_entry const *de = entries + in.dst_entry[r];
+			v_text = (uint64_t) de->text; v_text_len = de->text_len;
 			v_seq_off = in.seq_off[r]; v_l_seq = in.l_seq[r];
 			v_has_qual = ((in.flags[r] & PVC3_FLAG_HAS_QUAL) && in.qual) ? 1 : 0;
 			if (v_has_qual) v_qual_off = in.qual_off[r];
 		}
 
+		// The first 64 operations of a record live in lanes; those of the next marked record are fetched while this one is processed.
+		auto load_ops = [&](uint32_t r) -> uint32_t { return (lane < readlane(v_n, r)) ? (W.arena + readlane64(v_loc, r))[lane] : 0; };
+		uint32_t opv_next = load_ops(ctz64(todo));
 		while (todo)
 		{
 			uint32_t const ri = ctz64(todo);
 			uint64_t const rec = base + ri;
 			todo &= todo - 1;
+			uint32_t const opv = opv_next;
+			if (todo) opv_next = load_ops(ctz64(todo));
 
 			uint32_t const *ops = W.arena + readlane64(v_loc, ri);
 			uint32_t const n_ops = readlane(v_n, ri);
 			uint32_t const dst_pos = readlane(v_dst_pos, ri);
-			dev_entry const D = entries[readlane(v_dst_e, ri)];
+			uint8_t const *d_text = (uint8_t const *) readlane64(v_text, ri);
+			uint32_t const d_text_len = readlane(v_text_len, ri);
 			uint8_t const *seq4 = in.seq4 + readlane64(v_seq_off, ri);
 			uint32_t const l_seq = readlane(v_l_seq, ri);
 			uint8_t const *qual = readlane(v_has_qual, ri) ? (in.qual + readlane64(v_qual_off, ri)) : nullptr;
-			uint32_t const opv = (lane < n_ops) ? ops[lane] : 0;		// the first 64 operations live in lanes
 
 			// Upper bounds: every run of total length m + n yields at most m + n operations.
 			uint32_t indel_total = 0, n_indel_ops = 0;
 			for (uint32_t x = lane; x < n_ops; x += 64)
 			{
-				uint32_t const c = ops[x];
+				uint32_t const c = (x < 64) ? opv : ops[x];
 				uint32_t const op = c & 0xf;
 				if (OP_I == op || OP_D == op) { indel_total += c >> 4; ++n_indel_ops; }
 			}
@@ -334,14 +368,14 @@ __global__ __launch_bounds__(64) void k_realign(
 						runs[n_runs] = rr;
 					}
 					++n_runs;
-					if (!D.text || (uint64_t) run_ref_loc + m > D.text_len) { status = PVC3_ST_REF_RANGE; break; }
+					if (!d_text || (uint64_t) run_ref_loc + m > d_text_len) { status = PVC3_ST_REF_RANGE; break; }
 					if ((uint64_t) run_query_loc + nq > l_seq) { status = PVC3_ST_QUERY_RANGE; break; }
 
 					uint64_t const need = dp_bytes(m, nq);
 					if (need <= lds_budget)
 					{
 						// Separate call site: after inlining every access is provably to LDS (ds_read / ds_write instead of flat_*).
-						align_global(D.text + run_ref_loc, m, seq4, run_query_loc, nq, qual, prm, dp_carve(lds, m, nq), out, lane);
+						align_global(d_text + run_ref_loc, m, seq4, run_query_loc, nq, qual, sc, dp_carve(lds, m, nq), out, lane);
 					}
 					else
 					{
@@ -352,7 +386,7 @@ __global__ __launch_bounds__(64) void k_realign(
 							status = 0xff;	// not a record status: the host grows the scratch and repeats
 							break;
 						}
-						align_global(D.text + run_ref_loc, m, seq4, run_query_loc, nq, qual, prm, dp_carve(W.scratch + (uint64_t) wave * W.scratch_per_wave, m, nq), out, lane);
+						align_global(d_text + run_ref_loc, m, seq4, run_query_loc, nq, qual, sc, dp_carve(W.scratch + (uint64_t) wave * W.scratch_per_wave, m, nq), out, lane);
 					}
 				}
 				else if (prev_type)

@@ -23,7 +23,7 @@ BIN = os.path.join(ROOT, "bin")
 def tools():
 	from panvc3_amd import build
 	build.build_host()
-	return {n: os.path.join(BIN, n) for n in ("panvc3_index_msa", "panvc3_project_alignments")}
+	return {n: os.path.join(BIN, n) for n in ("panvc3_index_msa", "panvc3_project_alignments", "panvc3_convert_bed_positions")}
 
 
 def _run(cmd, cwd=None, check=True):
@@ -249,3 +249,34 @@ def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_m
 	for g in got[:50]:
 		span = sum(n for n, op in bamio.parse_cigar(g["cigar"]) if op in "MDN=X")
 		assert g["bin"] == bamio.reg2bin(g["pos"], g["pos"] + (span or 1))
+
+
+@pytest.mark.gpu
+def test_convert_bed_positions_cli(tools, built_index, oracle_mod):
+	"""convert-bed-positions/main.cc:60-106: both bounds of every interval of the chosen chromosome through project_position."""
+	tmp_path, _ = built_index
+	rows = load_test_msa()
+	o = oracle_mod.Oracle()
+	ent = {k: o.add_aligned(rows[k]) for k in ("REF", "1", "2", "3", "4")}
+	rng = np.random.default_rng(3)
+	n1 = o.zeros(ent["1"])
+	lines, expect = ["# a comment", "track name=x", ""], []
+	for i in range(3000):
+		a = int(rng.integers(0, n1 - 1)); b = int(rng.integers(a, n1))
+		if i % 10 == 3:
+			lines.append("other\t%d\t%d\tname" % (a, b))
+			continue
+		lines.append("test\t%d\t%d" % (a, b) + ("\tname%d\t0\t+" % i if i % 3 == 0 else ""))
+		expect.append("test\t%d\t%d" % (o.project_position(ent["1"], ent["REF"], a), o.project_position(ent["1"], ent["REF"], b)))
+	(tmp_path / "in.bed").write_text("\n".join(lines) + "\n")
+	p = _run([tools["panvc3_convert_bed_positions"], "--msa-index=msa-index.dat", "--chr=test", "--src-seq=1", "--dst-seq=REF", "--bed=in.bed"], cwd=tmp_path)
+	assert p.stdout.decode().split("\n")[:-1] == expect
+	assert b"Chromosome ID matches: %d mismatches: 300." % len(expect) in p.stderr
+	# stdin, the other direction, and the error paths
+	q = subprocess.run([tools["panvc3_convert_bed_positions"], "-m", "msa-index.dat", "-c", "test", "-s", "REF", "-d", "3"], cwd=tmp_path, input=b"test\t5\t100\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+	assert q.returncode == 0 and q.stdout.decode() == "test\t%d\t%d\n" % (o.project_position(ent["REF"], ent["3"], 5), o.project_position(ent["REF"], ent["3"], 100))
+	bad = _run([tools["panvc3_convert_bed_positions"], "-m", "msa-index.dat", "-c", "test", "-s", "nosuch", "-d", "3", "-b", "in.bed"], cwd=tmp_path, check=False)
+	assert bad.returncode != 0 and "Did not find an entry for sequence ID".encode() in bad.stderr
+	(tmp_path / "bad.bed").write_text("test\t5\n")
+	bad = _run([tools["panvc3_convert_bed_positions"], "-m", "msa-index.dat", "-c", "test", "-s", "1", "-d", "3", "-b", "bad.bed"], cwd=tmp_path, check=False)
+	assert bad.returncode != 0 and b"Parse error in BED input on line 1." in bad.stderr

@@ -34,6 +34,7 @@ def main():
 	ap.add_argument("--scale", type=float, default=1.0, help="shrink genome and read count together (smoke runs only)")
 	ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="target CPU time of the oracle sample; 0 disables")
 	ap.add_argument("--score-mode", type=int, default=0)
+	ap.add_argument("--skip-host-buffers", action="store_true", help="leave out the PCIe-inclusive leg (its smaller launches would enter rocprofv3's per-kernel averages)")
 	ap.add_argument("--sorted", action="store_true", help="sort the records by (source entry, position) like a coordinate-sorted BAM (secondary data point; the default is the unsorted worst case)")
 	args = ap.parse_args()
 
@@ -154,7 +155,7 @@ def main():
 		}
 
 		# ---- host-buffer entry point (PCIe-inclusive; never `value`): upload + kernels + download of a slice, no overlap ----
-		if world == 1:
+		if world == 1 and not args.skip_host_buffers:
 			k = int(min(n_local, 4_000_000))
 			sb = synth.slice_batch(batch, 0, k)
 			panvc3_amd.project_batch(ctx, synth.slice_batch(batch, 0, min(k, 100_000)))		# first-use allocations

@@ -5,7 +5,7 @@ set -e
 out=$1; shift
 ctrs=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 240 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/$out -- python3 bench.py --steps 2 --warmup 1 --cpu-baseline-seconds 0 "$@" > gpurun_out/$out.json 2> gpurun_out/$out.err
+timeout -k 10 240 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/$out -- python3 bench.py --steps 2 --warmup 1 --cpu-baseline-seconds 0 --skip-host-buffers "$@" > gpurun_out/$out.json 2> gpurun_out/$out.err
 python3 - "$out" <<'PY'
 import csv, glob, collections, re, sys
 f = glob.glob("gpurun_out/%s/**/*_counter_collection.csv" % sys.argv[1], recursive=True)[0]

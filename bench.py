@@ -60,7 +60,13 @@ def main():
 	from panvc3_amd.shard import reduce_job
 	from tests.synth import synth
 
-	pvc3_build.build()
+	# One rank per node builds (normally a no-op: the build is keyed by content), the others wait: several ranks must not
+	# write the same shared objects at once.
+	if 0 == local_rank:
+		pvc3_build.build()
+		synth.build()
+	if world > 1:
+		dist.barrier()
 	cores = os.cpu_count() or 1
 	threads = max(1, cores // max(1, world))
 
@@ -88,6 +94,11 @@ def main():
 	index_bytes, _ = ctx.hbm_bytes()
 	log("index %.2f GB in HBM; batch uploaded in %.1f s" % (index_bytes / 1e9, time.time() - t2))
 	params = panvc3_amd.api.make_params(0, -1, args.score_mode)
+	if world > 1:
+		# The host copies are only needed by the single-GPU legs (CPU baseline, host-buffer entry point): with one rank per
+		# GPU on one node they would add up to > 20 GB of host memory per rank.
+		batch = None
+		del reads, genome, index
 
 	def barrier():
 		if world > 1:

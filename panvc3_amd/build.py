@@ -3,6 +3,7 @@
 hipcc cross-compiles gfx950 without a GPU.  The shared object lands next to this file so that it travels to the GPU
 box with the repository snapshot.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -22,11 +23,26 @@ def hipcc():
 	raise RuntimeError("hipcc not found")
 
 
-def _newer(target, deps):
-	if not os.path.exists(target):
-		return True
-	t = os.path.getmtime(target)
-	return any(os.path.getmtime(d) > t for d in deps)
+def _key(deps, cmd):
+	"""Content key of a build step: the bytes of everything it reads and the command line.  (File times are useless here:
+	the snapshot that carries the tree to a GPU box does not keep them, and a rebuild by several ranks at once would race.)"""
+	h = hashlib.sha256()
+	for d in sorted(os.path.abspath(x) for x in deps):
+		h.update(os.path.basename(d).encode())
+		with open(d, "rb") as f:
+			h.update(f.read())
+	h.update("\0".join(cmd).encode())
+	return h.hexdigest()
+
+
+def _stale(target, key):
+	kp = target + ".key"
+	return not (os.path.exists(target) and os.path.exists(kp) and open(kp).read() == key)
+
+
+def _done(target, key):
+	with open(target + ".key", "w") as f:
+		f.write(key)
 
 
 def build(force=False, verbose=False):
@@ -42,16 +58,22 @@ def build(force=False, verbose=False):
 		sp = os.path.join(CSRC, src)
 		op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
 		objs.append(op)
-		if force or _newer(op, [sp] + headers):
-			cmd = [hipcc()] + flags + ["-c", sp, "-o", op]
+		cmd = [hipcc()] + flags + ["-c", sp, "-o", op]
+		key = _key([sp] + headers, cmd[1:])
+		if force or _stale(op, key):
 			if verbose:
 				print(" ".join(cmd), file=sys.stderr)
 			subprocess.check_call(cmd)
-	if force or _newer(LIB, objs):
-		cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+			_done(op, key)
+	cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+	key = _key([o + ".key" for o in objs], cmd[1:])
+	lib_key = os.path.join(OBJ, "libpvc3_hip.so")
+	if force or not os.path.exists(LIB) or _stale(lib_key if os.path.exists(lib_key) else LIB, key):
 		if verbose:
 			print(" ".join(cmd), file=sys.stderr)
 		subprocess.check_call(cmd)
+		open(lib_key, "w").close()		# marker whose .key holds the link key (keeps the key file out of the package directory)
+		_done(lib_key, key)
 	return LIB
 
 
@@ -75,11 +97,13 @@ def build_host(force=False, verbose=False):
 		src = os.path.join(HOST, name.replace("panvc3_", "") + "_main.cpp")
 		dst = os.path.join(BIN, name)
 		out.append(dst)
-		if force or _newer(dst, [src, LIB] + headers):
-			cmd = [cxx] + flags + ["-o", dst, src] + extra
+		cmd = [cxx] + flags + ["-o", dst, src] + extra
+		key = _key([src, os.path.join(OBJ, "libpvc3_hip.so.key")] + headers, cmd[1:])
+		if force or _stale(dst, key):
 			if verbose:
 				print(" ".join(cmd), file=sys.stderr)
 			subprocess.check_call(cmd)
+			_done(dst, key)
 	return out
 
 

@@ -4,11 +4,13 @@
 //   --build-index --sequence-inputs=inputs.tsv [--pipe-input='bzip2 -d -c'] --msa-index-output=index.dat [--output-fasta
 //   [--fasta-line-width=N]]      (test-workflow/Snakefile:36, bowtie2-workflow/Snakefile:96-101)
 //   --build-index --sequences=msa.a2m ...      --list-contents --msa-index-input=index.dat
+//   --query --msa-index-input=index.dat --chr-id=chr      (interactive project_position queries, index-msa/main.cc:88-186)
 // One gap bit-vector per (chromosome, sequence): bit i set iff byte i of the aligned sequence is '-' (every input byte is a
 // column, index-msa/index_vector_builder.cc:29-52); with --output-fasta the non-gap bytes go to stdout as ">chr/seq".
 // The index file format is this implementation's own (msa_index_file.hpp).
 #include <getopt.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -79,6 +81,100 @@ msa_chr_entry &chr_entry_for(msa_index_file &idx, std::string const &chr_id)
 
 }
 
+// Host-side rank0 / select0 over the plain gap words of one index entry (the --query mode needs a handful of look-ups, no GPU).
+struct entry_rank_select
+{
+	msa_sequence_entry const *e{};
+	std::vector <uint64_t> zeros_before;		// per 64-column word
+
+	explicit entry_rank_select(msa_sequence_entry const &entry): e(&entry)
+	{
+		std::size_t const n_words = (entry.n_cols + 63) / 64;
+		zeros_before.resize(n_words + 1, 0);
+		for (std::size_t w = 0; w < n_words; ++w)
+			zeros_before[w + 1] = zeros_before[w] + (uint64_t) __builtin_popcountll(~word(w));
+	}
+
+	uint64_t word(std::size_t w) const		// columns past the end count as gaps
+	{
+		uint64_t v = e->gap_words[w];
+		if (w == e->n_cols / 64 && (e->n_cols & 63)) v |= ~UINT64_C(0) << (e->n_cols & 63);
+		return v;
+	}
+
+	uint64_t n_zeros() const { return zeros_before.back(); }
+
+	uint64_t rank0(uint64_t col) const		// non-gap columns before col
+	{
+		std::size_t const w = col / 64;
+		if (w >= zeros_before.size() - 1) return n_zeros();
+		return zeros_before[w] + (uint64_t) __builtin_popcountll(~word(w) & ((UINT64_C(1) << (col & 63)) - 1));
+	}
+
+	uint64_t select0(uint64_t k) const		// column of the k-th (0-based) non-gap character; k < n_zeros()
+	{
+		std::size_t const w = (std::size_t) (std::upper_bound(zeros_before.begin(), zeros_before.end(), k) - zeros_before.begin()) - 1;
+		uint64_t z = ~word(w);
+		for (uint64_t skip = k - zeros_before[w]; skip; --skip) z &= z - 1;
+		return 64 * (uint64_t) w + (uint64_t) __builtin_ctzll(z);
+	}
+};
+
+// The interactive query mode (index-msa/main.cc:88-186): project_position of typed co-ordinates between two sequences of
+// one chromosome; 's' / 'd' switch the source / destination sequence; ends with the input.
+int query_index(char const *path, char const *chr_id)
+{
+	msa_index_file idx;
+	idx.load(path);
+	msa_chr_entry const *ce = idx.find_chr(chr_id);
+	if (!ce)
+	{
+		std::cerr << "ERROR: No entry for chromosome '" << chr_id << "'.\n";
+		return EXIT_FAILURE;
+	}
+	std::string buffer;
+	auto read_seq = [&](char const *msg) -> msa_sequence_entry const * {
+		for (;;)
+		{
+			std::cout << msg << std::flush;
+			if (!(std::cin >> buffer)) return nullptr;
+			msa_sequence_entry const *se = msa_index_file::find_seq(*ce, buffer);
+			if (se) return se;
+			std::cerr << "No entry for sequence '" << buffer << "'.\n";
+		}
+	};
+	msa_sequence_entry const *src = read_seq("Source sequence identifier? ");
+	if (!src) return 0;
+	msa_sequence_entry const *dst = read_seq("Destination sequence identifier? ");
+	if (!dst) return 0;
+	entry_rank_select rs_src(*src), rs_dst(*dst);
+	for (;;)
+	{
+		std::cout << "[" << src->seq_id << " → " << dst->seq_id << "] Source co-ordinate or 's' or 'd' to switch sequence? ([0, " << rs_src.n_zeros() << ")) " << std::flush;
+		if (!(std::cin >> buffer)) return 0;
+		if ("s" == buffer)
+		{
+			src = read_seq("Source sequence identifier? ");
+			if (!src) return 0;
+			rs_src = entry_rank_select(*src);
+		}
+		else if ("d" == buffer)
+		{
+			dst = read_seq("Destination sequence identifier? ");
+			if (!dst) return 0;
+			rs_dst = entry_rank_select(*dst);
+		}
+		else
+		{
+			char *end{};
+			unsigned long long const pos = std::strtoull(buffer.c_str(), &end, 10);
+			if (buffer.empty() || end != buffer.c_str() + buffer.size() || !(buffer[0] >= '0' && buffer[0] <= '9')) continue;		// :178-180
+			if (!(pos < rs_src.n_zeros())) continue;																		// :182-183
+			std::cout << rs_dst.rank0(rs_src.select0(pos)) << '\n';		// msa_index.hh:253-258
+		}
+	}
+}
+
 // (split helper without pulling in sam_bam.hpp)
 static std::vector <std::string> split_tabs(std::string const &s)
 {
@@ -96,7 +192,7 @@ static std::vector <std::string> split_tabs(std::string const &s)
 
 int main(int argc, char **argv)
 {
-	char const *msa_index_input{}, *sequence_inputs{}, *a2m_input{}, *msa_index_output{}, *pipe_input{};
+	char const *msa_index_input{}, *sequence_inputs{}, *a2m_input{}, *msa_index_output{}, *pipe_input{}, *chr_id{};
 	bool build_index = false, list_contents = false, query = false, output_fasta = false;
 	long fasta_line_width = 0;
 	static option const opts[] = {
@@ -121,7 +217,7 @@ int main(int argc, char **argv)
 			case 'w': fasta_line_width = std::atol(optarg); break;
 			case 'L': list_contents = true; break;
 			case 'Q': query = true; break;
-			case 1000: break;
+			case 1000: chr_id = optarg; break;
 			case 'V': std::cout << "index-msa 0.1 (panvc3-mi355x)\n"; return 0;
 			case 'h':
 				std::cout << "Usage: panvc3_index_msa --build-index --sequence-inputs=inputs.tsv [--pipe-input=cmd] --msa-index-output=msa-index.dat [--output-fasta [--fasta-line-width=N]] > combined.fa\n"
@@ -151,7 +247,11 @@ int main(int argc, char **argv)
 			}
 			return 0;
 		}
-		if (query) die("--query (interactive index queries) is not implemented in this build");
+		if (query)
+		{
+			if (!msa_index_input || !chr_id) die("--query needs --msa-index-input and --chr-id");
+			return query_index(msa_index_input, chr_id);
+		}
 		if (!build_index) die("one of --build-index, --list-contents is required");
 		if (!msa_index_output) die("--msa-index-output is required");
 		if (!sequence_inputs && !a2m_input) die("--sequence-inputs or --sequences is required");

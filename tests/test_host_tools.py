@@ -95,6 +95,26 @@ def test_index_msa_on_shipped_msa(tools, built_index):
 		assert lines[0] == ">test/REF" and all(len(x) == 60 for x in lines[1:167]) and len(lines[167]) == 10000 - 166 * 60
 
 
+def test_index_msa_query_mode(tools, built_index, oracle_mod):
+	"""index-msa/main.cc:88-186: interactive project_position queries, 's' / 'd' switch the sequences."""
+	tmp_path, _ = built_index
+	rows = load_test_msa()
+	o = oracle_mod.Oracle()
+	ent = {k: o.add_aligned(rows[k]) for k in ("REF", "1", "2", "3", "4")}
+	n1, n3 = o.zeros(ent["1"]), o.zeros(ent["3"])
+	script = "nosuch\n1\nREF\n0\n17\nabc\n%d\n%d\nd\n2\n100\ns\n3\n%d\n" % (n1 - 1, n1, n3 - 1)
+	p = subprocess.run([tools["panvc3_index_msa"], "--query", "--msa-index-input=msa-index.dat", "--chr-id=test"], cwd=tmp_path, input=script.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+	assert p.returncode == 0 and b"No entry for sequence 'nosuch'." in p.stderr
+	out = p.stdout.decode()
+	numbers = [int(x) for x in __import__("re").findall(r"\)\) (\d+)\n", out)]
+	pp = o.project_position
+	assert numbers == [pp(ent["1"], ent["REF"], 0), pp(ent["1"], ent["REF"], 17), pp(ent["1"], ent["REF"], n1 - 1), pp(ent["1"], ent["2"], 100), pp(ent["3"], ent["2"], n3 - 1)]
+	assert "Source sequence identifier? " in out and "Destination sequence identifier? " in out
+	assert "[1 \u2192 REF] Source co-ordinate or 's' or 'd' to switch sequence? ([0, %d)) " % n1 in out and "[3 \u2192 2] " in out
+	bad = _run([tools["panvc3_index_msa"], "--query", "--msa-index-input=msa-index.dat", "--chr-id=other"], cwd=tmp_path, check=False)
+	assert bad.returncode != 0 and b"ERROR: No entry for chromosome 'other'." in bad.stderr
+
+
 def test_index_msa_a2m_and_errors(tools, tmp_path):
 	(tmp_path / "in.a2m").write_text(">chrB s2\nAC-GT\nAC\n>chrA\tREF\nACGT--A\n>chrB REF\nA--GTAC\n")
 	_run([tools["panvc3_index_msa"], "--build-index", "--sequences=in.a2m", "--msa-index-output=o.dat"], cwd=tmp_path)

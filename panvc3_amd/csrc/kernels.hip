@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void k_project_positions(
 constexpr uint32_t SCAN_THREADS = 256;
 constexpr uint32_t SCAN_ITEMS = 8;
 constexpr uint32_t SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr uint32_t GATHER_STAGE = 4096;		// uint32 of LDS staging in k_offsets_gather (16 operations per record on average)
 
 __device__ __forceinline__ uint64_t block_reduce_add(uint64_t v, uint64_t *lds)
 {
@@ -130,6 +131,7 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *l
 __global__ __launch_bounds__(SCAN_THREADS) void k_offsets_gather(uint64_t n, dev_batch_work const W, dev_batch_packed const P, uint64_t const *__restrict__ tile_sums, uint64_t const *__restrict__ totals)
 {
 	__shared__ uint64_t lds[8];
+	__shared__ uint32_t stage[GATHER_STAGE];		// the operations of 256 records, in output order
 	uint64_t const base = (uint64_t) blockIdx.x * SCAN_TILE;
 	uint64_t carry_a = tile_sums[2 * (uint64_t) blockIdx.x], carry_b = tile_sums[2 * (uint64_t) blockIdx.x + 1];
 	for (uint32_t i = 0; i < SCAN_ITEMS; ++i)
@@ -140,17 +142,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_offsets_gather(uint64_t n, dev
 		uint64_t const loc = valid ? W.cig_loc[rec] : 0;
 		uint32_t const fl = valid ? W.rec_flags[rec] : 0;
 		uint64_t total_a, total_b;
-		uint64_t const off_a = carry_a + block_exclusive_scan(nc, lds, total_a);
+		uint64_t const local_a = block_exclusive_scan(nc, lds, total_a);
+		uint64_t const off_a = carry_a + local_a;
 		uint64_t const off_b = carry_b + block_exclusive_scan(nr, lds, total_b);
-		carry_a += total_a; carry_b += total_b;
+		// The operations of these 256 records form one contiguous piece of the output: every thread drops its own few into
+		// LDS, then the block writes the piece with coalesced stores (pieces that do not fit are written directly).
+		bool const staged = total_a <= GATHER_STAGE;
 		if (valid)
 		{
 			P.out_cigar_off[rec] = off_a;
 			P.run_off[rec] = off_b;
 			P.status[rec] = (int32_t) (fl & REC_STATUS_MASK);
 			uint32_t const *src = W.arena + loc;
-			uint32_t *dst = P.out_cigar + off_a;
-			for (uint32_t k = 0; k < nc; ++k) dst[k] = src[k];
+			if (staged)
+				for (uint32_t k = 0; k < nc; ++k) stage[local_a + k] = src[k];
+			else
+			{
+				uint32_t *dst = P.out_cigar + off_a;
+				for (uint32_t k = 0; k < nc; ++k) dst[k] = src[k];
+			}
 			if (nr)
 			{
 				pvc3_run const *rs = W.runs_arena + W.run_loc[rec];
@@ -158,6 +168,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_offsets_gather(uint64_t n, dev
 				for (uint32_t k = 0; k < nr; ++k) rd[k] = rs[k];
 			}
 		}
+		if (staged)
+		{
+			__syncthreads();
+			for (uint32_t j = threadIdx.x; j < (uint32_t) total_a; j += SCAN_THREADS)
+				P.out_cigar[carry_a + j] = stage[j];
+			__syncthreads();
+		}
+		carry_a += total_a; carry_b += total_b;
 	}
 	if (0 == blockIdx.x && 0 == threadIdx.x) { P.out_cigar_off[n] = totals[0]; P.run_off[n] = totals[1]; }
 }

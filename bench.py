@@ -34,6 +34,7 @@ def main():
 	ap.add_argument("--scale", type=float, default=1.0, help="shrink genome and read count together (smoke runs only)")
 	ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="target CPU time of the oracle sample; 0 disables")
 	ap.add_argument("--score-mode", type=int, default=0)
+	ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="pvc3_context_set_option (tuning experiments), e.g. realign_waves=5120")
 	ap.add_argument("--skip-host-buffers", action="store_true", help="leave out the PCIe-inclusive leg (its smaller launches would enter rocprofv3's per-kernel averages)")
 	ap.add_argument("--sorted", action="store_true", help="sort the records by (source entry, position) like a coordinate-sorted BAM (secondary data point; the default is the unsorted worst case)")
 	args = ap.parse_args()
@@ -89,6 +90,9 @@ def main():
 	ctx = panvc3_amd.Context(local_rank)
 	ctx.upload_index(index)
 	ctx.set_timing(True)
+	for kv in args.option:
+		k, v = kv.split("=", 1)
+		ctx.set_option(k, int(v))
 	t2 = time.time()
 	db = panvc3_amd.DeviceBatch(ctx, batch)
 	index_bytes, _ = ctx.hbm_bytes()

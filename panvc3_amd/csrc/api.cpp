@@ -52,7 +52,7 @@ struct pvc3_context
 	pvc3_params params{0, 0, -1, 0};
 
 	// Options.
-	uint32_t realign_waves{4096};		// one 64-thread block each; 8 KB of LDS per block => up to 20 per CU
+	uint32_t realign_waves{8192};		// one 64-thread block each, 64 VGPRs and 4.7 KB of LDS per block => all 32 wave slots of a CU
 	uint32_t realign_lds_bytes{};
 	uint64_t scratch_per_wave{128 * 1024};
 	uint64_t arena_initial{};

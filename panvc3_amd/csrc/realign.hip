@@ -18,7 +18,7 @@ namespace pvc3 {
 
 namespace {
 
-constexpr uint32_t REALIGN_LDS_BYTES = 8192;		// per wave (= per block); larger alignments use the wave's global scratch slot
+constexpr uint32_t REALIGN_LDS_BYTES = 4096;		// per wave (= per block); larger alignments (beyond about 55 x 55) use the wave's global scratch slot
 constexpr uint32_t TR_DIAG = 0, TR_UP = 1, TR_LEFT = 2, TR_DIR_MASK = 3, TR_V_OPEN = 4, TR_H_OPEN = 8, TR_MATCH = 16;
 constexpr uint32_t MAX_PHRED = 41;
 
@@ -235,7 +235,10 @@ __device__ __forceinline__ void align_global(
 		out.push(rfl(mem.rev[x - 1]), 1, lane);		// align.hh:94-108 through cigar_buffer
 }
 
-__global__ __launch_bounds__(64) void k_realign(
+// One record at a time per wave is bound by the latency of that record's dependent steps, so the kernel wants as many
+// resident waves as the CU has slots: 64 VGPRs (a few spills) and 4 KB of LDS give 8 per SIMD; on C5 that is 17.6 ms
+// against 22.5 ms with 86 VGPRs / 8 KB / 5 waves per SIMD.
+__global__ __launch_bounds__(64, 8) void k_realign(
 	dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W,
 	dev_params const *__restrict__ prm, uint32_t lds_budget
 )
@@ -259,12 +262,15 @@ __global__ __launch_bounds__(64) void k_realign(
 	// Contiguous range of 64-record stripes per wave; the flags of the next stripe are loaded while this one is processed.
 	uint64_t const n_stripes = (in.n + 63) / 64;
 	uint64_t const s_begin = n_stripes * wave / n_waves, s_end = n_stripes * (wave + 1) / n_waves;
-	uint32_t fl_next = (s_begin < s_end && s_begin * 64 + lane < in.n) ? W.rec_flags[s_begin * 64 + lane] : 0;
+	// Four stripes of flags are kept in flight: most stripes have no flagged record, so the scan advances at the rate of the
+	// loads, not of their latency.
+	auto load_flags = [&](uint64_t stripe) -> uint32_t { return (stripe < s_end && stripe * 64 + lane < in.n) ? W.rec_flags[stripe * 64 + lane] : 0; };
+	uint32_t fl0 = load_flags(s_begin), fl1 = load_flags(s_begin + 1), fl2 = load_flags(s_begin + 2), fl3 = load_flags(s_begin + 3);
 	for (uint64_t stripe = s_begin; stripe < s_end; ++stripe)
 	{
 		uint64_t const base = stripe * 64;
-		uint32_t const fl = fl_next;
-		fl_next = (stripe + 1 < s_end && base + 64 + lane < in.n) ? W.rec_flags[base + 64 + lane] : 0;
+		uint32_t const fl = fl0;
+		fl0 = fl1; fl1 = fl2; fl2 = fl3; fl3 = load_flags(stripe + 4);
 		bool const mine = 0 != (fl & REC_HAS_RUN);
 		uint64_t todo = ballot(mine);
 		if (!todo)

@@ -47,6 +47,21 @@ def test_scaled_configs(pvc3, oracle_mod, synth, name, scale):
 		assert np.array_equal(got["mate_dst_pos"][0::2][:b.size], b) and np.array_equal(got["mate_dst_pos"][1::2], a[:b.size])
 
 
+@pytest.mark.parametrize("name,scale", [("C2", 0.03), ("C3", 0.002), ("C5", 0.002)])
+def test_other_seeds_n_bases_and_soft_masking(pvc3, oracle_mod, synth, name, scale):
+	"""Fresh genomes and reads (seeds other than the configuration's own), some with N in the reads and lower-case stretches
+	in the reference: every output array against the oracle."""
+	for seed in (101, 102, 103):
+		gp, rp, _ = synth.config(name, scale=scale, seed=seed)
+		rp.n_base_rate = 0.01 if seed % 2 else 0.0
+		gp.lowercase_every = 7 if 0 == seed % 3 else 0
+		genome = synth.Genome(gp)
+		reads = synth.Reads(genome, rp)
+		got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, reads.batch())
+		assert stats["n_failed"] == 0
+		ctx.close()
+
+
 def test_device_checksum_matches_host_restatement(pvc3, oracle_mod, synth):
 	"""pvc3_dbatch_checksum (used for the additive multi-GPU / full-size checks) against its host restatement."""
 	from test_shard_gloo import _checksum

@@ -178,6 +178,15 @@ def main():
 			panvc3_amd.project_batch(ctx, sb)
 			dt = time.perf_counter() - tb
 			result["host_buffers"] = {"value": k / dt, "unit": "alignments/s", "records": k, "what": "pvc3_batch_project: pageable host arrays in, host arrays out (H2D + kernels + D2H, no overlap between batches)"}
+			# the same with the arrays in page-locked memory (pvc3_host_alloc), as a caller that fills them directly would have them
+			pb, owners = panvc3_amd.pinned_batch(sb)
+			res0, _ = panvc3_amd.project_batch(ctx, pb, pinned_out=True)		# the output arrays are reused below
+			owner0 = res0.pop("_owner")
+			tb = time.perf_counter()
+			panvc3_amd.project_batch(ctx, pb, out=res0)
+			dt = time.perf_counter() - tb
+			result["host_buffers"]["pinned"] = {"value": k / dt, "unit": "alignments/s", "what": "the same batch from and to page-locked arrays"}
+			del pb, owners, res0, owner0
 
 		# ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample, same box, rank 0 only ----
 		if world == 1 and args.cpu_baseline_seconds > 0:

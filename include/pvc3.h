@@ -205,6 +205,11 @@ PVC3_API int pvc3_dbatch_download(pvc3_context *ctx, pvc3_dbatch *batch, pvc3_ba
  * dst_pos, mate_dst_pos, status, CIGAR, runs).  Additive, so the checksums of shards add up to that of the whole. */
 PVC3_API int pvc3_dbatch_checksum(pvc3_context *ctx, pvc3_dbatch *batch, uint64_t first_record, uint64_t *checksum);
 
+/* Page-locked host memory for the batch arrays (hipHostMalloc): with pageable arrays the copies of pvc3_dbatch_create /
+ * pvc3_dbatch_download run at about a third of the PCIe rate.  Any thread; free with pvc3_host_free. */
+PVC3_API int pvc3_host_alloc(uint64_t bytes, void **ptr);
+PVC3_API void pvc3_host_free(void *ptr);
+
 /* project_position for n independent positions: out[i] = rank0_dst(select0_src(1 + pos[i])); PVC3_NO_MATE if out of range. */
 PVC3_API int pvc3_project_positions(pvc3_context *ctx, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out);
 

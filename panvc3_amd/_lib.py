@@ -95,6 +95,8 @@ def lib():
 		"pvc3_dbatch_download": ([vp, vp, P(BatchOut)], i32),
 		"pvc3_dbatch_checksum": ([vp, vp, u64, P(u64)], i32),
 		"pvc3_project_positions": ([vp, u64, vp, vp, vp, vp], i32),
+		"pvc3_host_alloc": ([u64, P(vp)], i32),
+		"pvc3_host_free": ([vp], None),
 	}
 	for name, (argtypes, restype) in sig.items():
 		f = getattr(L, name)

@@ -225,22 +225,33 @@ class DeviceBatch:
 		self.stats = _stats_dict(st)
 		return self.stats
 
-	def download(self):
+	def download(self, pinned=False, out=None):
+		"""Copies the packed results to host arrays: fresh ones, fresh page-locked ones, or the arrays of `out` (a previous
+		result of the same sizes, e.g. page-locked arrays that are reused from batch to batch)."""
 		n = self.n
-		res = dict(
-			dst_pos=np.zeros(n, dtype=np.uint32), mate_dst_pos=np.zeros(n, dtype=np.uint32), status=np.zeros(n, dtype=np.int32),
-			out_cigar_off=np.zeros(n + 1, dtype=np.uint64), run_off=np.zeros(n + 1, dtype=np.uint64),
-		)
 		ccap = int(self.stats["out_cigar_total"])
 		rcap = int(self.stats["n_runs"])
-		res["out_cigar"] = np.zeros(max(1, ccap), dtype=np.uint32)
-		res["runs"] = np.zeros(max(1, rcap), dtype=RUN_DTYPE)
+		shapes = dict(dst_pos=(n, np.uint32), mate_dst_pos=(n, np.uint32), status=(n, np.int32), out_cigar_off=(n + 1, np.uint64), run_off=(n + 1, np.uint64),
+					  out_cigar=(max(1, ccap), np.uint32), runs=(max(1, rcap), RUN_DTYPE))
+		if out is not None:
+			res = {k: out[k] for k in shapes}
+			for k, (cnt, dt) in shapes.items():
+				if res[k].size < cnt or res[k].dtype != np.dtype(dt):
+					raise ValueError("download: array %s of `out` is too small" % k)
+		elif pinned:
+			self._pinned_out = [PinnedArray((cnt,), dt) for cnt, dt in shapes.values()]
+			res = {k: pa.array for k, pa in zip(shapes, self._pinned_out)}
+		else:
+			res = {k: np.zeros(cnt, dtype=dt) for k, (cnt, dt) in shapes.items()}
 		bo = BatchOut()
 		for k in ("dst_pos", "mate_dst_pos", "status", "out_cigar_off", "out_cigar", "run_off", "runs"):
 			setattr(bo, k, res[k].ctypes.data)
 		bo.out_cigar_cap = res["out_cigar"].size
 		bo.run_cap = res["runs"].size
 		check(self._L.pvc3_dbatch_download(self.ctx._h, self._h, C.byref(bo)))
+		res = dict(res)
+		for k, (cnt, dt) in shapes.items():
+			res[k] = res[k][:cnt]
 		res["out_cigar"] = res["out_cigar"][:ccap]
 		res["runs"] = res["runs"][:rcap]
 		return res
@@ -251,17 +262,56 @@ class DeviceBatch:
 		return v.value
 
 
+class PinnedArray:
+	"""A numpy array in page-locked host memory (pvc3_host_alloc): `.array`; freed by close() or on collection."""
+
+	def __init__(self, shape, dtype):
+		self._L = _lib.lib()
+		dt = np.dtype(dtype)
+		n = int(np.prod(shape))
+		self._p = C.c_void_p()
+		check(self._L.pvc3_host_alloc(max(1, n * dt.itemsize), C.byref(self._p)))
+		buf = (C.c_uint8 * max(1, n * dt.itemsize)).from_address(self._p.value)
+		self.array = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+	def close(self):
+		if getattr(self, "_p", None) and self._p.value:
+			self.array = None
+			self._L.pvc3_host_free(self._p)
+			self._p = C.c_void_p()
+
+	def __del__(self):
+		self.close()
+
+
+def pinned_batch(batch):
+	"""A copy of a batch (dict of arrays) in page-locked memory.  Returns (batch of arrays, owners to keep alive)."""
+	out, owners = {}, []
+	for k, v in batch.items():
+		if not isinstance(v, np.ndarray):
+			continue
+		pa = PinnedArray(v.shape, v.dtype)
+		pa.array[...] = v
+		out[k] = pa.array
+		owners.append(pa)
+	return out, owners
+
+
 def make_params(gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, tiebreak_mode=0):
 	return Params(gap_open, gap_ext, score_mode, tiebreak_mode)
 
 
-def project_batch(ctx, batch, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64):
-	"""Host arrays in, host arrays out through pvc3_dbatch_* (upload, kernels, pack, download).  Returns (results, stats)."""
+def project_batch(ctx, batch, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, pinned_out=False, out=None):
+	"""Host arrays in, host arrays out through pvc3_dbatch_* (upload, kernels, pack, download).  Returns (results, stats).
+	With pinned_out the result arrays live in page-locked memory owned by the returned dict's "_owner"."""
 	db = DeviceBatch(ctx, batch)
 	try:
 		db.project(make_params(gap_open, gap_ext, score_mode))
 		stats = db.finish()
-		return db.download(), stats
+		res = db.download(pinned=pinned_out, out=out)
+		if pinned_out and out is None:
+			res["_owner"] = db._pinned_out
+		return res, stats
 	finally:
 		db.close()
 

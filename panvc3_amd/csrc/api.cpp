@@ -435,6 +435,19 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 	return PVC3_OK;
 }
 
+int pvc3_host_alloc(uint64_t bytes, void **ptr)
+{
+	if (!ptr) return set_error(PVC3_E_INVALID, "pvc3_host_alloc: null argument");
+	*ptr = nullptr;
+	HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+	return PVC3_OK;
+}
+
+void pvc3_host_free(void *ptr)
+{
+	if (ptr) (void) hipHostFree(ptr);
+}
+
 int pvc3_context_hbm_bytes(pvc3_context const *ctx, uint64_t *index_bytes, uint64_t *workspace_bytes)
 {
 	if (!ctx) return set_error(PVC3_E_INVALID, "pvc3_context_hbm_bytes: null context");

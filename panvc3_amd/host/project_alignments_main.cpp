@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -368,11 +369,11 @@ int main(int argc, char **argv)
 		};
 		std::vector <slice_state> slices;
 
-		while (!eof)
-		{
-			// Fill a batch with records that pass the filters; a multiple of the reference's CHUNK_SIZE (4) unless the input ends.
-			batch.clear();
-			while (batch.size() < opt.batch_size || (batch.size() & 3))
+		// Fills a batch with records that pass the filters; a multiple of the reference's CHUNK_SIZE (4) unless the input ends.
+		// Runs on a helper thread while the previous batch is on the GPU / being rewritten / being written.
+		auto read_batch = [&](std::vector <pending_record> &dst) {
+			dst.clear();
+			while (!eof && (dst.size() < opt.batch_size || (dst.size() & 3)))
 			{
 				if (!reader.next(rec)) { eof = true; break; }
 				uint64_t const idx = input_index++;
@@ -381,11 +382,18 @@ int main(int argc, char **argv)
 				if (rec.ref_id() < 0) { ++st.ref_id_missing; continue; }						// :546-551
 				if (rec.pos() < 0) { ++st.flags_not_matched; continue; }						// :553-564
 				if (0 == rec.l_seq()) { ++st.seq_missing; continue; }							// :566-570
-				if ((std::size_t) rec.ref_id() >= src_entries.size()) die("record with a reference id outside the header");
+				if ((std::size_t) rec.ref_id() >= src_entries.size()) throw std::runtime_error("record with a reference id outside the header");
 				++st.matched_reads;
-				batch.push_back({rec, idx});
+				dst.push_back({rec, idx});
 			}
-			if (batch.empty()) break;
+		};
+		std::vector <pending_record> next_batch;
+		read_batch(batch);
+		while (!batch.empty())
+		{
+			std::future <void> prefetch;
+			if (!eof) prefetch = std::async(std::launch::async, [&]() { read_batch(next_batch); });
+			struct join_prefetch { std::future <void> &f; ~join_prefetch() { if (f.valid()) f.wait(); } } joiner{prefetch};
 			uint64_t const n = batch.size();
 
 			// SoA batch (include/pvc3.h).
@@ -584,6 +592,13 @@ int main(int argc, char **argv)
 				realigned_ranges.insert(realigned_ranges.end(), S.ranges.begin(), S.ranges.end());
 				for (auto const &kv : S.removed) removed_tag_counts[kv.first] += kv.second;
 			}
+			if (prefetch.valid())
+			{
+				prefetch.get();		// rethrows what the reader threw
+				batch.swap(next_batch);
+			}
+			else
+				batch.clear();
 		}
 		writer.close();
 		pvc3_context_destroy(ctx);

@@ -310,11 +310,13 @@ def test_project_positions(pvc3, oracle_mod, synth):
 	assert np.array_equal(got, want)
 
 
-def test_c3_full_size_properties(pvc3, oracle_mod, synth):
-	"""BASELINE.json configs[2] at full size (20 M pairs, 8 founders, 1 Gbp): size-independent properties + sampled oracle parity."""
+@pytest.mark.parametrize("name", ["C3", "C5"])
+def test_full_size_properties(pvc3, oracle_mod, synth, name):
+	"""BASELINE.json configs[2] and configs[4] at full size (20 M pairs, 8 founders, 1 Gbp; 2x150 and 2x250 bp with long
+	indels): size-independent properties + sampled oracle parity."""
 	if "default" != pvc3.paths_mode:
 		pytest.skip("full size is run in the product configuration only")
-	gp, rp, desc = synth.config("C3")
+	gp, rp, desc = synth.config(name)
 	genome = synth.Genome(gp)
 	reads = synth.Reads(genome, rp)
 	batch = reads.batch()

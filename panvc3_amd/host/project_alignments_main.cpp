@@ -151,26 +151,9 @@ void process_headers(sam_header const &in, options const &opt, sam_header &out, 
 	out.index_refs();
 }
 
-// append_sam_program_info (include/panvc3/utility.hh:92-143)
 void append_program_info(sam_header const &in, sam_header &out, int argc, char **argv)
 {
-	out.programs = in.programs;
-	std::string const prefix = "panvc3.project-alignments.";
-	uint32_t idx = 0;
-	for (auto const &pg : out.programs)
-		if (0 == pg.id.compare(0, prefix.size(), prefix))
-		{
-			char *end{};
-			unsigned long const v = std::strtoul(pg.id.c_str() + prefix.size(), &end, 10);
-			if (end != pg.id.c_str() + prefix.size()) idx = std::max <uint32_t>(idx, (uint32_t) v);
-		}
-	pg_line pg;
-	pg.id = prefix + std::to_string(idx + 1);
-	pg.name = "PanVC 3 project_alignments";
-	for (int i = 0; i < argc; ++i) { if (i) pg.command_line += ' '; pg.command_line += argv[i]; }
-	pg.version = "0.1-mi355x";
-	if (!out.programs.empty()) pg.previous = out.programs.back().id;
-	out.programs.push_back(std::move(pg));
+	append_sam_program_info(in, out, "panvc3.project-alignments.", "PanVC 3 project_alignments", argc, argv);
 }
 
 struct pending_record

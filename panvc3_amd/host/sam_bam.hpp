@@ -457,6 +457,28 @@ inline void parse_sam_record(std::string const &line, sam_header const &hdr, bam
 }
 
 
+// append_sam_program_info (include/panvc3/utility.hh:92-143): a new @PG line "<prefix><k + 1>" chained to the last program.
+inline void append_sam_program_info(sam_header const &in, sam_header &out, std::string const &prefix, std::string const &name, int argc, char **argv)
+{
+	out.programs = in.programs;
+	uint32_t idx = 0;
+	for (auto const &pg : out.programs)
+		if (0 == pg.id.compare(0, prefix.size(), prefix))
+		{
+			char *end{};
+			unsigned long const v = std::strtoul(pg.id.c_str() + prefix.size(), &end, 10);
+			if (end != pg.id.c_str() + prefix.size()) idx = std::max <uint32_t>(idx, (uint32_t) v);
+		}
+	pg_line pg;
+	pg.id = prefix + std::to_string(idx + 1);
+	pg.name = name;
+	for (int i = 0; i < argc; ++i) { if (i) pg.command_line += ' '; pg.command_line += argv[i]; }
+	pg.version = "0.1-mi355x";
+	if (!out.programs.empty()) pg.previous = out.programs.back().id;
+	out.programs.push_back(std::move(pg));
+}
+
+
 // ---- input: SAM text or BAM -----------------------------------------------------------------------------------------------
 class alignment_reader
 {

@@ -132,6 +132,56 @@ def _edge_index(pvc3, oracle_mod, pairs):
 	return ctx, o, ids
 
 
+def test_abi_call_sequence_capacity_and_empty_batch(pvc3, oracle_mod):
+	"""Error behaviour of the C ABI on a GPU: wrong call order, output buffers that are too small, an empty batch, page-locked
+	arrays in and out.  (Codes: include/pvc3.h.)"""
+	import ctypes as C
+	from panvc3_amd import _lib
+	L = _lib.lib()
+	E_STATE, E_CAPACITY = -6, -5
+	ctx = pvc3.Context(0)
+	bb = BatchBuilder()
+	bb.add(0, 0, 1, "5M", "ACGTA", qual=[30] * 5)
+	batch = bb.build()
+	with pytest.raises(pvc3.Error) as ei:		# no index uploaded yet
+		pvc3.DeviceBatch(ctx, batch)
+	assert ei.value.code == E_STATE
+	idx = pvc3.Index()
+	s = idx.add_aligned("ACGTA-CGT"); d = idx.add_aligned("ACGTAACGT")
+	idx.set_reference(d, "ACGTAACGT")
+	ctx.upload_index(idx)
+	db = pvc3.DeviceBatch(ctx, batch)
+	with pytest.raises(pvc3.Error) as ei:		# finish before project
+		db.finish()
+	assert ei.value.code == E_STATE
+	st = _lib.BatchStats()
+	bo = _lib.BatchOut()
+	assert L.pvc3_dbatch_download(ctx._h, db._h, C.byref(bo)) == E_STATE		# download before finish
+	db.project()
+	stats = db.finish()
+	assert stats["n_records"] == 1 and stats["out_cigar_total"] == 1
+	out = db.download()
+	assert cigar_decode(out["out_cigar"]) == "5="
+	# too little room for the operations: an error, nothing written past the buffers
+	small = dict(dst_pos=np.zeros(1, np.uint32), mate_dst_pos=np.zeros(1, np.uint32), status=np.zeros(1, np.int32), out_cigar_off=np.zeros(2, np.uint64),
+				 run_off=np.zeros(2, np.uint64), out_cigar=np.full(4, 0xdeadbeef, np.uint32), runs=np.zeros(1, pvc3.RUN_DTYPE))
+	for k in ("dst_pos", "mate_dst_pos", "status", "out_cigar_off", "out_cigar", "run_off", "runs"):
+		setattr(bo, k, small[k].ctypes.data)
+	bo.out_cigar_cap = 0; bo.run_cap = 0
+	assert L.pvc3_dbatch_download(ctx._h, db._h, C.byref(bo)) == E_CAPACITY
+	assert (small["out_cigar"] == 0xdeadbeef).all()
+	db.close()
+	# an empty batch is not an error
+	empty = BatchBuilder().build()
+	got, stats = pvc3.project_batch(ctx, empty)
+	assert stats["n_records"] == 0 and got["dst_pos"].size == 0 and got["out_cigar_off"].tolist() == [0]
+	# page-locked arrays in and out give the same bytes
+	pb, owners = pvc3.pinned_batch(batch)
+	got2, _ = pvc3.project_batch(ctx, pb, pinned_out=True)
+	assert cigar_decode(got2["out_cigar"]) == "5=" and got2["dst_pos"].tolist() == out["dst_pos"].tolist()
+	ctx.close()
+
+
 def test_edge_cases_and_statuses(pvc3, oracle_mod):
 	rng = np.random.default_rng(1)
 	src = "GATTACA" * 40

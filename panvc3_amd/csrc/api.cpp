@@ -531,6 +531,8 @@ int pvc3_dbatch_create(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_dbatch *
 	PVC3_TRY(dev_alloc(&w.counters, 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.slow_list, (n + 63) / 64 * 64 + 64, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.slow_count, project_wave_count(n), &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.run_list, (n + 63) / 64 * 64 + 64, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.run_count, project_wave_count(n), &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.wave_stats, 3 * (uint64_t) project_wave_count(n) * WAVE_STATS, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.out_cigar_off, n + 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.run_off, n + 1, &b->allocs, &b->bytes));

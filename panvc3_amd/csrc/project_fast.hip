@@ -389,7 +389,8 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		}
 	}
 
-	W.slow_count[wave] = n_slow;		// wave-uniform store
+	W.slow_count[wave] = n_slow;		// wave-uniform stores
+	W.run_count[wave] = 0;				// k_project_mid / k_project_general append the records with indel runs
 	// Per-lane accumulators -> wave totals -> one atomic each.
 	for (int off = 32; off; off >>= 1)
 	{

@@ -20,6 +20,8 @@ __global__ __launch_bounds__(256) void k_project_general(dev_entry const *__rest
 	uint64_t const g_begin = n_groups * wave / n_waves;
 	uint64_t const g_end = n_groups * (wave + 1) / n_waves;
 	arena_alloc arena{0, 0};
+	uint32_t *run_list = W.run_list + 64 * g_begin;		// work list for k_realign, after the entries of k_project_mid
+	uint32_t n_run = rfl(W.run_count[wave]);
 	group_out G;
 	G.n_failed = 0; G.n_with_runs = 0; G.bitvec_bytes = 0; G.ref_bytes = 0; G.bytes = 0;
 
@@ -71,6 +73,11 @@ __global__ __launch_bounds__(256) void k_project_general(dev_entry const *__rest
 			if (!has0) break;
 		}
 
+		{
+			uint64_t const m = ballot(mine && (0 == (G.flags & REC_STATUS_MASK)) && (0 != (G.flags & REC_HAS_RUN)));
+			if ((m >> lane) & 1) run_list[n_run + mbcnt64(m)] = (uint32_t) rec;
+			n_run += popc64(m);
+		}
 		if (mine)
 		{
 			bool const ok = (0 == (G.flags & REC_STATUS_MASK));
@@ -80,6 +87,7 @@ __global__ __launch_bounds__(256) void k_project_general(dev_entry const *__rest
 			W.cig_loc[rec] = ((uint64_t) G.loc_hi << 32) | G.loc_lo;
 		}
 	}
+	W.run_count[wave] = n_run;		// wave-uniform store
 	if (0 == lane)
 	{
 		unsigned long long *ws = W.wave_stats + ((uint64_t) 2 * n_waves + wave) * WAVE_STATS;

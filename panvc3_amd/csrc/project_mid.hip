@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 	uint64_t const n_groups = (in.n + 63) / 64;
 	uint32_t const *list = W.slow_list + 64 * (n_groups * wave / n_waves);
 	uint32_t const count = W.slow_count[wave];
+	uint32_t *run_list = W.run_list + 64 * (n_groups * wave / n_waves);
+	uint32_t n_run = 0;		// wave-uniform
 	__shared__ uint32_t lds_tok[4][64 * MID_TOKENS];
 	uint32_t *my_tok = lds_tok[rfl(threadIdx.x >> 6)] + lane;
 	arena_alloc arena{0, 0};
@@ -261,6 +263,12 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 		uint64_t const loc = base_loc + (scan - (ok ? out.n_out : 0));
 		for (uint32_t k = 0; k < n_tok; ++k)
 			W.arena[loc + k] = my_tok[64 * k];
+		{
+			// Work list for k_realign.
+			uint64_t const m = ballot(done && ok && out.has_run);
+			if ((m >> lane) & 1) run_list[n_run + mbcnt64(m)] = rec;
+			n_run += popc64(m);
+		}
 		if (done)
 		{
 			W.rec_flags[rec] = status | ((ok && out.has_run) ? REC_HAS_RUN : 0);
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 		}
 	}
 
+	W.run_count[wave] = n_run;		// wave-uniform store
 	for (int off = 32; off; off >>= 1)
 	{
 		acc_bitvec += __shfl_xor(acc_bitvec, off);

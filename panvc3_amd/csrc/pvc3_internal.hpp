@@ -106,6 +106,8 @@ struct dev_batch_work
 	uint64_t scratch_per_wave;
 	uint32_t *slow_list;				// records left by the fast path: wave w of k_project_fast fills [64 * first group of w ...)
 	uint32_t *slow_count;				// [waves of k_project_fast]
+	uint32_t *run_list;					// records with an indel run, same partition: k_project_mid appends, then k_project_general
+	uint32_t *run_count;				// [waves of k_project_fast]
 	unsigned long long *wave_stats;		// [3 kernels][waves][WAVE_STATS]: per-wave sums, folded into `counters` by k_reduce_stats
 	dev_counters *counters;
 };
@@ -144,7 +146,7 @@ struct dev_params
 int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream);
 int launch_project_mid(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
 int launch_project_general(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
-int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream);
+int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream);	// consumes run_list / run_count
 int launch_reduce_stats(uint64_t n, dev_batch_work const &work, void *stream);
 int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &packed, uint64_t *scan_tmp, void *stream);
 int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);

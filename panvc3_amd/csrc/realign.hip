@@ -240,7 +240,7 @@ __device__ __forceinline__ void align_global(
 // against 22.5 ms with 86 VGPRs / 8 KB / 5 waves per SIMD.
 __global__ __launch_bounds__(64, 8) void k_realign(
 	dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W,
-	dev_params const *__restrict__ prm, uint32_t lds_budget
+	dev_params const *__restrict__ prm, uint32_t lds_budget, uint32_t n_regions
 )
 {
 	__shared__ __attribute__((aligned(16))) uint8_t lds[REALIGN_LDS_BYTES];
@@ -256,32 +256,28 @@ __global__ __launch_bounds__(64, 8) void k_realign(
 	uint32_t const wave = blockIdx.x;
 	uint32_t const n_waves = gridDim.x;
 	arena_alloc arena{0, 0}, runs_alloc{0, 0};
-	uint32_t total_runs = 0, n_failed = 0;
+	uint32_t total_runs = 0, n_failed = 0, touched = 0;
 	uint64_t qual_bytes = 0;
 
-	// Contiguous range of 64-record stripes per wave; the flags of the next stripe are loaded while this one is processed.
-	uint64_t const n_stripes = (in.n + 63) / 64;
-	uint64_t const s_begin = n_stripes * wave / n_waves, s_end = n_stripes * (wave + 1) / n_waves;
-	// Four stripes of flags are kept in flight: most stripes have no flagged record, so the scan advances at the rate of the
-	// loads, not of their latency.
-	auto load_flags = [&](uint64_t stripe) -> uint32_t { return (stripe < s_end && stripe * 64 + lane < in.n) ? W.rec_flags[stripe * 64 + lane] : 0; };
-	uint32_t fl0 = load_flags(s_begin), fl1 = load_flags(s_begin + 1), fl2 = load_flags(s_begin + 2), fl3 = load_flags(s_begin + 3);
-	for (uint64_t stripe = s_begin; stripe < s_end; ++stripe)
+	// The records with indel runs come as per-region work lists (region = the record range of one wave of the projection
+	// kernels, filled by k_project_mid and k_project_general); every wave takes a contiguous range of regions and walks each
+	// list 64 entries at a time.  (Scanning the flags of all records instead cost more than half of this kernel on C3.)
+	uint64_t const n_groups = (in.n + 63) / 64;
+	uint32_t const r_begin = (uint32_t) ((uint64_t) n_regions * wave / n_waves), r_end = (uint32_t) ((uint64_t) n_regions * (wave + 1) / n_waves);
+	for (uint32_t region = r_begin; region < r_end; ++region)
+	for (uint32_t chunk = 0, cnt = rfl(W.run_count[region]); chunk < cnt; chunk += 64)
 	{
-		uint64_t const base = stripe * 64;
-		uint32_t const fl = fl0;
-		fl0 = fl1; fl1 = fl2; fl2 = fl3; fl3 = load_flags(stripe + 4);
-		bool const mine = 0 != (fl & REC_HAS_RUN);
+		uint32_t const *list = W.run_list + 64 * (n_groups * region / n_regions);
+		bool const mine = chunk + lane < cnt;
+		uint32_t const v_rec = mine ? list[chunk + lane] : 0;
 		uint64_t todo = ballot(mine);
-		if (!todo)
-			continue;
 
 		// Descriptors of the marked records, lane-parallel.
 		uint64_t v_loc = 0, v_seq_off = 0, v_qual_off = 0, v_text = 0;
 		uint32_t v_n = 0, v_dst_pos = 0, v_text_len = 0, v_l_seq = 0, v_has_qual = 0;
 		if (mine)
 		{
-			uint64_t const r = base + lane;
+			uint64_t const r = v_rec;
 			v_loc = W.cig_loc[r]; v_n = W.cig_n[r]; v_dst_pos = W.dst_pos[r];
 			dev_entry const *de = entries + in.dst_entry[r];
 			v_text = (uint64_t) de->text; v_text_len = de->text_len;
@@ -290,13 +286,35 @@ __global__ __launch_bounds__(64, 8) void k_realign(
 			if (v_has_qual) v_qual_off = in.qual_off[r];
 		}
 
+		// Touch what the records of this chunk will read (operations, text around the projected position, SEQ, QUAL), one
+		// record per lane, all at once: the records are then walked one after the other with warm caches and TLBs instead of
+		// paying a full miss at every dependent step.  The values only keep the loads alive.
+		if (mine)
+		{
+			uint32_t const *o = W.arena + v_loc;
+			touched ^= o[0];
+			if (v_n > 16) touched ^= o[16];
+			if (v_text)
+			{
+				uint8_t const *t = (uint8_t const *) v_text + v_dst_pos;		// texts carry TEXT_PAD readable bytes past their end
+				touched ^= (uint32_t) t[0] ^ (uint32_t) t[64] ^ (uint32_t) t[128] ^ (uint32_t) t[192];
+			}
+			uint8_t const *q = in.seq4 + v_seq_off;
+			touched ^= (uint32_t) q[0] ^ (uint32_t) q[(v_l_seq + 1) / 2 - 1];
+			if (v_has_qual)
+			{
+				uint8_t const *qq = in.qual + v_qual_off;
+				touched ^= (uint32_t) qq[0] ^ (uint32_t) qq[v_l_seq / 2] ^ (uint32_t) qq[v_l_seq - 1];
+			}
+		}
+
 		// The first 64 operations of a record live in lanes; those of the next marked record are fetched while this one is processed.
 		auto load_ops = [&](uint32_t r) -> uint32_t { return (lane < readlane(v_n, r)) ? (W.arena + readlane64(v_loc, r))[lane] : 0; };
 		uint32_t opv_next = load_ops(ctz64(todo));
 		while (todo)
 		{
 			uint32_t const ri = ctz64(todo);
-			uint64_t const rec = base + ri;
+			uint64_t const rec = readlane(v_rec, ri);
 			todo &= todo - 1;
 			uint32_t const opv = opv_next;
 			if (todo) opv_next = load_ops(ctz64(todo));
@@ -425,6 +443,8 @@ __global__ __launch_bounds__(64, 8) void k_realign(
 			if (!status) { total_runs += n_runs; qual_bytes += qual ? l_seq : 0; }
 		}
 	}
+	if (0xA5A5A5A5u == touched && 0xFFFFFFFFu == n_failed)		// never true: keeps the touch loads
+		W.counters->scratch_needed = touched;
 	if (0 == lane && n_failed)
 		atomicAdd(&W.counters->n_failed, (unsigned long long) n_failed);
 	if (0 == lane && total_runs)
@@ -442,9 +462,9 @@ int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in co
 {
 	if (0 == in.n) return 0;
 	if (lds_budget > REALIGN_LDS_BYTES) lds_budget = REALIGN_LDS_BYTES;
-	uint64_t const useful = (in.n + 63) / 64;
-	if (n_waves > useful) n_waves = (uint32_t) useful;
-	hipLaunchKernelGGL(k_realign, dim3(n_waves), dim3(64), 0, (hipStream_t) stream, entries, n_entries, in, work, params, lds_budget);
+	uint32_t const n_regions = project_wave_count(in.n);		// one work list per wave of the projection kernels
+	if (n_waves > n_regions) n_waves = n_regions;
+	hipLaunchKernelGGL(k_realign, dim3(n_waves), dim3(64), 0, (hipStream_t) stream, entries, n_entries, in, work, params, lds_budget, n_regions);
 	return (int) hipGetLastError();
 }
 

@@ -2,9 +2,13 @@
 """bench.py — throughput of the project_alignments hot path on MI355X (BASELINE.json metric).
 
 A step = one pass of the whole hot path (projection walk, mate projection, indel-run realignment, packing) over one
-device-resident batch of synthetic 2x150 bp records (config C3 of BASELINE.json: 20 M pairs = 40 M records per GPU,
-REF + 8 founders, 1 Gbp in 8 contigs).  Inputs are resident in HBM when the timed region starts.  Multi-GPU: one process
-per GPU, every rank owns its own slice of the read stream (weak scaling), the index is replicated, no data-path collective.
+device-resident batch of synthetic records (default: config C3 of BASELINE.json, 20 M 2x150 bp pairs = 40 M records per GPU,
+REF + 8 founders, 1 Gbp in 8 contigs).  Inputs are resident in HBM when the timed region starts.
+
+Multi-GPU: one process per GPU, every rank owns its own slice of the read stream (weak scaling), the index is replicated,
+no data-path collective.  `python bench.py --gpus N` starts the N ranks itself (children are fresh processes, started before
+anything in this process touches the GPU); under `python -m torch.distributed.run` the ranks are already there and this file
+is one of them.
 
 Prints ONE JSON line on rank 0.
 """
@@ -19,31 +23,105 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0		# MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
+METRIC = {
+	"C2": "projected+realigned alignments/sec, 150 bp single-end",
+	"C3": "projected+realigned alignments/sec, 2x150 bp",
+	"C3G": "projected+realigned alignments/sec, 2x150 bp, gap-dense MSA",
+	"C4": "projected+realigned alignments/sec, 2x150 bp",
+	"C5": "projected+realigned alignments/sec, 2x250 bp, 5 % long-indel reads",
+}
+
 
 def log(msg):
 	if int(os.environ.get("RANK", "0")) == 0:
 		print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args(argv=None):
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=10)
 	ap.add_argument("--warmup", type=int, default=2)
-	ap.add_argument("--config", default="C3", help="BASELINE.json workload: C2, C3 (metric config), C5")
+	ap.add_argument("--config", default="C3", help="BASELINE.json workload: C2, C3 (metric config), C3G (C3 on a gap-dense MSA), C4 (its per-GPU shard: 50 M records), C5")
 	ap.add_argument("--scale", type=float, default=1.0, help="shrink genome and read count together (smoke runs only)")
 	ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="target CPU time of the oracle sample; 0 disables")
 	ap.add_argument("--score-mode", type=int, default=0)
 	ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="pvc3_context_set_option (tuning experiments), e.g. realign_waves=5120")
-	ap.add_argument("--skip-host-buffers", action="store_true", help="leave out the PCIe-inclusive leg (its smaller launches would enter rocprofv3's per-kernel averages)")
+	ap.add_argument("--skip-host-buffers", action="store_true", help="leave out the PCIe-inclusive legs (their smaller launches would enter rocprofv3's per-kernel averages)")
 	ap.add_argument("--sorted", action="store_true", help="sort the records by (source entry, position) like a coordinate-sorted BAM (secondary data point; the default is the unsorted worst case)")
-	args = ap.parse_args()
+	ap.add_argument("--no-build", action="store_true", help="never compile: exit non-zero if a native library is stale (use under rocprofv3, after `python3 -m panvc3_amd.build`)")
+	return ap.parse_args(argv)
+
+
+def ensure_built(no_build, local_rank):
+	"""All native pieces, before torch or any HIP call exists in this process (a compiler must never be started from a process
+	that has initialised the GPU, least of all under rocprofv3).  Builds are keyed by content, so on the GPU box, where the
+	libraries travel with the tree, this compiles nothing.  Only local rank 0 builds; the others wait for fresh keys."""
+	from panvc3_amd import build as pvc3_build
+	from oracle import oracle as orc
+	from tests.synth import synth
+
+	def stale():
+		return [name for name, fn in (("libpvc3_hip.so", pvc3_build.is_stale), ("libpvc3_oracle.so", orc.is_stale), ("libpvc3_synth.so", synth.is_stale)) if fn()]
+	s = stale()
+	if not s:
+		return
+	if no_build:
+		raise SystemExit("bench.py --no-build: stale native libraries %s; run `python3 -m panvc3_amd.build` (and the oracle / synth builds) first" % ", ".join(s))
+	if 0 == local_rank:
+		pvc3_build.build()
+		orc.build()
+		synth.build()
+		return
+	t0 = time.time()
+	while stale():
+		if time.time() - t0 > 900:
+			raise SystemExit("bench.py: rank %d gave up waiting for local rank 0 to build" % local_rank)
+		time.sleep(1.0)
+
+
+def launch_children(args):
+	"""`python bench.py --gpus N` without a launcher: this process becomes the parent of N rank processes and never touches
+	the GPU itself (no torch import, no HIP call)."""
+	from panvc3_amd.shard import launch_ranks
+	ensure_built(args.no_build, 0)
+	argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-build"]
+	codes = launch_ranks(argv, args.gpus)
+	bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+	if bad:
+		print("[bench] ranks failed: %s" % ", ".join("rank %d exit %s" % rc for rc in bad), file=sys.stderr, flush=True)
+		return 1
+	return 0
+
+
+def traffic_for(config, scale):
+	"""HBM bytes per k_project_fast launch from the committed PMC passes, but only if they were taken with the kernels that
+	are running now (profiles/pmc_traffic.json records the build key); otherwise null — never a stale constant."""
+	from panvc3_amd import build as pvc3_build
+	prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+	try:
+		pj = json.load(open(prof))
+		ent = pj.get("%s@%g" % (config, scale))
+		if ent and ent.get("kernel_key") == pvc3_build.kernel_key():
+			return ent["k_project_fast_hbm_bytes_per_launch"], ent
+	except Exception:
+		pass
+	return None, None
+
+
+def main():
+	args = parse_args()
+	if args.gpus < 1:
+		raise SystemExit("--gpus must be positive")
+	if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+		sys.exit(launch_children(args))
 
 	rank = int(os.environ.get("RANK", "0"))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-	if world != args.gpus and world > 1:
-		log("warning: WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+	if world != args.gpus:
+		raise SystemExit("bench.py: WORLD_SIZE %d does not match --gpus %d" % (world, args.gpus))
+	ensure_built(args.no_build, local_rank)
 
 	import numpy as np
 	import torch
@@ -54,25 +132,24 @@ def main():
 	torch.cuda.set_device(local_rank)
 	device = torch.device("cuda", local_rank)
 	if world > 1:
-		dist.init_process_group(backend="nccl", device_id=device)
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		dist.init_process_group(backend="nccl", device_id=device)		# "nccl" is RCCL on ROCm
 
 	import panvc3_amd
 	from panvc3_amd import build as pvc3_build
 	from panvc3_amd.shard import reduce_job
 	from tests.synth import synth
 
-	# One rank per node builds (normally a no-op: the build is keyed by content), the others wait: several ranks must not
-	# write the same shared objects at once.
-	if 0 == local_rank:
-		pvc3_build.build()
-		synth.build()
-	if world > 1:
-		dist.barrier()
 	cores = os.cpu_count() or 1
 	threads = max(1, cores // max(1, world))
+	config = args.config.upper()
 
 	# ---- synthetic workload ---------------------------------------------------------------------------------------------
-	gp, rp, desc = synth.config(args.config, scale=args.scale)
+	gp, rp, desc = synth.config(config, scale=args.scale)
+	if "C4" == config:
+		# C4 is 200 M pairs over 8 GPUs: every rank generates and owns its own shard of 50 M records (never the 400 M whole).
+		rp.n_records = max(2, rp.n_records // 8)
+		desc += "; this rank's shard: %d records" % rp.n_records
 	rp.seed = rp.seed + 1000 * rank			# every rank samples its own reads (weak scaling); the genome is identical
 	t0 = time.time()
 	genome = synth.Genome(gp, n_threads=min(threads, gp.n_contigs))
@@ -99,7 +176,7 @@ def main():
 	log("index %.2f GB in HBM; batch uploaded in %.1f s" % (index_bytes / 1e9, time.time() - t2))
 	params = panvc3_amd.api.make_params(0, -1, args.score_mode)
 	if world > 1:
-		# The host copies are only needed by the single-GPU legs (CPU baseline, host-buffer entry point): with one rank per
+		# The host copies are only needed by the single-GPU legs (CPU baseline, host-buffer entry points): with one rank per
 		# GPU on one node they would add up to > 20 GB of host memory per rank.
 		batch = None
 		del reads, genome, index
@@ -117,7 +194,8 @@ def main():
 		raise SystemExit("unexpected: %d records failed" % stats["n_failed"])
 
 	# ---- timed region ------------------------------------------------------------------------------------------------------
-	ms = dict(project=0.0, mid=0.0, general=0.0, realign=0.0, pack=0.0)
+	ms_keys = ("project", "mid", "general", "realign", "pack")
+	ms = dict.fromkeys(ms_keys, 0.0)
 	barrier()
 	torch.cuda.synchronize()
 	t_begin = time.perf_counter()
@@ -140,18 +218,9 @@ def main():
 		value = n_total * steps / elapsed_max
 		project_bytes = stats["algorithmic_bytes_project"]
 		achieved = project_bytes / (ms_avg["project"] * 1e-3) / 1e9 if ms_avg["project"] > 0 else 0.0
-		traffic = None
-		prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-		if os.path.exists(prof):
-			try:
-				pj = json.load(open(prof))
-				key = "%s@%g" % (args.config, args.scale)
-				if key in pj:
-					traffic = pj[key]["k_project_fast_hbm_bytes_per_launch"]
-			except Exception:
-				traffic = None
+		traffic, traffic_src = traffic_for(config, args.scale)
 		result = {
-			"metric": "projected+realigned alignments/sec, 2x150 bp",
+			"metric": METRIC.get(config, METRIC["C3"]),
 			"value": value, "unit": "alignments/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
 			"ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": "u64 bit-vectors / u32 CIGAR (f64 only in the realign DP)", "data": "synthetic",
@@ -161,11 +230,11 @@ def main():
 			},
 			"roofline": {
 				"bound": "hbm", "kernel": "k_project_fast", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-				"traffic": traffic, "algorithmic_bytes_per_launch": project_bytes, "ms_per_launch": ms_avg["project"],
+				"traffic": traffic, "traffic_source": (traffic_src or {}).get("source"), "algorithmic_bytes_per_launch": project_bytes, "ms_per_launch": ms_avg["project"],
 				"bytes_per_alignment": project_bytes / max(1, n_local),
 				"whole_step": {"algorithmic_bytes": stats["algorithmic_bytes"], "GBps": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9, "frac": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
 			},
-			"kernel_ms": ms_avg,
+			"kernel_ms": ms_avg, "kernel_key": pvc3_build.kernel_key()[:16],
 			"batch": {"fast_path_records": stats["n_fast_path"], "mid_path_records": stats["n_mid_path"], "realigned_records": stats["n_realigned_records"], "indel_runs": stats["n_runs"], "out_cigar_ops": stats["out_cigar_total"], "checksum": "%016x" % checksum_total},
 		}
 
@@ -187,13 +256,23 @@ def main():
 			dt = time.perf_counter() - tb
 			result["host_buffers"]["pinned"] = {"value": k / dt, "unit": "alignments/s", "what": "the same batch from and to page-locked arrays"}
 			del pb, owners, res0, owner0
+			if hasattr(panvc3_amd, "pipeline_bench"):
+				result["pipeline"] = panvc3_amd.pipeline_bench(ctx, batch, params)
 
 		# ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample, same box, rank 0 only ----
 		if world == 1 and args.cpu_baseline_seconds > 0:
 			from oracle import oracle as orc
 			o = orc.Oracle()
 			genome.fill_index(o)
+			# one thread first (the reference's record loop is serial: project_alignments.cc:354, 608-611)
 			probe = min(n_local, 20000)
+			tb = time.perf_counter()
+			o.batch_project(synth.slice_batch(batch, 0, probe), 0, -1, args.score_mode, n_threads=1)
+			rate1 = probe / max(1e-6, time.perf_counter() - tb)
+			sample1 = int(min(n_local, max(probe, rate1 * min(5.0, args.cpu_baseline_seconds))))
+			tb = time.perf_counter()
+			o.batch_project(synth.slice_batch(batch, 0, sample1), 0, -1, args.score_mode, n_threads=1)
+			one_thread = {"value": sample1 / (time.perf_counter() - tb), "unit": "alignments/s", "cores": 1, "sample": "first %d records, one thread" % sample1}
 			tb = time.perf_counter()
 			o.batch_project(synth.slice_batch(batch, 0, probe), 0, -1, args.score_mode, n_threads=cores)
 			rate = probe / max(1e-6, time.perf_counter() - tb)
@@ -204,7 +283,8 @@ def main():
 			cpu_s = time.perf_counter() - tb
 			result["cpu_baseline"] = {
 				"value": sample / cpu_s, "unit": "alignments/s", "cores": cores, "kind": "port",
-				"sample": "first %d records of the same batch through oracle/pvc3_oracle.c (plain bit-vectors + binary-search select: faster than the reference's rrr_vector<15> + seqan3 path, which cannot be built here)" % sample,
+				"sample": "first %d records of the same batch through oracle/pvc3_oracle.c on %d threads (a restatement of the reference algorithm on plain bit-vectors; the reference itself cannot be built here)" % (sample, cores),
+				"one_thread": one_thread,
 			}
 			# parity spot check of the sample against the device results
 			got = db.download()

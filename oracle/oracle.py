@@ -23,12 +23,22 @@ STATUS_NAMES = {0: "ok", 1: "src_range", 2: "cigar_op", 3: "query_range", 4: "re
 
 
 def build(force=False):
-	"""Compile the oracle with gcc (make -C oracle)."""
-	if force or not os.path.exists(_LIB_PATH) or any(
-		os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH) for f in ("pvc3_oracle.c", "pvc3_oracle.h")
-	):
-		subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+	"""Compile the oracle with gcc.  Keyed by the content of the sources and the command line (file times do not survive the
+	snapshot that carries the tree to a GPU box), so a fresh library is never rebuilt there."""
+	from panvc3_amd.build import _done, _key, _stale
+	srcs = [os.path.join(_HERE, f) for f in ("pvc3_oracle.c", "pvc3_oracle.h", "Makefile")]
+	cmd = ["make", "-C", _HERE, "-s", "-B"]
+	key = _key(srcs, cmd)
+	if force or _stale(_LIB_PATH, key):
+		subprocess.check_call(cmd)
+		_done(_LIB_PATH, key)
 	return _LIB_PATH
+
+
+def is_stale():
+	from panvc3_amd.build import _key, _stale
+	srcs = [os.path.join(_HERE, f) for f in ("pvc3_oracle.c", "pvc3_oracle.h", "Makefile")]
+	return _stale(_LIB_PATH, _key(srcs, ["make", "-C", _HERE, "-s", "-B"]))
 
 
 class Run(C.Structure):

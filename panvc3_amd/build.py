@@ -45,35 +45,55 @@ def _done(target, key):
 		f.write(key)
 
 
-def build(force=False, verbose=False):
-	os.makedirs(OBJ, exist_ok=True)
+def _plan():
+	"""(compile steps [(object, key, command)], link step (marker, key, command))."""
 	headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
 	headers.append(os.path.join(HERE, "..", "include", "pvc3.h"))
 	flags = [
 		"-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off", "-fvisibility=hidden",
 		"-Wall", "-Wextra", "-Wno-unused-parameter", "-x", "hip",
 	]
-	objs = []
+	steps, keys = [], []
 	for src in SOURCES:
 		sp = os.path.join(CSRC, src)
 		op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-		objs.append(op)
 		cmd = [hipcc()] + flags + ["-c", sp, "-o", op]
 		key = _key([sp] + headers, cmd[1:])
+		steps.append((op, key, cmd))
+		keys.append(key)
+	objs = [s[0] for s in steps]
+	cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+	h = hashlib.sha256("\0".join(keys + cmd[1:]).encode()).hexdigest()
+	return steps, (os.path.join(OBJ, "libpvc3_hip.so"), h, cmd)
+
+
+def kernel_key():
+	"""Content key of libpvc3_hip.so (every kernel source, header and flag): profiles that report per-kernel numbers record it,
+	and bench.py only quotes such a number when the key matches the library that is running."""
+	return _plan()[1][1]
+
+
+def is_stale():
+	"""True if build() would compile or link anything (nothing is built here)."""
+	steps, (marker, link_key, _) = _plan()
+	return any(_stale(op, key) for op, key, _ in steps) or not os.path.exists(LIB) or _stale(marker, link_key)
+
+
+def build(force=False, verbose=False):
+	os.makedirs(OBJ, exist_ok=True)
+	steps, (marker, link_key, link_cmd) = _plan()
+	for op, key, cmd in steps:
 		if force or _stale(op, key):
 			if verbose:
 				print(" ".join(cmd), file=sys.stderr)
 			subprocess.check_call(cmd)
 			_done(op, key)
-	cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
-	key = _key([o + ".key" for o in objs], cmd[1:])
-	lib_key = os.path.join(OBJ, "libpvc3_hip.so")
-	if force or not os.path.exists(LIB) or _stale(lib_key if os.path.exists(lib_key) else LIB, key):
+	if force or not os.path.exists(LIB) or _stale(marker, link_key):
 		if verbose:
-			print(" ".join(cmd), file=sys.stderr)
-		subprocess.check_call(cmd)
-		open(lib_key, "w").close()		# marker whose .key holds the link key (keeps the key file out of the package directory)
-		_done(lib_key, key)
+			print(" ".join(link_cmd), file=sys.stderr)
+		subprocess.check_call(link_cmd)
+		open(marker, "w").close()		# marker whose .key holds the link key (keeps the key file out of the package directory)
+		_done(marker, link_key)
 	return LIB
 
 

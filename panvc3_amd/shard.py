@@ -26,3 +26,61 @@ def reduce_job(dist, device, elapsed_s, n_records, checksum=0):
 	n = v[0] + (v[1] << 16) + (v[2] << 32) + (v[3] << 48)
 	c = (v[4] + (v[5] << 16) + (v[6] << 32) + (v[7] << 48)) & 0xFFFFFFFFFFFFFFFF
 	return float(t.item()), n, c
+
+
+def free_port():
+	import socket
+	s = socket.socket()
+	s.bind(("127.0.0.1", 0))
+	port = s.getsockname()[1]
+	s.close()
+	return port
+
+
+def launch_ranks(cmd, world_size, env=None, timeout=None, poll_s=0.2):
+	"""Starts `cmd` (argv list) once per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one process
+	per GPU of this node, and waits for all of them.  Returns the list of exit codes in rank order.  When a rank fails, the
+	others are terminated (their exit code is then the signal's) so that nobody waits at a barrier forever.
+
+	The caller must not have initialised the GPU: the children are fresh processes (fork + exec of the interpreter), and a
+	process that has touched the GPU is never exec'ed over.  Nothing here imports torch."""
+	import os
+	import subprocess
+	import time
+	if world_size < 1:
+		raise ValueError("world_size must be positive")
+	base = dict(os.environ if env is None else env)
+	base.setdefault("MASTER_ADDR", "127.0.0.1")
+	base.setdefault("MASTER_PORT", str(free_port()))
+	base["WORLD_SIZE"] = str(world_size)
+	base["LOCAL_WORLD_SIZE"] = str(world_size)
+	procs = []
+	for r in range(world_size):
+		e = dict(base)
+		e["RANK"] = str(r)
+		e["LOCAL_RANK"] = str(r)
+		procs.append(subprocess.Popen(list(cmd), env=e))
+	t0 = time.time()
+	failed = False
+	while True:
+		codes = [p.poll() for p in procs]
+		if all(c is not None for c in codes):
+			break
+		failed = failed or any(c not in (None, 0) for c in codes)
+		timed_out = timeout is not None and time.time() - t0 > timeout
+		if failed or timed_out:
+			for p in procs:
+				if p.poll() is None:
+					p.terminate()
+			for p in procs:
+				try:
+					p.wait(timeout=20)
+				except subprocess.TimeoutExpired:
+					p.kill()
+					p.wait()
+			codes = [p.returncode for p in procs]
+			if timed_out and not failed:
+				codes = [c if c else -1 for c in codes]
+			break
+		time.sleep(poll_s)
+	return codes

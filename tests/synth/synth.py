@@ -13,11 +13,25 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpvc3_synth.so")
 
 
+def _build_key():
+	from panvc3_amd.build import _key
+	cmd = ["make", "-C", HERE, "-s", "-B"]
+	return _key([os.path.join(HERE, "synth.cpp"), os.path.join(HERE, "Makefile")], cmd), cmd
+
+
 def build(force=False):
-	src = os.path.join(HERE, "synth.cpp")
-	if force or not os.path.exists(LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(LIB_PATH):
-		subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
+	"""Keyed by the content of the sources (file times do not survive the snapshot that carries the tree to a GPU box)."""
+	from panvc3_amd.build import _done, _stale
+	key, cmd = _build_key()
+	if force or _stale(LIB_PATH, key):
+		subprocess.check_call(cmd)
+		_done(LIB_PATH, key)
 	return LIB_PATH
+
+
+def is_stale():
+	from panvc3_amd.build import _stale
+	return _stale(LIB_PATH, _build_key()[0])
 
 
 class GenomeParams(C.Structure):

@@ -4,6 +4,7 @@ What bench.py does on GPUs is reproduced with the oracle as the stand-in compute
 ranges tile the batch, per-shard results concatenated in rank order equal the unsharded result byte for byte, and the
 collectives used for bookkeeping (max of elapsed times, sum of record counts, wrapping sum of checksums) behave.
 """
+import json
 import os
 import sys
 
@@ -107,3 +108,70 @@ def test_two_ranks_gloo(tmp_path):
 		assert np.array_equal(cat, whole[off]), off
 	# the checksum is additive over shards
 	assert int(whole["csum"]) == int(whole["whole_csum"])
+
+
+def _whole_oracle(scale):
+	from oracle import oracle as orc
+	from tests.synth import synth
+	gp, rp, _ = synth.config("C5", scale=scale)
+	genome = synth.Genome(gp, n_threads=2)
+	reads = synth.Reads(genome, rp, n_threads=2)
+	o = orc.Oracle()
+	genome.fill_index(o)
+	return o.batch_project(reads.batch())
+
+
+def check_shards_against_whole(out_dir, world, whole):
+	"""Concatenation of the ranks' results in rank order == the unsharded result, byte for byte; the job checksum (summed
+	through reduce_job) == the checksum of the whole."""
+	shards = [np.load(os.path.join(out_dir, "shard%d.npz" % r)) for r in range(world)]
+	assert int(shards[0]["lo"]) == 0
+	for a, b in zip(shards, shards[1:]):
+		assert int(a["hi"]) == int(b["lo"])
+	for k in ("dst_pos", "mate_dst_pos", "status", "out_cigar", "runs"):
+		assert np.array_equal(np.concatenate([s[k] for s in shards]), whole[k]), k
+	for off in ("out_cigar_off", "run_off"):
+		parts, base = [], 0
+		for s in shards:
+			parts.append(s[off][:-1].astype(np.uint64) + np.uint64(base))
+			base += int(s[off][-1])
+		assert np.array_equal(np.concatenate(parts + [np.array([base], dtype=np.uint64)]), whole[off]), off
+	job = np.load(os.path.join(out_dir, "job.npz"))
+	assert int(job["csum"]) == _checksum(whole, 0)
+	assert int(job["n"]) == whole["dst_pos"].size
+
+
+def test_launch_ranks_gloo(tmp_path):
+	"""The launcher bench.py --gpus N uses (panvc3_amd.shard.launch_ranks), driven with gloo on CPU: three ranks."""
+	from panvc3_amd.shard import launch_ranks
+	world = 3
+	codes = launch_ranks([sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), "oracle", str(tmp_path)], world, timeout=600)
+	assert codes == [0] * world
+	check_shards_against_whole(str(tmp_path), world, _whole_oracle(0.0003))
+
+
+def test_launch_ranks_failure_does_not_hang(tmp_path):
+	"""A rank that dies takes the job down: the launcher terminates the ranks waiting at the barrier and reports non-zero."""
+	from panvc3_amd.shard import launch_ranks
+	import time
+	t0 = time.time()
+	codes = launch_ranks([sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), "fail", str(tmp_path)], 2, timeout=300)
+	assert codes[1] == 3 and codes[0] != 0
+	assert time.time() - t0 < 120
+
+
+def test_bench_parent_starts_ranks_and_reports_their_failure():
+	"""`python bench.py --gpus 2` with no launcher: the parent starts two ranks itself (here, without a GPU, both stop with the
+	"needs a GPU" message) and exits non-zero; with WORLD_SIZE that contradicts --gpus it refuses to run."""
+	import subprocess
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.0001", "--steps", "1", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+	if r.returncode == 0:
+		line = json.loads(r.stdout.strip().splitlines()[-1])		# a box with GPUs: the job ran on two ranks
+		assert line["n_gpus"] == 2
+	else:
+		assert "ranks failed" in r.stderr and "rank 0" in r.stderr and "rank 1" in r.stderr
+		assert r.stderr.count("bench.py needs a GPU") == 2
+	env.update(RANK="0", WORLD_SIZE="3", LOCAL_RANK="0")
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
+	assert r.returncode != 0 and "does not match --gpus" in r.stderr

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 CSV output (kernel trace stats + separate FETCH_SIZE / WRITE_SIZE PMC passes) into profiles/.
 
-usage: summarize_rocprof.py OUT_DIR TRACE_DIR [FETCH_DIR WRITE_DIR] [--traffic-key C3@1]
+usage: summarize_rocprof.py OUT_DIR TRACE_DIR [FETCH_DIR WRITE_DIR] [--traffic-key=C3@1] [--fetch-factor=F]
+The traffic entry records the content key of the kernels it was measured on (panvc3_amd.build.kernel_key() of the tree the
+script runs in, which must be the tree that ran): bench.py quotes the number only for that same library.
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 tallies 128-byte requests at 64 bytes, so the read side is doubled ("corrected"); both raw and corrected are stored.
 """
@@ -23,9 +25,12 @@ def short(name):
 def main():
 	args = [a for a in sys.argv[1:] if not a.startswith("--")]
 	key = None
+	fetch_factor = None
 	for a in sys.argv[1:]:
 		if a.startswith("--traffic-key="):
 			key = a.split("=", 1)[1]
+		if a.startswith("--fetch-factor="):
+			fetch_factor = float(a.split("=", 1)[1])
 	out_dir, trace_dir = args[0], args[1]
 	os.makedirs(out_dir, exist_ok=True)
 	stats = glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True)
@@ -59,10 +64,21 @@ def main():
 	if key and "k_project_fast" in summary and "hbm_bytes_corrected" in summary["k_project_fast"]:
 		p = os.path.join(os.path.dirname(os.path.abspath(out_dir)), "pmc_traffic.json")
 		cur = json.load(open(p)) if os.path.exists(p) else {}
+		sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+		from panvc3_amd import build as pvc3_build
+		kf = summary["k_project_fast"]
+		fetch = kf.get("FETCH_SIZE_KiB_avg", 0.0) * 1024
+		write = kf.get("WRITE_SIZE_KiB_avg", 0.0) * 1024
+		# The guide's correction (FETCH_SIZE doubled) is exact for wide streams only; this kernel's mix of random 64-byte blocks,
+		# short unaligned rows and streams was calibrated on known byte counts (profiles/r01_final/fetch_calibration.json).
+		factor = fetch_factor if fetch_factor is not None else 2.0
 		cur[key] = {
-			"k_project_fast_hbm_bytes_per_launch": summary["k_project_fast"]["hbm_bytes_corrected"],
-			"k_project_fast_hbm_bytes_raw": summary["k_project_fast"]["hbm_bytes_raw"],
+			"k_project_fast_hbm_bytes_per_launch": factor * fetch + write,
+			"k_project_fast_hbm_bytes_raw": fetch + write,
+			"k_project_fast_hbm_bytes_fetch_doubled": 2 * fetch + write,
+			"fetch_factor": factor,
 			"source": os.path.basename(os.path.abspath(out_dir)),
+			"kernel_key": pvc3_build.kernel_key(),
 		}
 		json.dump(cur, open(p, "w"), indent=1, sort_keys=True)
 	for k, s in sorted(summary.items(), key=lambda kv: -kv[1].get("avg_ns", 0)):

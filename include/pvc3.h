@@ -181,9 +181,11 @@ PVC3_API void pvc3_context_destroy(pvc3_context *ctx);
 PVC3_API int pvc3_context_set_stream(pvc3_context *ctx, void *hip_stream);
 PVC3_API int pvc3_context_set_timing(pvc3_context *ctx, int enabled);	/* hipEvent pairs around each kernel group */
 PVC3_API int pvc3_context_synchronize(pvc3_context *ctx);
-/* Tuning / test knobs: "realign_waves", "realign_lds_bytes", "scratch_per_wave", "arena_initial", "runs_initial",
+/* Tuning / test knobs: "realign_waves", "big_waves", "realign_lds_bytes", "scratch_per_wave", "scratch_budget" (bytes: the
+ * alignment scratch slots together never exceed it), "arena_initial", "runs_initial",
  * "fast_path" (0: no lane-parallel compare in k_project_fast), "mid_path" (0: skip k_project_mid; with both at 0 every
- * record goes through the cooperative column walk of k_project_general). */
+ * record goes through the cooperative column walk of k_project_general), "packed_dp" (0: every indel run is aligned by the
+ * striped one-run-per-wavefront kernel instead of the packed kernels). */
 PVC3_API int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value);
 /* Replicates the index (bit-vector blocks, select samples, reference texts) into this context's HBM. */
 PVC3_API int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx);

@@ -52,13 +52,16 @@ struct pvc3_context
 	pvc3_params params{0, 0, -1, 0};
 
 	// Options.
-	uint32_t realign_waves{8192};		// one 64-thread block each, 64 VGPRs and 4.7 KB of LDS per block => all 32 wave slots of a CU
+	uint32_t realign_waves{8192};		// packed alignment kernels: one 64-thread block each
+	uint32_t big_waves{1024};			// striped alignment kernel (runs that do not fit the packed kernels): waves = scratch slots
 	uint32_t realign_lds_bytes{};
 	uint64_t scratch_per_wave{128 * 1024};
+	uint64_t scratch_budget{UINT64_C(8) << 30};	// the scratch slots together never exceed this: fewer waves when one run needs a large slot
 	uint64_t arena_initial{};
 	uint64_t runs_initial{};
 	uint32_t fast_path{1};
 	uint32_t mid_path{1};
+	uint32_t packed_dp{1};
 	uint8_t *scratch{};
 	uint64_t scratch_alloc{};
 };
@@ -166,9 +169,18 @@ void free_index_replica(pvc3_context *ctx)
 	ctx->index_bytes = 0;
 }
 
+// Waves of the striped alignment kernel: one scratch slot each, all slots within the budget.  A single long run (e.g. a
+// 250-base query slice against a 60 kb deletion needs 16 MB) must not multiply by thousands of waves.
+uint32_t big_wave_count(pvc3_context const *ctx)
+{
+	uint64_t const fit = ctx->scratch_budget / (ctx->scratch_per_wave ? ctx->scratch_per_wave : 1);
+	uint64_t const w = (fit < ctx->big_waves) ? fit : ctx->big_waves;
+	return (uint32_t) (w < 1 ? 1 : w);
+}
+
 int ensure_scratch(pvc3_context *ctx)
 {
-	uint64_t const need = ctx->scratch_per_wave * ctx->realign_waves;
+	uint64_t const need = ctx->scratch_per_wave * big_wave_count(ctx);
 	if (ctx->scratch && ctx->scratch_alloc >= need)
 		return PVC3_OK;
 	if (ctx->scratch) { (void) hipFree(ctx->scratch); ctx->workspace_bytes -= ctx->scratch_alloc; ctx->scratch = nullptr; }
@@ -181,12 +193,18 @@ int alloc_arenas(pvc3_dbatch *b, uint64_t arena_cap, uint64_t runs_cap)
 {
 	pvc3_context *ctx = b->ctx;
 	if (b->work.arena) { (void) hipFree(b->work.arena); (void) hipFree(b->packed.out_cigar); b->bytes -= 8 * b->work.arena_cap; }
-	if (b->work.runs_arena) { (void) hipFree(b->work.runs_arena); (void) hipFree(b->packed.runs); b->bytes -= 2 * sizeof(pvc3_run) * b->work.runs_cap; }
-	b->work.arena = nullptr; b->packed.out_cigar = nullptr; b->work.runs_arena = nullptr; b->packed.runs = nullptr;
+	if (b->work.runs_arena)
+	{
+		(void) hipFree(b->work.runs_arena); (void) hipFree(b->packed.runs); (void) hipFree(b->work.run_items); (void) hipFree(b->work.dp_list);
+		b->bytes -= (2 * sizeof(pvc3_run) + sizeof(run_work) + DP_CLASSES * sizeof(uint32_t)) * b->work.runs_cap;
+	}
+	b->work.arena = nullptr; b->packed.out_cigar = nullptr; b->work.runs_arena = nullptr; b->packed.runs = nullptr; b->work.run_items = nullptr; b->work.dp_list = nullptr;
 	PVC3_TRY(dev_alloc(&b->work.arena, arena_cap, nullptr, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.out_cigar, arena_cap, nullptr, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->work.runs_arena, runs_cap, nullptr, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.runs, runs_cap, nullptr, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->work.run_items, runs_cap, nullptr, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->work.dp_list, DP_CLASSES * runs_cap, nullptr, &b->bytes));
 	b->work.arena_cap = arena_cap; b->packed.out_cigar_cap = arena_cap;
 	b->work.runs_cap = runs_cap; b->packed.run_cap = runs_cap;
 	(void) ctx;
@@ -210,7 +228,7 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	if (int const e = launch_reduce_stats(b->n, b->work, s)) return set_error(PVC3_E_HIP, "k_reduce_stats launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	uint32_t const lds = ctx->realign_lds_bytes ? ctx->realign_lds_bytes : realign_lds_bytes();
-	if (int const e = launch_realign(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->d_params, ctx->realign_waves, lds, s)) return set_error(PVC3_E_HIP, "k_realign launch: %s", hipGetErrorString((hipError_t) e));
+	if (int const e = launch_realign(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->d_params, ctx->realign_waves, big_wave_count(ctx), lds, ctx->packed_dp, s)) return set_error(PVC3_E_HIP, "k_realign launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[3], s));
 	if (int const e = launch_pack(b->n, b->work, b->packed, b->scan_tmp, s)) return set_error(PVC3_E_HIP, "pack launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[4], s));
@@ -374,10 +392,13 @@ int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value)
 	if ("realign_waves" == k) { if (value < 1 || value > 65536) return set_error(PVC3_E_INVALID, "realign_waves out of range"); ctx->realign_waves = (uint32_t) value; }
 	else if ("realign_lds_bytes" == k) ctx->realign_lds_bytes = (uint32_t) value;
 	else if ("scratch_per_wave" == k) ctx->scratch_per_wave = (uint64_t) value;
+	else if ("scratch_budget" == k) ctx->scratch_budget = (uint64_t) value;
+	else if ("big_waves" == k) { if (value < 1 || value > 65536) return set_error(PVC3_E_INVALID, "big_waves out of range"); ctx->big_waves = (uint32_t) value; }
 	else if ("arena_initial" == k) ctx->arena_initial = (uint64_t) value;
 	else if ("runs_initial" == k) ctx->runs_initial = (uint64_t) value;
 	else if ("fast_path" == k) ctx->fast_path = (0 != value);
 	else if ("mid_path" == k) ctx->mid_path = (0 != value);
+	else if ("packed_dp" == k) ctx->packed_dp = (0 != value);
 	else return set_error(PVC3_E_INVALID, "pvc3_context_set_option: unknown option %s", key);
 	return PVC3_OK;
 }
@@ -467,6 +488,8 @@ void pvc3_dbatch_destroy(pvc3_dbatch *b)
 	if (b->packed.out_cigar) (void) hipFree(b->packed.out_cigar);
 	if (b->work.runs_arena) (void) hipFree(b->work.runs_arena);
 	if (b->packed.runs) (void) hipFree(b->packed.runs);
+	if (b->work.run_items) (void) hipFree(b->work.run_items);
+	if (b->work.dp_list) (void) hipFree(b->work.dp_list);
 	delete b;
 }
 
@@ -533,6 +556,7 @@ int pvc3_dbatch_create(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_dbatch *
 	PVC3_TRY(dev_alloc(&w.slow_count, project_wave_count(n), &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.run_list, (n + 63) / 64 * 64 + 64, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.run_count, project_wave_count(n), &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.run_prefix, (uint64_t) project_wave_count(n) + 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.wave_stats, 3 * (uint64_t) project_wave_count(n) * WAVE_STATS, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.out_cigar_off, n + 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.run_off, n + 1, &b->allocs, &b->bytes));
@@ -594,6 +618,8 @@ int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stat
 			ctx->scratch_per_wave = ((uint64_t) c.scratch_needed + 4095) / 4096 * 4096;
 			if (0xFFFFFFFFu == c.scratch_needed)
 				return set_error(PVC3_E_NOMEM, "pvc3_dbatch_finish: an indel run needs more than 4 GiB of alignment scratch");
+			// ensure_scratch allocates one slot per wave of the striped kernel, and fewer waves when the slots are large, so the
+			// total stays within the budget (a slot larger than the budget gets one wave)
 			PVC3_TRY(ensure_scratch(ctx));
 		}
 		if (c.arena_overflow || c.runs_overflow)

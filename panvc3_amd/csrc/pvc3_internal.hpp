@@ -67,6 +67,30 @@ struct dev_batch_in
 	uint32_t const *mate_pos;
 };
 
+// ---- indel-run realignment ----------------------------------------------------------------------------------------
+// One work item per indel run that has both insertions and deletions (k_realign_scan writes them next to the pvc3_run of the
+// same index in the runs arena).  The alignment kernels leave the run's new operations in its slot of the CIGAR arena;
+// k_realign_splice puts the record's CIGAR together.
+struct run_work
+{
+	uint32_t rec;
+	uint32_t ref_loc;			// run start in destination coordinates (pvc3_run::ref_position is the position after the terminator)
+	uint32_t query_loc;
+	uint32_t m;					// reference bases (horizontal)
+	uint32_t n;					// query bases (vertical)
+	uint32_t n_out;				// operations produced by the alignment
+	uint32_t op_first, op_end;	// the run's operations in the rewritten CIGAR: [op_first, op_end)
+	uint64_t ops_loc;			// arena offset of the first produced operation
+	uint64_t splice_loc;		// first run of a record: arena space reserved for the record's final CIGAR
+};
+static_assert(48 == sizeof(run_work), "run_work layout");
+
+// Alignment classes: lanes per run W in {16, 32, 64} x orientation (0: lane = query row, 1: lane = reference column), plus the
+// runs that need the striped one-wave-per-run kernel (short side > 64 or more anti-diagonals than the LDS trace holds).
+constexpr uint32_t DP_CLASSES = 7;
+constexpr uint32_t DP_CLASS_BIG = 6;
+constexpr uint32_t DP_MAX_STEPS = 128;		// anti-diagonal steps of a packed alignment (long + short - 1)
+
 // Global counters of one projection attempt (zeroed before every launch sequence).
 struct dev_counters
 {
@@ -86,6 +110,8 @@ struct dev_counters
 	unsigned long long fast_bytes;		// algorithmic bytes of k_project_fast
 	unsigned long long n_mid;			// records finished by k_project_mid
 	unsigned long long general_bytes;	// algorithmic bytes of k_project_general (data the fast kernel had not read yet)
+	unsigned int dp_count[DP_CLASSES];	// indel runs per alignment class (k_realign_scan appends, the k_realign_dp launches consume)
+	unsigned int run_records;			// records with an indel run (sum of the per-region work lists, k_run_prefix)
 };
 
 // Per-record results before packing.  flags: bits 0-7 status, bit 8 = has at least one indel run.
@@ -108,6 +134,9 @@ struct dev_batch_work
 	uint32_t *slow_count;				// [waves of k_project_fast]
 	uint32_t *run_list;					// records with an indel run, same partition: k_project_mid appends, then k_project_general
 	uint32_t *run_count;				// [waves of k_project_fast]
+	uint32_t *run_prefix;				// [waves of k_project_fast + 1] exclusive prefix sums of run_count (k_run_prefix)
+	run_work *run_items;				// [runs_cap], parallel to runs_arena
+	uint32_t *dp_list;					// [DP_CLASSES][runs_cap] indices into run_items
 	unsigned long long *wave_stats;		// [3 kernels][waves][WAVE_STATS]: per-wave sums, folded into `counters` by k_reduce_stats
 	dev_counters *counters;
 };
@@ -146,7 +175,7 @@ struct dev_params
 int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream);
 int launch_project_mid(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
 int launch_project_general(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
-int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream);	// consumes run_list / run_count
+int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t big_waves, uint32_t lds_budget, uint32_t packed, void *stream);	// consumes run_list / run_count
 int launch_reduce_stats(uint64_t n, dev_batch_work const &work, void *stream);
 int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &packed, uint64_t *scan_tmp, void *stream);
 int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);

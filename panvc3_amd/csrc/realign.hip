@@ -1,13 +1,22 @@
-// realign.hip — local realignment of indel runs (the rare, compute-heavy leg of the hot path).
+// realign.hip — local realignment of indel runs (the compute-heavy leg of the hot path).
 //
-// One wavefront per flagged record.  Replays indel_run_checker (libpanvc3/indel_run_checker.cc:31-121) over the rewritten
-// CIGAR, realigns every run that has both insertions and deletions with a global affine alignment of the run's reference
-// slice against its query slice (include/panvc3/align.hh:59-112; seqan3::align_pairwise restated, see oracle/pvc3_oracle.c
-// for the recurrence and the traceback priority), splices the result (libpanvc3/alignment_projector.cc:58-148) and
-// merges adjacent equal operations (collapse_cigar_operations, libpanvc3/cigar.cc:13-51).
+// The records whose rewritten CIGAR holds an indel run come as per-region work lists (k_project_mid / k_project_general).
+// Five steps, all in record order of nothing: every step writes to places that only depend on the record or the run.
 //
-// DP: anti-diagonal wavefront, one lane per query row in stripes of 64 rows, fp64 adds / compares only (score tables are
-// computed on the host with libm), one trace byte per cell in LDS (or in the wave's global scratch slot for large runs).
+//   k_run_prefix      prefix sums of the per-region list lengths: the lists become one dense index space
+//   k_realign_scan    lane = record.  Replays indel_run_checker (libpanvc3/indel_run_checker.cc:31-121) over the rewritten
+//                     CIGAR; every run with both insertions and deletions becomes a pvc3_run (alignment_projector.cc:69-73)
+//                     and a work item, binned by the shape of its alignment
+//   k_realign_dp      lane = row (or column) of one run's alignment matrix, 4 / 2 / 1 runs per wavefront: global affine
+//                     alignment of the run's reference slice against its query slice (include/panvc3/align.hh:59-112;
+//                     seqan3::align_pairwise restated, see oracle/pvc3_oracle.c for the recurrence and the traceback
+//                     priority), anti-diagonal by anti-diagonal, fp64 adds / compares only (the score table comes from
+//                     the host's libm), four trace bits per cell in LDS, traceback by one lane per run
+//   k_realign_big     the same alignment for runs that do not fit the packed kernel: one run per wavefront, lane = query row
+//                     in stripes of 64 rows, trace bytes in LDS or in a global scratch slot
+//   k_realign_splice  lane = record.  Copies the untouched operations, splices the realigned runs
+//                     (alignment_projector.cc:58-148) and merges adjacent equal operations (collapse_cigar_operations,
+//                     libpanvc3/cigar.cc:13-51)
 #include <hip/hip_runtime.h>
 
 #include "pvc3_internal.hpp"
@@ -18,9 +27,11 @@ namespace pvc3 {
 
 namespace {
 
-constexpr uint32_t REALIGN_LDS_BYTES = 4096;		// per wave (= per block); larger alignments (beyond about 55 x 55) use the wave's global scratch slot
+constexpr uint32_t REALIGN_LDS_BYTES = 4096;		// k_realign_big, per wave (= per block); larger alignments use the wave's global scratch slot
 constexpr uint32_t TR_DIAG = 0, TR_UP = 1, TR_LEFT = 2, TR_DIR_MASK = 3, TR_V_OPEN = 4, TR_H_OPEN = 8, TR_MATCH = 16;
 constexpr uint32_t MAX_PHRED = 41;
+constexpr uint32_t NO_QUAL = MAX_PHRED + 1;			// row of the score table for records without base qualities: 0 / -1
+constexpr uint32_t SCORE_ROWS = NO_QUAL + 1;
 
 // seqan3::dna5 ranks (A C G N T); assign_char is case-insensitive, U -> T, anything else -> N.
 __device__ __forceinline__ uint32_t dna5_rank_of_char(uint32_t c)
@@ -32,11 +43,6 @@ __device__ __forceinline__ uint32_t dna5_rank_of_char(uint32_t c)
 __device__ __forceinline__ uint32_t dna5_rank_of_seq4(uint32_t code)
 {
 	return (1 == code) ? 0 : (2 == code) ? 1 : (4 == code) ? 2 : (8 == code) ? 4 : 3;
-}
-
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t lane)
-{
-	return ((uint64_t) readlane((uint32_t) (v >> 32), lane) << 32) | readlane((uint32_t) v, lane);
 }
 
 __device__ __forceinline__ uint32_t seq4_at(uint8_t const *seq4, uint32_t i)
@@ -55,19 +61,426 @@ __device__ __forceinline__ double shfl_up_f64(double v)
 	return r.d;
 }
 
+// Lane i of every row of 16 receives lane i - 1's value, the first lane of a row receives `first`: DPP row_shr:1.
+__device__ __forceinline__ double row_shr1_f64(double v, double first)
+{
+	union { double d; int i[2]; } a, f, r;
+	a.d = v; f.d = first;
+	r.i[0] = __builtin_amdgcn_update_dpp(f.i[0], a.i[0], 0x111, 0xf, 0xf, false);
+	r.i[1] = __builtin_amdgcn_update_dpp(f.i[1], a.i[1], 0x111, 0xf, 0xf, false);
+	return r.d;
+}
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- dense index space over the per-region work lists ---------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_run_prefix(uint32_t n_regions, dev_batch_work const W)
+{
+	__shared__ uint32_t lds[1024];
+	uint32_t const per = (n_regions + 1023) / 1024;
+	uint32_t const begin = threadIdx.x * per;
+	uint32_t sum = 0;
+	for (uint32_t i = begin; i < begin + per && i < n_regions; ++i)
+		sum += W.run_count[i];
+	lds[threadIdx.x] = sum;
+	__syncthreads();
+	for (uint32_t off = 1; off < 1024; off <<= 1)		// Hillis-Steele inclusive scan
+	{
+		uint32_t const t = (threadIdx.x >= off) ? lds[threadIdx.x - off] : 0;
+		__syncthreads();
+		lds[threadIdx.x] += t;
+		__syncthreads();
+	}
+	uint32_t run = lds[threadIdx.x] - sum;
+	for (uint32_t i = begin; i < begin + per && i < n_regions; ++i)
+	{
+		W.run_prefix[i] = run;
+		run += W.run_count[i];
+	}
+	if (1023 == threadIdx.x)
+	{
+		W.run_prefix[n_regions] = lds[1023];
+		W.counters->run_records = lds[1023];
+	}
+}
+
+// Record number `i` of the concatenated work lists.
+__device__ __forceinline__ uint32_t listed_record(dev_batch_work const &W, uint32_t n_regions, uint64_t n_groups, uint32_t i)
+{
+	uint32_t lo = 0, hi = n_regions;		// largest r with run_prefix[r] <= i (empty regions repeat a prefix: take the last)
+	while (hi - lo > 1)
+	{
+		uint32_t const mid = (lo + hi) >> 1;
+		if (W.run_prefix[mid] <= i) lo = mid; else hi = mid;
+	}
+	return W.run_list[64 * (n_groups * lo / n_regions) + (i - W.run_prefix[lo])];
+}
+
+// indel_run_checker (indel_run_checker.cc:13-121) over `n_ops` operations; calls on_run(first op, end op, reference start,
+// reference length, query start, query length, reference position at report time) for every run with both I and D.
+template <typename t_on_run>
+__device__ __forceinline__ void replay_runs(uint32_t const *ops, uint32_t n_ops, uint32_t dst_pos, t_on_run &&on_run)
+{
+	uint32_t ref_pos = dst_pos, query_pos = 0, run_type = 0;
+	uint32_t run_first = 0, run_ref_loc = dst_pos, run_query_loc = 0;
+	for (uint32_t x = 0; x <= n_ops; ++x)
+	{
+		bool const at_end = (x == n_ops);
+		uint32_t op = 0xf, cnt = 0;
+		if (!at_end)
+		{
+			uint32_t const c = ops[x];
+			op = c & 0xf; cnt = c >> 4;
+			if (0 == run_type) { run_ref_loc = ref_pos; run_query_loc = query_pos; run_first = x; }	// :45-50
+			if (OP_I == op) { query_pos += cnt; run_type |= 1; continue; }							// :62-65
+			if (OP_D == op) { ref_pos += cnt; run_type |= 2; continue; }							// :67-70
+		}
+		// A run-terminating operation (:55-60, :72-94) or the end of the CIGAR (:111-118).
+		uint32_t const prev_type = run_type;
+		uint32_t const run_ref_end = ref_pos, run_query_end = query_pos;
+		run_type = 0;
+		if (!at_end)
+		{
+			if (OP_S == op) query_pos += cnt;
+			else if (OP_N == op) ref_pos += cnt;
+			else if (OP_M == op || OP_EQ == op || OP_X == op) { ref_pos += cnt; query_pos += cnt; }
+		}
+		if (3 == prev_type)
+			on_run(run_first, x, run_ref_loc, run_ref_end - run_ref_loc, run_query_loc, run_query_end - run_query_loc, ref_pos);
+	}
+}
+
+__device__ __forceinline__ uint32_t dp_class_of(uint32_t m, uint32_t n, uint32_t packed)
+{
+	uint32_t const shorter = (m < n) ? m : n, longer = (m < n) ? n : m;
+	if (!packed || shorter > 64 || longer + shorter - 1 > DP_MAX_STEPS)
+		return DP_CLASS_BIG;
+	uint32_t const w = (shorter <= 16) ? 0 : (shorter <= 32) ? 1 : 2;
+	return 2 * w + ((m < n) ? 1 : 0);		// orientation 1: lanes along the reference (the shorter side)
+}
+
+__global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restrict__ entries, dev_batch_in const in, dev_batch_work const W, uint32_t n_regions, uint32_t packed)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const wave = rfl((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	uint32_t const n_waves = (gridDim.x * blockDim.x) >> 6;
+	uint64_t const n_groups = (in.n + 63) / 64;
+	uint32_t const total = W.run_prefix[n_regions];
+	arena_alloc arena{0, 0}, runs_alloc{0, 0};
+	uint32_t acc_runs = 0, acc_failed = 0;
+	uint64_t acc_qual = 0;
+
+	for (uint32_t base = 64 * wave; base < total; base += 64 * n_waves)
+	{
+		bool const mine = base + lane < total;
+		uint32_t rec = 0, n_ops = 0, dst_pos = 0, text_len = 0, l_seq = 0;
+		uint32_t const *ops = W.arena;
+		bool has_text = false, has_qual = false;
+		if (mine)
+		{
+			rec = listed_record(W, n_regions, n_groups, base + lane);
+			ops = W.arena + W.cig_loc[rec];
+			n_ops = W.cig_n[rec];
+			dst_pos = W.dst_pos[rec];
+			dev_entry const *de = entries + in.dst_entry[rec];
+			has_text = nullptr != de->text; text_len = de->text_len;
+			l_seq = in.l_seq[rec];
+			has_qual = (in.flags[rec] & PVC3_FLAG_HAS_QUAL) && in.qual;
+		}
+
+		// Pass 1: count the runs, the slots they need and check their ranges (alignment_projector.cc:76-137 slices both sequences).
+		uint32_t n3 = 0, slot_need = 0, status = PVC3_ST_OK;
+		replay_runs(ops, n_ops, dst_pos, [&](uint32_t, uint32_t, uint32_t r_loc, uint32_t m, uint32_t q_loc, uint32_t nq, uint32_t) {
+			if (status) return;
+			if (!has_text || (uint64_t) r_loc + m > text_len) { status = PVC3_ST_REF_RANGE; return; }
+			if ((uint64_t) q_loc + nq > l_seq) { status = PVC3_ST_QUERY_RANGE; return; }
+			++n3; slot_need += m + nq;
+		});
+		if (mine && status)
+		{
+			W.cig_n[rec] = 0; W.run_n[rec] = 0; W.dst_pos[rec] = 0;		// a rejected record has empty outputs
+			W.rec_flags[rec] = status;
+			++acc_failed;
+			n3 = 0; slot_need = 0;
+		}
+		// One piece of the arena per record: its final CIGAR has at most one operation per realigned base plus the untouched
+		// operations.  The runs' slots (m + n operations each, filled from their end by the alignment kernels) lie inside the same
+		// piece, run k behind the untouched operations that precede it and the slots of the runs before it: k_realign_splice writes
+		// the piece from its start and can never reach an operation of a run before it has read it.
+		uint32_t const need = (mine && !status && n3) ? (n_ops + slot_need + 1) : 0;
+		uint32_t const run_scan = wave_inclusive_scan(n3, lane), need_scan = wave_inclusive_scan(need, lane);
+		uint32_t const run_total = readlane(run_scan, 63), need_total = readlane(need_scan, 63);
+		uint64_t run_base = 0, arena_base = 0;
+		bool ok = true;
+		if (run_total) ok = runs_take(runs_alloc, run_total, W, lane, run_base);
+		if (need_total) ok = arena_take(arena, need_total, W, lane, arena_base) && ok;
+		if (!ok)
+			continue;		// the overflow flag is set; the host grows the arenas and repeats the batch
+
+		// Pass 2: the pvc3_run entries, the work items and the class lists.
+		uint64_t const my_runs = run_base + (run_scan - n3);
+		uint64_t const my_arena = arena_base + (need_scan - need);
+		uint32_t k = 0, slot = 0, run_ops = 0;
+		uint32_t cls[2] = {DP_CLASSES, DP_CLASSES};		// the first two runs of the lane go to the class lists wave-wide
+		if (mine && !status)
+		{
+			replay_runs(ops, n_ops, dst_pos, [&](uint32_t first, uint32_t end, uint32_t r_loc, uint32_t m, uint32_t q_loc, uint32_t nq, uint32_t ref_pos) {
+				pvc3_run rr;
+				rr.query_location = q_loc; rr.query_length = nq; rr.ref_position = ref_pos; rr.ref_length = m;		// alignment_projector.cc:69-73 (quirk Q7)
+				W.runs_arena[my_runs + k] = rr;
+				run_work it;
+				it.rec = rec; it.ref_loc = r_loc; it.query_loc = q_loc; it.m = m; it.n = nq; it.n_out = 0;
+				it.op_first = first; it.op_end = end;
+				it.ops_loc = my_arena + (first - run_ops) + slot;
+				it.splice_loc = my_arena;
+				W.run_items[my_runs + k] = it;
+				uint32_t const c = dp_class_of(m, nq, packed);
+				if (k < 2) cls[k] = c;
+				else
+				{
+					uint32_t const at = atomicAdd(&W.counters->dp_count[c], 1u);		// third and later runs of one record: rare
+					W.dp_list[(uint64_t) c * W.runs_cap + at] = (uint32_t) (my_runs + k);
+				}
+				slot += m + nq; run_ops += end - first; ++k;
+			});
+			W.run_loc[rec] = my_runs; W.run_n[rec] = n3;
+			acc_runs += n3;
+			acc_qual += has_qual ? l_seq : 0;
+		}
+#pragma unroll
+		for (uint32_t r = 0; r < 2; ++r)
+		{
+			if (0 == ballot(cls[r] < DP_CLASSES)) continue;
+			for (uint32_t c = 0; c < DP_CLASSES; ++c)
+			{
+				uint64_t const mk = ballot(cls[r] == c);
+				if (!mk) continue;
+				uint32_t at = 0;
+				if (0 == lane) at = atomicAdd(&W.counters->dp_count[c], popc64(mk));
+				at = rfl(at);
+				if ((mk >> lane) & 1) W.dp_list[(uint64_t) c * W.runs_cap + at + mbcnt64(mk)] = (uint32_t) (my_runs + r);
+			}
+		}
+	}
+	for (int off = 32; off; off >>= 1)
+	{
+		acc_runs += __shfl_xor(acc_runs, off);
+		acc_failed += __shfl_xor(acc_failed, off);
+		acc_qual += __shfl_xor(acc_qual, off);
+	}
+	if (0 == lane && acc_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) acc_failed);
+	if (0 == lane && acc_runs)
+	{
+		atomicAdd(&W.counters->n_runs, (unsigned long long) acc_runs);
+		atomicAdd(&W.counters->qual_bytes, (unsigned long long) acc_qual);
+	}
+}
+
+
+// ---- packed alignment: t_width lanes per run, 64 / t_width runs per wavefront ----------------------------------------------
+// Matrix M(i, j), i = 0..n over the query (vertical), j = 0..m over the reference (horizontal); V = best score ending in a
+// vertical gap (query base against nothing: 'I'), H = horizontal gap ('D').  A lane owns one line of the matrix along the
+// shorter side of the run (t_ref_lanes: a column j, otherwise a row i) and walks along the longer side, one cell per step,
+// lane l one step behind lane l - 1: every step computes one anti-diagonal.  What a cell needs from the neighbouring line
+// (its M and its gap score towards this line) arrives by DPP from lane l - 1; the line's own M and gap score stay in registers.
+struct dp_shared
+{
+	double score[SCORE_ROWS][2];					// [phred or NO_QUAL][0 match, 1 mismatch]
+	uint32_t trace[DP_MAX_STEPS / 8][64];			// 4 bits per cell: lane's nibble of step t in trace[t / 8][lane] at 4 (t % 8)
+	uint16_t stream[4][DP_MAX_STEPS];				// per run: the items along the longer side, dna5 rank | phred << 8
+};
+
+template <uint32_t t_width, bool t_ref_lanes>
+__global__ __launch_bounds__(64, 7) void k_realign_dp(
+	dev_entry const *__restrict__ entries, dev_batch_in const in, dev_batch_work const W, dev_params const *__restrict__ prm, uint32_t cls
+)
+{
+	constexpr uint32_t G = 64 / t_width;
+	__shared__ dp_shared S;
+	uint32_t const lane = lane_id();
+	uint32_t const g = lane / t_width, l = lane % t_width;
+	for (uint32_t i = lane; i < SCORE_ROWS; i += 64)
+	{
+		S.score[i][0] = (i <= MAX_PHRED) ? prm->s_match[i] : 0.0;		// NO_QUAL: nucleotide_scoring_scheme<> default 0 / -1
+		S.score[i][1] = (i <= MAX_PHRED) ? prm->s_mismatch[i] : -1.0;
+	}
+	double const open = (double) prm->gap_open, ge = (double) prm->gap_ext;
+	double const go = open + ge;						// seqan3's internal gap-open score = open + extension
+	double const bnd_step = (open > 0.0) ? go : ge;		// first row / column: x_1 = go, x_k = x_{k-1} + max(go, ge), ties keep the extension
+	double const neg_inf = -__builtin_inf();
+	uint32_t const count = W.counters->dp_count[cls];
+	uint32_t const *list = W.dp_list + (uint64_t) cls * W.runs_cap;
+	uint32_t const n_tasks = (count + G - 1) / G;
+
+	for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x)
+	{
+		wave_lds_fence();		// the previous task's LDS reads are done
+		uint32_t const slot_idx = task * G + g;
+		bool const have = slot_idx < count;
+		uint32_t const item_idx = have ? list[slot_idx] : 0;
+		run_work it{};
+		if (have) it = W.run_items[item_idx];
+		uint32_t const n_short = have ? (t_ref_lanes ? it.m : it.n) : 0;
+		uint32_t const n_long = have ? (t_ref_lanes ? it.n : it.m) : 0;
+		uint32_t const rec = it.rec;
+		uint8_t const *text = nullptr, *seq4 = in.seq4, *qual = nullptr;
+		if (have)
+		{
+			text = entries[in.dst_entry[rec]].text + it.ref_loc;
+			seq4 = in.seq4 + in.seq_off[rec];
+			if ((in.flags[rec] & PVC3_FLAG_HAS_QUAL) && in.qual) qual = in.qual + in.qual_off[rec];
+		}
+		auto query_item = [&](uint32_t idx) -> uint32_t {		// rank | phred << 8 of query base idx of the run
+			uint32_t const q = it.query_loc + idx;
+			uint32_t ph = NO_QUAL;
+			if (qual) { ph = qual[q]; ph = (ph > MAX_PHRED) ? MAX_PHRED : ph; }		// phred42 saturates
+			return dna5_rank_of_seq4(seq4_at(seq4, q)) | (ph << 8);
+		};
+		// The lane's own item (shorter side) and the run's stream (longer side).
+		uint32_t own = 3 | (NO_QUAL << 8);
+		if (l < n_short)
+			own = t_ref_lanes ? dna5_rank_of_char(text[l]) : query_item(l);
+		for (uint32_t x = l; x < n_long; x += t_width)
+			S.stream[g][x] = (uint16_t) (t_ref_lanes ? query_item(x) : dna5_rank_of_char(text[x]));
+		uint32_t const own_rank = own & 7, own_q = own >> 8;
+
+		uint32_t steps = have ? (n_long + n_short - 1) : 0;
+#pragma unroll
+		for (int off = 32; off; off >>= 1)
+		{
+			uint32_t const o = (uint32_t) __shfl_xor((int) steps, off);
+			steps = (o > steps) ? o : steps;
+		}
+		steps = rfl(steps);
+		wave_lds_fence();
+
+		// Line 0 of the matrix (the first row, or the first column) feeds lane 0 of the run: M = the boundary gap, gap score -inf.
+		// gap(k) = k * (open + ext) when the opening score is positive, open + k * ext otherwise (small integers: exact).
+		auto gap = [&](uint32_t k) -> double { return (0 == k) ? 0.0 : ((open > 0.0) ? (double) k * go : open + (double) k * ge); };
+		bool const line_ok = l < n_short;
+		double own_m = gap(l + 1), own_b = neg_inf;		// M and the along-the-line gap score of the cell before the first one
+		double diag = gap(l);
+		double cur_m = 0.0, cur_a = neg_inf;			// what the next lane receives: this line's M and its across-the-lines gap score
+		double bnd = 0.0;								// lane 0: gap(t + 1) while stepping
+		uint32_t acc = 0;
+		uint32_t item_next = S.stream[g][0];			// item of position 1 (index 0); lane l uses index t - l at step t
+		for (uint32_t t = 0; t < steps; ++t)
+		{
+			double nb_m, nb_a;
+			bnd = (0 == t) ? go : bnd + bnd_step;
+			if constexpr (16 == t_width)
+			{
+				nb_m = row_shr1_f64(cur_m, bnd);
+				nb_a = row_shr1_f64(cur_a, neg_inf);
+			}
+			else
+			{
+				nb_m = shfl_up_f64(cur_m);
+				nb_a = shfl_up_f64(cur_a);
+				if (0 == l) { nb_m = bnd; nb_a = neg_inf; }
+			}
+			uint32_t const pos = t - l + 1;				// 1-based position along the longer side handled in this step
+			bool const active = line_ok && (t >= l) && (pos <= n_long);
+			uint32_t const item = item_next;
+			{
+				uint32_t const nx = (t + 1 >= l) ? (t + 1 - l) : 0;
+				item_next = S.stream[g][(nx < DP_MAX_STEPS) ? nx : 0];
+			}
+			uint32_t nib = 0;
+			if (active)
+			{
+				bool const is_match = (item & 7) == own_rank;
+				uint32_t const qi = t_ref_lanes ? (item >> 8) : own_q;
+				double const s = S.score[qi][is_match ? 0 : 1];
+				double const a_open = nb_m + go, a_ext = nb_a + ge;
+				double a; bool a_opened;
+				if (a_ext < a_open) { a = a_open; a_opened = true; } else { a = a_ext; a_opened = false; }
+				double const b_open = own_m + go, b_ext = own_b + ge;
+				double b; bool b_opened;
+				if (b_ext < b_open) { b = b_open; b_opened = true; } else { b = b_ext; b_opened = false; }
+				// lanes along the query: a = V (from the row above), b = H; lanes along the reference: a = H (from the column to the left), b = V
+				double const v = t_ref_lanes ? b : a, h = t_ref_lanes ? a : b;
+				bool const v_opened = t_ref_lanes ? b_opened : a_opened, h_opened = t_ref_lanes ? a_opened : b_opened;
+				double best = diag + s;
+				uint32_t state = is_match ? 0u : 1u;		// 0 diagonal match, 1 diagonal mismatch, 2 up, 3 left
+				if (best < v) { best = v; state = 2; }
+				if (best < h) { best = h; state = 3; }
+				nib = state | (v_opened ? 4u : 0u) | (h_opened ? 8u : 0u);
+				own_m = best; own_b = b; cur_m = best; cur_a = a; diag = nb_m;
+			}
+			acc |= nib << (4 * (t & 7));
+			if (7 == (t & 7) || t + 1 == steps)
+			{
+				S.trace[t >> 3][lane] = acc;
+				acc = 0;
+			}
+		}
+		wave_lds_fence();
+
+		// Traceback (trace_iterator_base) by the first lane of every run: diagonal > up > left where the direction is decided; a
+		// gap continues until the cell whose gap score was formed by opening.  Cell (i, j) was computed in step i + j - 2 by the
+		// lane of its line.  The operations come out last to first and are written run-length from the end of the run's slot.
+		if (have && 0 == l)
+		{
+			uint32_t *slot_end = W.arena + it.ops_loc + (it.m + it.n);
+			uint32_t n_out = 0, cur_op = 0xf, cur_cnt = 0;
+			auto emit = [&](uint32_t op) {
+				if (op == cur_op) { ++cur_cnt; return; }
+				if (cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
+				cur_op = op; cur_cnt = 1;
+			};
+			uint32_t i = it.n, j = it.m, st = 0;		// st: 0 = M, 1 = V (up), 2 = H (left)
+			while (i || j)
+			{
+				uint32_t nibble;
+				if (0 == i) nibble = 3 | ((1 == j) ? 8u : 0u);			// first row: left, opened at column 1
+				else if (0 == j) nibble = 2 | ((1 == i) ? 4u : 0u);		// first column
+				else
+				{
+					uint32_t const t = i + j - 2;
+					uint32_t const ln = g * t_width + (t_ref_lanes ? j : i) - 1;
+					nibble = (S.trace[t >> 3][ln] >> (4 * (t & 7))) & 0xf;
+				}
+				if (0 == st)
+				{
+					uint32_t const state = nibble & 3;
+					if (state < 2)
+					{
+						emit(state ? OP_X : OP_EQ);		// align.hh:103-106
+						--i; --j;
+						continue;
+					}
+					st = (2 == state) ? 1 : 2;
+				}
+				if (1 == st) { emit(OP_I); if (nibble & 4) st = 0; --i; }
+				else { emit(OP_D); if (nibble & 8) st = 0; --j; }
+			}
+			if (cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
+			W.run_items[item_idx].n_out = n_out;
+			W.run_items[item_idx].ops_loc = it.ops_loc + (it.m + it.n) - n_out;
+		}
+	}
+}
+
+
+// ---- striped alignment, one run per wavefront (runs that do not fit the packed kernel) --------------------------------------
 struct dp_memory
 {
 	double *col_m;		// M(i, 0), i = 0..n
 	double *bnd_m;		// M(i0, j), j = 0..m   (row above the current stripe)
 	double *bnd_v;		// V(i0, j)
 	uint8_t *trace;		// n * m bytes
-	uint8_t *rev;		// m + n bytes
 	uint8_t *ref_rank;	// m bytes: dna5 ranks of the reference slice
 };
 
 __device__ __forceinline__ uint64_t dp_bytes(uint32_t m, uint32_t n)
 {
-	return 8ull * (n + 1) + 16ull * (m + 1) + (uint64_t) m * n + (m + n) + m + 8;
+	return 8ull * (n + 1) + 16ull * (m + 1) + (uint64_t) m * n + m + 8;
 }
 
 __device__ __forceinline__ dp_memory dp_carve(uint8_t *base, uint32_t m, uint32_t n)
@@ -77,13 +490,10 @@ __device__ __forceinline__ dp_memory dp_carve(uint8_t *base, uint32_t m, uint32_
 	d.bnd_m = d.col_m + (n + 1);
 	d.bnd_v = d.bnd_m + (m + 1);
 	d.trace = (uint8_t *) (d.bnd_v + (m + 1));
-	d.rev = d.trace + (uint64_t) m * n;
-	d.ref_rank = d.rev + (m + n);
+	d.ref_rank = d.trace + (uint64_t) m * n;
 	return d;
 }
 
-// Global affine alignment of ref[0, m) (horizontal) against query bases [q0, q0 + n) (vertical); pushes the resulting
-// operations into `out`.  All control flow is wave-uniform.
 struct dp_scores
 {
 	double open, ext;			// pvc3_params gap costs
@@ -91,17 +501,17 @@ struct dp_scores
 	double const *mismatch;
 };
 
-__device__ __forceinline__ void align_global(
+// Global affine alignment of ref[0, m) (horizontal) against query bases [q0, q0 + n) (vertical); writes the operations
+// run-length, last to first, below `slot_end` and returns their number.  All control flow is wave-uniform.
+__device__ __forceinline__ uint32_t align_global_striped(
 	uint8_t const *ref, uint32_t m, uint8_t const *seq4, uint32_t q0, uint32_t n, uint8_t const *qual /* or nullptr */,
-	dp_scores const &sc, dp_memory const mem, sink &out, uint32_t lane
+	dp_scores const &sc, dp_memory const mem, uint32_t *slot_end, uint32_t lane
 )
 {
 	double const go = sc.open + sc.ext;	// seqan3's internal gap-open score = open + extension
 	double const ge = sc.ext;
 	double const neg_inf = -__builtin_inf();
 
-	// Query base and scores of a lane's row in the stripe starting at i0.  Called for the first stripe before the reference
-	// slice is fetched, so that the two global round trips overlap.
 	auto load_row = [&](uint32_t i0, uint32_t &q_rank, double &s_match, double &s_mismatch) {
 		q_rank = 3; s_match = 0.0; s_mismatch = -1.0;			// nucleotide_scoring_scheme<> default: 0 / -1
 		if (i0 + lane < n)
@@ -119,7 +529,6 @@ __device__ __forceinline__ void align_global(
 	uint32_t q_rank0; double s_match0, s_mismatch0;
 	load_row(0, q_rank0, s_match0, s_mismatch0);
 
-	// Reference slice -> dna5 ranks, once (a global load per DP step would put an HBM round trip on the critical path).
 	for (uint32_t j = lane; j < m; j += 64)
 		mem.ref_rank[j] = (uint8_t) dna5_rank_of_char(ref[j]);
 
@@ -136,9 +545,7 @@ __device__ __forceinline__ void align_global(
 			if (k <= m) { mem.bnd_m[k] = x; mem.bnd_v[k] = neg_inf; }
 		}
 	}
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	wave_lds_fence();
 
 	for (uint32_t i0 = 0; i0 < n; i0 += 64)
 	{
@@ -183,14 +590,17 @@ __device__ __forceinline__ void align_global(
 				if (lane == nr - 1) { mem.bnd_m[j] = best; mem.bnd_v[j] = v; }
 			}
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		wave_lds_fence();
 	}
 
 	// Traceback (trace_iterator_base): diagonal > up > left where the direction is decided; a gap continues until the
-	// cell whose gap score was formed by opening.
-	uint32_t k = 0;
+	// cell whose gap score was formed by opening.  Wave-uniform; the stores are uniform too.
+	uint32_t n_out = 0, cur_op = 0xf, cur_cnt = 0;
+	auto emit = [&](uint32_t op) {
+		if (op == cur_op) { ++cur_cnt; return; }
+		if (cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
+		cur_op = op; cur_cnt = 1;
+	};
 	{
 		uint32_t i = n, j = m;
 		uint32_t st = 0;	// 0 = M, 1 = V (up), 2 = H (left)
@@ -206,41 +616,22 @@ __device__ __forceinline__ void align_global(
 				uint32_t const dir = t & TR_DIR_MASK;
 				if (TR_DIAG == dir)
 				{
-					mem.rev[k] = (uint8_t) ((t & TR_MATCH) ? OP_EQ : OP_X);		// align.hh:103-106; wave-uniform stores
-					++k; --i; --j;
+					emit((t & TR_MATCH) ? OP_EQ : OP_X);		// align.hh:103-106
+					--i; --j;
 					continue;
 				}
 				st = (TR_UP == dir) ? 1 : 2;
 			}
-			if (1 == st)
-			{
-				mem.rev[k] = (uint8_t) OP_I;
-				++k;
-				if (t & TR_V_OPEN) st = 0;
-				--i;
-			}
-			else
-			{
-				mem.rev[k] = (uint8_t) OP_D;
-				++k;
-				if (t & TR_H_OPEN) st = 0;
-				--j;
-			}
+			if (1 == st) { emit(OP_I); if (t & TR_V_OPEN) st = 0; --i; }
+			else { emit(OP_D); if (t & TR_H_OPEN) st = 0; --j; }
 		}
 	}
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-	for (uint32_t x = k; x > 0; --x)
-		out.push(rfl(mem.rev[x - 1]), 1, lane);		// align.hh:94-108 through cigar_buffer
+	if (cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
+	return n_out;
 }
 
-// One record at a time per wave is bound by the latency of that record's dependent steps, so the kernel wants as many
-// resident waves as the CU has slots: 64 VGPRs (a few spills) and 4 KB of LDS give 8 per SIMD; on C5 that is 17.6 ms
-// against 22.5 ms with 86 VGPRs / 8 KB / 5 waves per SIMD.
-__global__ __launch_bounds__(64, 8) void k_realign(
-	dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W,
-	dev_params const *__restrict__ prm, uint32_t lds_budget, uint32_t n_regions
+__global__ __launch_bounds__(64, 8) void k_realign_big(
+	dev_entry const *__restrict__ entries, dev_batch_in const in, dev_batch_work const W, dev_params const *__restrict__ prm, uint32_t lds_budget
 )
 {
 	__shared__ __attribute__((aligned(16))) uint8_t lds[REALIGN_LDS_BYTES];
@@ -250,207 +641,92 @@ __global__ __launch_bounds__(64, 8) void k_realign(
 	dp_scores sc;
 	sc.open = (double) prm->gap_open; sc.ext = (double) prm->gap_ext;
 	sc.match = lds_scores; sc.mismatch = lds_scores + (MAX_PHRED + 1);
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-	uint32_t const wave = blockIdx.x;
-	uint32_t const n_waves = gridDim.x;
-	arena_alloc arena{0, 0}, runs_alloc{0, 0};
-	uint32_t total_runs = 0, n_failed = 0, touched = 0;
-	uint64_t qual_bytes = 0;
-
-	// The records with indel runs come as per-region work lists (region = the record range of one wave of the projection
-	// kernels, filled by k_project_mid and k_project_general); every wave takes a contiguous range of regions and walks each
-	// list 64 entries at a time.  (Scanning the flags of all records instead cost more than half of this kernel on C3.)
-	uint64_t const n_groups = (in.n + 63) / 64;
-	uint32_t const r_begin = (uint32_t) ((uint64_t) n_regions * wave / n_waves), r_end = (uint32_t) ((uint64_t) n_regions * (wave + 1) / n_waves);
-	for (uint32_t region = r_begin; region < r_end; ++region)
-	for (uint32_t chunk = 0, cnt = rfl(W.run_count[region]); chunk < cnt; chunk += 64)
+	wave_lds_fence();
+	uint32_t const count = W.counters->dp_count[DP_CLASS_BIG];
+	uint32_t const *list = W.dp_list + (uint64_t) DP_CLASS_BIG * W.runs_cap;
+	for (uint32_t task = blockIdx.x; task < count; task += gridDim.x)
 	{
-		uint32_t const *list = W.run_list + 64 * (n_groups * region / n_regions);
-		bool const mine = chunk + lane < cnt;
-		uint32_t const v_rec = mine ? list[chunk + lane] : 0;
-		uint64_t todo = ballot(mine);
-
-		// Descriptors of the marked records, lane-parallel.
-		uint64_t v_loc = 0, v_seq_off = 0, v_qual_off = 0, v_text = 0;
-		uint32_t v_n = 0, v_dst_pos = 0, v_text_len = 0, v_l_seq = 0, v_has_qual = 0;
-		if (mine)
+		uint32_t const item_idx = rfl(list[task]);
+		run_work const it = W.run_items[item_idx];
+		uint32_t const rec = rfl(it.rec), m = rfl(it.m), nq = rfl(it.n), q_loc = rfl(it.query_loc), r_loc = rfl(it.ref_loc);
+		uint64_t const ops_loc = rfl64(it.ops_loc);
+		uint8_t const *text = rfl_ptr(entries[in.dst_entry[rec]].text) + r_loc;
+		uint8_t const *seq4 = in.seq4 + rfl64(in.seq_off[rec]);
+		uint8_t const *qual = ((rfl(in.flags[rec]) & PVC3_FLAG_HAS_QUAL) && in.qual) ? (in.qual + rfl64(in.qual_off[rec])) : nullptr;
+		uint32_t *slot_end = W.arena + ops_loc + (m + nq);
+		uint64_t const need = dp_bytes(m, nq);
+		uint32_t n_out;
+		wave_lds_fence();
+		if (need <= lds_budget)
 		{
-			uint64_t const r = v_rec;
-			v_loc = W.cig_loc[r]; v_n = W.cig_n[r]; v_dst_pos = W.dst_pos[r];
-			dev_entry const *de = entries + in.dst_entry[r];
-			v_text = (uint64_t) de->text; v_text_len = de->text_len;
-			v_seq_off = in.seq_off[r]; v_l_seq = in.l_seq[r];
-			v_has_qual = ((in.flags[r] & PVC3_FLAG_HAS_QUAL) && in.qual) ? 1 : 0;
-			if (v_has_qual) v_qual_off = in.qual_off[r];
+			// Separate call site: after inlining every access is provably to LDS (ds_read / ds_write instead of flat_*).
+			n_out = align_global_striped(text, m, seq4, q_loc, nq, qual, sc, dp_carve(lds, m, nq), slot_end, lane);
 		}
-
-		// Touch what the records of this chunk will read (operations, text around the projected position, SEQ, QUAL), one
-		// record per lane, all at once: the records are then walked one after the other with warm caches and TLBs instead of
-		// paying a full miss at every dependent step.  The values only keep the loads alive.
-		if (mine)
+		else
 		{
-			uint32_t const *o = W.arena + v_loc;
-			touched ^= o[0];
-			if (v_n > 16) touched ^= o[16];
-			if (v_text)
+			if (need > W.scratch_per_wave)
 			{
-				uint8_t const *t = (uint8_t const *) v_text + v_dst_pos;		// texts carry TEXT_PAD readable bytes past their end
-				touched ^= (uint32_t) t[0] ^ (uint32_t) t[64] ^ (uint32_t) t[128] ^ (uint32_t) t[192];
-			}
-			uint8_t const *q = in.seq4 + v_seq_off;
-			touched ^= (uint32_t) q[0] ^ (uint32_t) q[(v_l_seq + 1) / 2 - 1];
-			if (v_has_qual)
-			{
-				uint8_t const *qq = in.qual + v_qual_off;
-				touched ^= (uint32_t) qq[0] ^ (uint32_t) qq[v_l_seq / 2] ^ (uint32_t) qq[v_l_seq - 1];
-			}
-		}
-
-		// The first 64 operations of a record live in lanes; those of the next marked record are fetched while this one is processed.
-		auto load_ops = [&](uint32_t r) -> uint32_t { return (lane < readlane(v_n, r)) ? (W.arena + readlane64(v_loc, r))[lane] : 0; };
-		uint32_t opv_next = load_ops(ctz64(todo));
-		while (todo)
-		{
-			uint32_t const ri = ctz64(todo);
-			uint64_t const rec = readlane(v_rec, ri);
-			todo &= todo - 1;
-			uint32_t const opv = opv_next;
-			if (todo) opv_next = load_ops(ctz64(todo));
-
-			uint32_t const *ops = W.arena + readlane64(v_loc, ri);
-			uint32_t const n_ops = readlane(v_n, ri);
-			uint32_t const dst_pos = readlane(v_dst_pos, ri);
-			uint8_t const *d_text = (uint8_t const *) readlane64(v_text, ri);
-			uint32_t const d_text_len = readlane(v_text_len, ri);
-			uint8_t const *seq4 = in.seq4 + readlane64(v_seq_off, ri);
-			uint32_t const l_seq = readlane(v_l_seq, ri);
-			uint8_t const *qual = readlane(v_has_qual, ri) ? (in.qual + readlane64(v_qual_off, ri)) : nullptr;
-
-			// Upper bounds: every run of total length m + n yields at most m + n operations.
-			uint32_t indel_total = 0, n_indel_ops = 0;
-			for (uint32_t x = lane; x < n_ops; x += 64)
-			{
-				uint32_t const c = (x < 64) ? opv : ops[x];
-				uint32_t const op = c & 0xf;
-				if (OP_I == op || OP_D == op) { indel_total += c >> 4; ++n_indel_ops; }
-			}
-			for (int off = 32; off; off >>= 1)
-			{
-				indel_total += __shfl_xor(indel_total, off);
-				n_indel_ops += __shfl_xor(n_indel_ops, off);
-			}
-			indel_total = rfl(indel_total); n_indel_ops = rfl(n_indel_ops);
-
-			uint64_t out_loc = 0, runs_loc = 0;
-			bool ok = arena_take(arena, n_ops + indel_total + 1, W, lane, out_loc);
-			ok = ok && runs_take(runs_alloc, n_indel_ops / 2 + 1, W, lane, runs_loc);
-			if (!ok)
-				continue;	// the overflow flag is set; the host grows the arenas and repeats the batch
-
-			sink out;
-			out.init();
-			out.spill = W.arena + out_loc;
-			pvc3_run *runs = W.runs_arena + runs_loc;
-			uint32_t n_runs = 0;
-			uint32_t status = PVC3_ST_OK;
-
-			// indel_run_checker state (indel_run_checker.cc:13-21)
-			uint32_t ref_pos = dst_pos, query_pos = 0, run_type = 0;
-			uint32_t run_first = 0, run_ref_loc = dst_pos, run_query_loc = 0;
-
-			for (uint32_t x = 0; x <= n_ops && !status; ++x)
-			{
-				bool const at_end = (x == n_ops);
-				uint32_t op = 0xf, cnt = 0;
-				if (!at_end)
-				{
-					uint32_t const c = (x < 64) ? readlane(opv, x) : rfl(ops[x]);
-					op = c & 0xf; cnt = c >> 4;
-					if (0 == run_type) { run_ref_loc = ref_pos; run_query_loc = query_pos; run_first = x; }	// :45-50
-					if (OP_I == op) { query_pos += cnt; run_type |= 1; continue; }							// :62-65
-					if (OP_D == op) { ref_pos += cnt; run_type |= 2; continue; }							// :67-70
-				}
-				// A run-terminating operation (:55-60, :72-94) or the end of the CIGAR (:111-118).
-				uint32_t const prev_type = run_type;
-				uint32_t const run_ref_end = ref_pos, run_query_end = query_pos;
-				run_type = 0;
-				if (!at_end)
-				{
-					if (OP_S == op) query_pos += cnt;
-					else if (OP_N == op) ref_pos += cnt;
-					else if (OP_M == op || OP_EQ == op || OP_X == op) { ref_pos += cnt; query_pos += cnt; }
-				}
-				if (3 == prev_type)
-				{
-					uint32_t const m = run_ref_end - run_ref_loc, nq = run_query_end - run_query_loc;
-					// alignment_projector.cc:69-73: reference_position() already includes the terminating operation.
-					{
-						pvc3_run rr;		// wave-uniform store
-						rr.query_location = run_query_loc; rr.query_length = nq; rr.ref_position = ref_pos; rr.ref_length = m;
-						runs[n_runs] = rr;
-					}
-					++n_runs;
-					if (!d_text || (uint64_t) run_ref_loc + m > d_text_len) { status = PVC3_ST_REF_RANGE; break; }
-					if ((uint64_t) run_query_loc + nq > l_seq) { status = PVC3_ST_QUERY_RANGE; break; }
-
-					uint64_t const need = dp_bytes(m, nq);
-					if (need <= lds_budget)
-					{
-						// Separate call site: after inlining every access is provably to LDS (ds_read / ds_write instead of flat_*).
-						align_global(d_text + run_ref_loc, m, seq4, run_query_loc, nq, qual, sc, dp_carve(lds, m, nq), out, lane);
-					}
-					else
-					{
-						if (need > W.scratch_per_wave)
-						{
-							atomicMax(&W.counters->scratch_needed, (unsigned int) ((need > 0xFFFFFFFFull) ? 0xFFFFFFFFu : need));	// idempotent
-							W.counters->scratch_overflow = 1;
-							status = 0xff;	// not a record status: the host grows the scratch and repeats
-							break;
-						}
-						align_global(d_text + run_ref_loc, m, seq4, run_query_loc, nq, qual, sc, dp_carve(W.scratch + (uint64_t) wave * W.scratch_per_wave, m, nq), out, lane);
-					}
-				}
-				else if (prev_type)
-				{
-					for (uint32_t y = run_first; y < x; ++y)	// single-type run: copied as is (alignment_projector.cc:61-65)
-					{
-						uint32_t const c = (y < 64) ? readlane(opv, y) : rfl(ops[y]);
-						out.push(c & 0xf, c >> 4, lane);
-					}
-				}
-				if (!at_end)
-					out.push(op, cnt, lane);
-			}
-			out.finish(lane);
-
-			if (0xff == status)
+				atomicMax(&W.counters->scratch_needed, (unsigned int) ((need > 0xFFFFFFFFull) ? 0xFFFFFFFFu : need));	// idempotent
+				W.counters->scratch_overflow = 1;		// the host grows the scratch and repeats the batch
 				continue;
-			// Wave-uniform stores (every lane writes the same values).
-			if (status)
-			{
-				W.cig_n[rec] = 0; W.run_n[rec] = 0; W.dst_pos[rec] = 0;
-				W.rec_flags[rec] = status;
-				++n_failed;
 			}
-			else
-			{
-				W.cig_loc[rec] = out_loc; W.cig_n[rec] = out.n_out;
-				W.run_loc[rec] = runs_loc; W.run_n[rec] = n_runs;
-			}
-			if (!status) { total_runs += n_runs; qual_bytes += qual ? l_seq : 0; }
+			n_out = align_global_striped(text, m, seq4, q_loc, nq, qual, sc, dp_carve(W.scratch + (uint64_t) blockIdx.x * W.scratch_per_wave, m, nq), slot_end, lane);
 		}
+		// wave-uniform stores
+		W.run_items[item_idx].n_out = n_out;
+		W.run_items[item_idx].ops_loc = ops_loc + (m + nq) - n_out;
 	}
-	if (0xA5A5A5A5u == touched && 0xFFFFFFFFu == n_failed)		// never true: keeps the touch loads
-		W.counters->scratch_needed = touched;
-	if (0 == lane && n_failed)
-		atomicAdd(&W.counters->n_failed, (unsigned long long) n_failed);
-	if (0 == lane && total_runs)
+}
+
+
+// ---- splice -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_realign_splice(dev_batch_in const in, dev_batch_work const W, uint32_t n_regions)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const wave = rfl((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	uint32_t const n_waves = (gridDim.x * blockDim.x) >> 6;
+	uint64_t const n_groups = (in.n + 63) / 64;
+	uint32_t const total = W.run_prefix[n_regions];
+	for (uint32_t base = 64 * wave; base < total; base += 64 * n_waves)
 	{
-		atomicAdd(&W.counters->n_runs, (unsigned long long) total_runs);
-		atomicAdd(&W.counters->qual_bytes, (unsigned long long) qual_bytes);
+		if (base + lane >= total) continue;
+		uint32_t const rec = listed_record(W, n_regions, n_groups, base + lane);
+		uint32_t const n_runs = W.run_n[rec];
+		if (0 == n_runs || (W.rec_flags[rec] & REC_STATUS_MASK))
+			continue;		// rejected by k_realign_scan (or left out by an arena overflow: the batch is repeated)
+		uint32_t const *ops = W.arena + W.cig_loc[rec];
+		uint32_t const n_ops = W.cig_n[rec];
+		run_work const *items = W.run_items + W.run_loc[rec];
+		uint64_t const out_loc = items[0].splice_loc;
+		uint32_t *out = W.arena + out_loc;
+		// cigar_buffer (cigar.cc:54-95); the rewritten CIGAR has no zero counts and neither have the alignments.
+		uint32_t n_out = 0, cur_op = 0xf, cur_cnt = 0;
+		auto push = [&](uint32_t c) {
+			uint32_t const op = c & 0xf, cnt = c >> 4;
+			if (op == cur_op) { cur_cnt += cnt; return; }
+			if (cur_cnt) out[n_out++] = (cur_cnt << 4) | cur_op;
+			cur_op = op; cur_cnt = cnt;
+		};
+		uint32_t k = 0;
+		uint32_t next_first = items[0].op_first;
+		for (uint32_t x = 0; x < n_ops; )
+		{
+			if (x == next_first)		// alignment_projector.cc:140-141: the run's operations are replaced by its alignment
+			{
+				run_work const it = items[k];
+				uint32_t const *src = W.arena + it.ops_loc;
+				for (uint32_t y = 0; y < it.n_out; ++y) push(src[y]);
+				x = it.op_end;
+				++k;
+				next_first = (k < n_runs) ? items[k].op_first : 0xFFFFFFFFu;
+				continue;
+			}
+			push(ops[x]);				// :61-65, :145-148
+			++x;
+		}
+		if (cur_cnt) out[n_out++] = (cur_cnt << 4) | cur_op;
+		W.cig_loc[rec] = out_loc;
+		W.cig_n[rec] = n_out;
 	}
 }
 
@@ -458,13 +734,26 @@ __global__ __launch_bounds__(64, 8) void k_realign(
 
 uint32_t realign_lds_bytes() { return REALIGN_LDS_BYTES; }
 
-int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t lds_budget, void *stream)
+int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t big_waves, uint32_t lds_budget, uint32_t packed, void *stream)
 {
 	if (0 == in.n) return 0;
+	(void) n_entries;
 	if (lds_budget > REALIGN_LDS_BYTES) lds_budget = REALIGN_LDS_BYTES;
 	uint32_t const n_regions = project_wave_count(in.n);		// one work list per wave of the projection kernels
-	if (n_waves > n_regions) n_waves = n_regions;
-	hipLaunchKernelGGL(k_realign, dim3(n_waves), dim3(64), 0, (hipStream_t) stream, entries, n_entries, in, work, params, lds_budget, n_regions);
+	hipStream_t const s = (hipStream_t) stream;
+	uint32_t const list_blocks = (n_regions + 3) / 4 < 2048 ? (n_regions + 3) / 4 : 2048;
+	hipLaunchKernelGGL(k_run_prefix, dim3(1), dim3(1024), 0, s, n_regions, work);
+	hipLaunchKernelGGL(k_realign_scan, dim3(list_blocks), dim3(256), 0, s, entries, in, work, n_regions, packed);
+	if (n_waves < 1) n_waves = 1;
+	hipLaunchKernelGGL((k_realign_dp <16, false>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 0u);
+	hipLaunchKernelGGL((k_realign_dp <16, true>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 1u);
+	hipLaunchKernelGGL((k_realign_dp <32, false>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 2u);
+	hipLaunchKernelGGL((k_realign_dp <32, true>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 3u);
+	hipLaunchKernelGGL((k_realign_dp <64, false>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 4u);
+	hipLaunchKernelGGL((k_realign_dp <64, true>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 5u);
+	if (big_waves < 1) big_waves = 1;
+	hipLaunchKernelGGL(k_realign_big, dim3(big_waves), dim3(64), 0, s, entries, in, work, params, lds_budget);
+	hipLaunchKernelGGL(k_realign_splice, dim3(list_blocks), dim3(256), 0, s, in, work, n_regions);
 	return (int) hipGetLastError();
 }
 

@@ -23,8 +23,9 @@ def oracle_mod():
 
 # Which projection kernels the GPU tests send the records through.  "default" is the product configuration (lane-parallel
 # fast path, then the lane-per-record walk, then the cooperative column walk for what is left); the other two force every
-# record through one of the slower kernels so that each of them is compared with the oracle on every test input.
-PATH_MODES = {"default": {}, "mid_only": {"fast_path": 0}, "walk_only": {"fast_path": 0, "mid_path": 0}}
+# record through one of the slower kernels so that each of them is compared with the oracle on every test input
+# ("walk_only" also sends every indel run through the striped alignment kernel instead of the packed ones).
+PATH_MODES = {"default": {}, "mid_only": {"fast_path": 0}, "walk_only": {"fast_path": 0, "mid_path": 0, "packed_dp": 0}}
 
 
 @pytest.fixture(scope="module", params=list(PATH_MODES))

@@ -290,7 +290,7 @@ def test_workspace_growth_and_scratch_paths(pvc3, oracle_mod, synth):
 	base, stats0, ctx, o = _run_both(pvc3, oracle_mod, genome, batch)
 	index = pvc3.Index()
 	genome.fill_index(index)
-	for opts in (dict(arena_initial=1000), dict(runs_initial=3), dict(realign_lds_bytes=64), dict(realign_lds_bytes=64, scratch_per_wave=512), dict(realign_waves=3), dict(fast_path=0)):
+	for opts in (dict(arena_initial=1000), dict(runs_initial=3), dict(realign_lds_bytes=64, packed_dp=0), dict(realign_lds_bytes=64, scratch_per_wave=512, packed_dp=0), dict(realign_waves=3), dict(big_waves=2, packed_dp=0), dict(packed_dp=1), dict(fast_path=0)):
 		c2 = pvc3.Context(0)
 		for k, v in opts.items():
 			c2.set_option(k, v)
@@ -360,18 +360,22 @@ def test_project_positions(pvc3, oracle_mod, synth):
 	assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("name", ["C3", "C5"])
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
 def test_full_size_properties(pvc3, oracle_mod, synth, name):
 	"""BASELINE.json configs[2] and configs[4] at full size (20 M pairs, 8 founders, 1 Gbp; 2x150 and 2x250 bp with long
-	indels): size-independent properties + sampled oracle parity."""
+	indels) and one GPU's shard of configs[3] (200 M pairs over 8 GPUs = 50 M records per GPU, as bench.py --config C4
+	generates it): size-independent properties + sampled oracle parity."""
 	if "default" != pvc3.paths_mode:
 		pytest.skip("full size is run in the product configuration only")
 	gp, rp, desc = synth.config(name)
+	if "C4" == name:
+		rp.n_records //= 8
+		rp.seed += 3000		# the shard of rank 3
 	genome = synth.Genome(gp)
 	reads = synth.Reads(genome, rp)
 	batch = reads.batch()
 	n = reads.n
-	assert n == 40_000_000
+	assert n == (50_000_000 if "C4" == name else 40_000_000)
 	index = pvc3.Index()
 	genome.fill_index(index)
 	ctx = pvc3.Context(0)
@@ -415,3 +419,72 @@ def test_full_size_properties(pvc3, oracle_mod, synth, name):
 			assert_results_equal(sample, g2, o.batch_project(sample, n_threads=16))
 		d2.close()
 	assert total == whole
+
+
+def test_indel_run_shapes_and_gap_scores(pvc3, oracle_mod):
+	"""One indel run of m reference bases against n query bases for every packing shape of the alignment kernels (16 / 32 / 64
+	lanes per run, lanes along the query or along the reference, the striped kernel beyond 64 x ... or 128 anti-diagonals),
+	with related and unrelated slices (co-optimal paths), mixed base qualities, N bases, lower-case reference text, records
+	without qualities, and gap scores with a positive, zero and negative opening score (open + extension > 0, == 0, < 0)."""
+	rng = np.random.default_rng(77)
+	seg = lambda k: "".join("ACGT"[x] for x in rng.integers(0, 4, size=k))
+	shapes = [(1, 1), (1, 16), (16, 1), (16, 16), (17, 5), (5, 17), (15, 40), (40, 15), (16, 113), (113, 16), (17, 17), (32, 32), (32, 60),
+			  (60, 32), (33, 32), (32, 33), (33, 33), (64, 64), (64, 65), (65, 64), (40, 64), (64, 40), (65, 10), (10, 65), (100, 20), (20, 100),
+			  (100, 29), (100, 30), (30, 100), (120, 9), (9, 120), (3, 126), (126, 3), (127, 2), (2, 128), (70, 70), (150, 7), (1, 200)]
+	pairs, recs = [], []
+	for m, n in shapes:
+		for variant in range(3):
+			p, s = seg(int(rng.integers(3, 40))), seg(int(rng.integers(3, 40)))
+			q = seg(n)
+			if 0 == variant:
+				r = seg(m)								# unrelated
+			elif 1 == variant:
+				r = (q * (m // max(1, n) + 2))[:m]		# the query slice repeated: many co-optimal alignments
+			else:
+				r = "".join(c if rng.random() < 0.7 else "ACGT"[rng.integers(4)] for c in (q + seg(m))[:m])
+			if 2 == variant and m > 4:
+				r = r[:2] + r[2:4].lower() + "N" + r[5:]	# soft-masked reference text and an N (the alignment compares dna5 ranks)
+			src = p + q + "-" * m + s
+			dst = p + "-" * n + r + s
+			query = p + q + s
+			if 1 == variant and n > 3:
+				query = query[:len(p) + 1] + "N" + query[len(p) + 2:]
+			qual = [int(x) for x in rng.integers(0, 46, size=len(query))] if variant != 0 or (m + n) % 2 else None
+			pairs.append((src, dst, dst.replace("-", "")))
+			recs.append((query, qual))
+	ctx, o, ids = _edge_index(pvc3, oracle_mod, pairs)
+	bb = BatchBuilder()
+	for (s, d), (query, qual) in zip(ids, recs):
+		bb.add(0, s, d, "%dM" % len(query), query, qual=qual)
+		bb.add(1, s, d, "1S%dM" % (len(query) - 2), query[:-1], qual=qual[:-1] if qual else None)
+	batch = bb.build()
+	for go, ge in ((0, -1), (-3, -1), (2, -1), (1, -1), (3, -5), (5, -2), (0, -4), (4, 0)):
+		for mode in (0, 1):
+			got, stats = pvc3.project_batch(ctx, batch, go, ge, mode)
+			assert_results_equal(batch, got, o.batch_project(batch, go, ge, mode))
+			assert stats["n_failed"] == 0 and stats["n_runs"] >= len(recs)
+
+
+def test_one_large_alignment_among_many_small(pvc3, oracle_mod):
+	"""A run whose alignment needs megabytes of scratch (a 250-base query slice against a 9 kb deletion of the source
+	sequence) among many small ones: the scratch grows, but slots x waves stays within the budget instead of multiplying the
+	large slot by thousands of waves; the results do not change."""
+	rng = np.random.default_rng(78)
+	seg = lambda k: "".join("ACGT"[x] for x in rng.integers(0, 4, size=k))
+	pairs, recs = [], []
+	for i in range(300):
+		m, n = (9000, 250) if 17 == i else (int(rng.integers(1, 30)), int(rng.integers(1, 30)))
+		p, s, q, r = seg(20), seg(20), seg(n), seg(m)
+		pairs.append((p + q + "-" * m + s, p + "-" * n + r + s, p + r + s))
+		recs.append(p + q + s)
+	ctx, o, ids = _edge_index(pvc3, oracle_mod, pairs)
+	ctx.set_option("scratch_budget", 16 << 20)
+	bb = BatchBuilder()
+	for (s, d), query in zip(ids, recs):
+		bb.add(0, s, d, "%dM" % len(query), query, qual=[int(x) for x in rng.integers(2, 42, size=len(query))])
+	batch = bb.build()
+	got, stats = pvc3.project_batch(ctx, batch)
+	assert_results_equal(batch, got, o.batch_project(batch))
+	assert stats["attempts"] == 2 and stats["n_runs"] == 300
+	_, workspace = ctx.hbm_bytes()
+	assert workspace <= (16 << 20) + (1 << 20)

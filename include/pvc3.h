@@ -207,6 +207,31 @@ PVC3_API int pvc3_dbatch_download(pvc3_context *ctx, pvc3_dbatch *batch, pvc3_ba
  * dst_pos, mate_dst_pos, status, CIGAR, runs).  Additive, so the checksums of shards add up to that of the whole. */
 PVC3_API int pvc3_dbatch_checksum(pvc3_context *ctx, pvc3_dbatch *batch, uint64_t first_record, uint64_t *checksum);
 
+/* Pipelined form of pvc3_batch_project for a stream of batches (the loop project_alignments.cc:600-627 runs record by
+ * record): batch k + 1 is copied to the GPU while batch k is projected and the results of batch k - 1 are copied back.  The
+ * device batches are allocated once, for the capacities given here.  Input and output arrays should be page-locked
+ * (pvc3_host_alloc): the copies are then asynchronous, and QUAL is not copied at all — the kernels fetch it from the
+ * caller's arrays for the records with an indel run only.  Arrays handed to pvc3_pipeline_submit must stay valid and
+ * unchanged until pvc3_pipeline_wait has returned that batch.  Batches are returned in submission order. */
+typedef struct pvc3_pipeline pvc3_pipeline;
+typedef struct pvc3_pipeline_caps
+{
+	uint64_t max_records;			/* per batch */
+	uint64_t max_cigar_ops;
+	uint64_t max_seq_bytes;
+	uint64_t max_qual_bytes;		/* only used for batches whose QUAL arrays are not page-locked (then QUAL is uploaded); may be 0 */
+	uint32_t depth;					/* batches in flight, 2 .. 8; 0 = 3 */
+} pvc3_pipeline_caps;
+PVC3_API int pvc3_pipeline_create(pvc3_context *ctx, pvc3_pipeline_caps const *caps, pvc3_pipeline **pipeline);
+PVC3_API void pvc3_pipeline_destroy(pvc3_pipeline *pipeline);
+/* Enqueues one batch and returns; PVC3_E_STATE when `depth` batches are in flight (call pvc3_pipeline_wait), PVC3_E_CAPACITY
+ * when the batch exceeds the capacities.  out->out_cigar_cap / run_cap bound the variable-length results. */
+PVC3_API int pvc3_pipeline_submit(pvc3_pipeline *pipeline, pvc3_batch_in const *in, pvc3_batch_out const *out, pvc3_params const *params);
+/* Waits for the oldest batch in flight: its results are in the arrays given at submission.  Returns that batch's error, if
+ * it had one (PVC3_E_CAPACITY: results larger than the output arrays; PVC3_E_INVALID: malformed offsets). */
+PVC3_API int pvc3_pipeline_wait(pvc3_pipeline *pipeline, pvc3_batch_stats *stats);
+PVC3_API int pvc3_pipeline_in_flight(pvc3_pipeline const *pipeline, uint32_t *count);
+
 /* Page-locked host memory for the batch arrays (hipHostMalloc): with pageable arrays the copies of pvc3_dbatch_create /
  * pvc3_dbatch_download run at about a third of the PCIe rate.  Any thread; free with pvc3_host_free. */
 PVC3_API int pvc3_host_alloc(uint64_t bytes, void **ptr);

@@ -50,6 +50,10 @@ class BatchStats(C.Structure):
 	]
 
 
+class PipelineCaps(C.Structure):
+	_fields_ = [("max_records", C.c_uint64), ("max_cigar_ops", C.c_uint64), ("max_seq_bytes", C.c_uint64), ("max_qual_bytes", C.c_uint64), ("depth", C.c_uint32)]
+
+
 def lib():
 	"""The loaded library (raises OSError if it has not been built: there is no CPU fallback)."""
 	global _lib
@@ -95,6 +99,11 @@ def lib():
 		"pvc3_dbatch_download": ([vp, vp, P(BatchOut)], i32),
 		"pvc3_dbatch_checksum": ([vp, vp, u64, P(u64)], i32),
 		"pvc3_project_positions": ([vp, u64, vp, vp, vp, vp], i32),
+		"pvc3_pipeline_create": ([vp, P(PipelineCaps), P(vp)], i32),
+		"pvc3_pipeline_destroy": ([vp], None),
+		"pvc3_pipeline_submit": ([vp, P(BatchIn), P(BatchOut), P(Params)], i32),
+		"pvc3_pipeline_wait": ([vp, P(BatchStats)], i32),
+		"pvc3_pipeline_in_flight": ([vp, P(u32)], i32),
 		"pvc3_host_alloc": ([u64, P(vp)], i32),
 		"pvc3_host_free": ([vp], None),
 	}

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BatchIn, BatchOut, BatchStats, Params, check
+from ._lib import BatchIn, BatchOut, BatchStats, Params, PipelineCaps, check
 
 CIGAR_OPS = "MIDNSHP=X"
 SCORE_FP64 = 0
@@ -295,6 +295,124 @@ def pinned_batch(batch):
 		out[k] = pa.array
 		owners.append(pa)
 	return out, owners
+
+
+class Pipeline:
+	"""pvc3_pipeline_*: a stream of batches with the upload of batch k + 1, the kernels of batch k and the download of batch
+	k - 1 overlapping.  submit() takes the batch arrays and the output arrays (see output_arrays()); both should be
+	page-locked (PinnedArray / pinned_batch) and must stay untouched until wait() has returned the batch."""
+
+	def __init__(self, ctx, max_records, max_cigar_ops, max_seq_bytes, max_qual_bytes=0, depth=3):
+		self._L = _lib.lib()
+		self.ctx = ctx
+		self._h = C.c_void_p()
+		caps = PipelineCaps(max_records, max_cigar_ops, max_seq_bytes, max_qual_bytes, depth)
+		check(self._L.pvc3_pipeline_create(ctx._h, C.byref(caps), C.byref(self._h)))
+		self._keep = []
+
+	def close(self):
+		if getattr(self, "_h", None):
+			self._L.pvc3_pipeline_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		self.close()
+
+	@staticmethod
+	def output_arrays(max_records, max_cigar_ops, max_runs, pinned=True):
+		"""A set of output arrays for one batch in flight: dict of numpy arrays (+ "_owner" keeping page-locked memory alive)."""
+		shapes = dict(dst_pos=(max_records, np.uint32), mate_dst_pos=(max_records, np.uint32), status=(max_records, np.int32),
+					  out_cigar_off=(max_records + 1, np.uint64), run_off=(max_records + 1, np.uint64), out_cigar=(max(1, max_cigar_ops), np.uint32), runs=(max(1, max_runs), RUN_DTYPE))
+		if pinned:
+			owners = [PinnedArray((cnt,), dt) for cnt, dt in shapes.values()]
+			res = {k: pa.array for k, pa in zip(shapes, owners)}
+			res["_owner"] = owners
+		else:
+			res = {k: np.zeros(cnt, dtype=dt) for k, (cnt, dt) in shapes.items()}
+		return res
+
+	def submit(self, batch, out, params=None):
+		bi, keep = _pack_batch_in(batch)
+		bo = BatchOut()
+		for k in ("dst_pos", "mate_dst_pos", "status", "out_cigar_off", "out_cigar", "run_off", "runs"):
+			setattr(bo, k, out[k].ctypes.data)
+		bo.out_cigar_cap = out["out_cigar"].size
+		bo.run_cap = out["runs"].size
+		p = params if isinstance(params, Params) else make_params(**(params or {}))
+		check(self._L.pvc3_pipeline_submit(self._h, C.byref(bi), C.byref(bo), C.byref(p)))
+		self._keep.append((keep, out, bi.n))
+
+	def wait(self):
+		"""(results of the oldest batch as views of its output arrays, stats)."""
+		st = BatchStats()
+		keep, out, n = self._keep.pop(0)
+		check(self._L.pvc3_pipeline_wait(self._h, C.byref(st)))
+		stats = _stats_dict(st)
+		res = {k: out[k][:n] for k in ("dst_pos", "mate_dst_pos", "status")}
+		res["out_cigar_off"] = out["out_cigar_off"][:n + 1]
+		res["run_off"] = out["run_off"][:n + 1]
+		res["out_cigar"] = out["out_cigar"][:int(stats["out_cigar_total"])]
+		res["runs"] = out["runs"][:int(stats["n_runs"])]
+		return res, stats
+
+	def in_flight(self):
+		v = C.c_uint32()
+		check(self._L.pvc3_pipeline_in_flight(self._h, C.byref(v)))
+		return v.value
+
+
+def pipeline_bench(ctx, batch, params, batch_records=2_000_000, total_records=16_000_000, depth=3):
+	"""PCIe-inclusive throughput of the pipelined entry point (SURVEY.md §8d protocol ii): the batch is cut into slices of
+	`batch_records`, copied once into page-locked arrays (the state a caller that fills its arrays directly is in), and the
+	slices are streamed through pvc3_pipeline_submit / _wait.  Returns the dict bench.py prints as "pipeline"."""
+	import time
+	n_all = int(np.asarray(batch["src_pos"]).size)
+	n_use = min(n_all, total_records)
+	n_slices = max(1, n_use // batch_records)
+	per = n_use // n_slices
+
+	def cut(lo, hi):
+		out = {}
+		for name in ("src_pos", "src_entry", "dst_entry", "flags", "l_seq", "mate_src_entry", "mate_dst_entry", "mate_pos"):
+			out[name] = batch[name][lo:hi]
+		for off, data in (("cigar_off", "cigar"), ("seq_off", "seq4"), ("qual_off", "qual")):
+			o = batch[off][lo:hi + 1]
+			out[off] = (o - o[0]).astype(np.uint64)
+			out[data] = batch[data][int(o[0]):int(o[-1])]
+		return out
+	slices, owners = [], []
+	for i in range(n_slices):
+		pb, own = pinned_batch(cut(i * per, (i + 1) * per))
+		slices.append(pb)
+		owners.append(own)
+	max_cig = max(int(s["cigar"].size) for s in slices)
+	max_seq = max(int(s["seq4"].size) for s in slices)
+	pipe = Pipeline(ctx, per, max_cig, max_seq, 0, depth)
+	outs = [Pipeline.output_arrays(per, 4 * max_cig + 8 * per, per // 4 + 1024) for _ in range(depth)]
+	h2d = sum(sum(int(v.nbytes) for k, v in s.items() if k not in ("qual", "qual_off")) for s in slices)
+	d2h = 0
+	# warm-up: one slice through the pipeline (first-use allocations, workspaces)
+	pipe.submit(slices[0], outs[0], params)
+	pipe.wait()
+	t0 = time.perf_counter()
+	done = 0
+	for i, sl in enumerate(slices):
+		if pipe.in_flight() == depth:
+			res, st = pipe.wait()
+			d2h += 28 * per + 16 + 4 * int(st["out_cigar_total"]) + 16 * int(st["n_runs"])
+			done += 1
+		pipe.submit(sl, outs[i % depth], params)
+	while pipe.in_flight():
+		res, st = pipe.wait()
+		d2h += 28 * per + 16 + 4 * int(st["out_cigar_total"]) + 16 * int(st["n_runs"])
+		done += 1
+	dt = time.perf_counter() - t0
+	pipe.close()
+	return {
+		"value": n_slices * per / dt, "unit": "alignments/s", "records": n_slices * per, "batch_records": per, "depth": depth,
+		"GBps_h2d": h2d / dt / 1e9, "GBps_d2h": d2h / dt / 1e9,
+		"what": "pvc3_pipeline_submit / _wait over page-locked arrays: upload of batch k + 1, kernels of batch k and download of batch k - 1 overlap; QUAL is fetched by the kernels for realigned records only",
+	}
 
 
 def make_params(gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, tiebreak_mode=0):

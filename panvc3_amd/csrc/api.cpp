@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -66,6 +67,15 @@ struct pvc3_context
 	uint64_t scratch_alloc{};
 };
 
+namespace {
+struct batch_caps
+{
+	uint64_t n{}, cigar{}, seq{}, qual{};		// records, CIGAR operations, SEQ bytes, QUAL bytes uploaded with the batch
+	uint64_t qual_compact{};					// bytes of the compact QUAL buffer of a pipelined batch (0: QUAL travels with the batch)
+	bool mates{};
+};
+}
+
 struct pvc3_dbatch
 {
 	pvc3_context *ctx{};
@@ -77,13 +87,18 @@ struct pvc3_dbatch
 	unsigned long long *d_checksum{};
 	std::vector <void *> allocs;		// everything except the growable arenas
 	uint64_t bytes{};
-	// host-side facts for the statistics
-	uint64_t sum_cigar{}, sum_seq_bytes{}, n_mates{};
+	batch_caps caps{};
+	// optional inputs: device arrays exist when the capacities ask for them, `in` points to them when the batch has them
+	uint64_t *up_qual_off{};
+	uint8_t *up_qual{};
+	uint32_t *up_mate_src_entry{}, *up_mate_dst_entry{}, *up_mate_pos{};
+	uint32_t *d_invalid{};				// the first malformed record, 0xFFFFFFFF if the layout is sound (k_validate_batch)
 	bool projected{};
 	bool finished{};
 	pvc3_params params{};
 	uint32_t attempts{};
 	dev_counters counters{};
+	uint64_t totals[2]{};				// packed CIGAR operations and runs of the finished batch
 };
 
 namespace {
@@ -490,57 +505,53 @@ void pvc3_dbatch_destroy(pvc3_dbatch *b)
 	if (b->packed.runs) (void) hipFree(b->packed.runs);
 	if (b->work.run_items) (void) hipFree(b->work.run_items);
 	if (b->work.dp_list) (void) hipFree(b->work.dp_list);
+	if (b->work.qual_compact) (void) hipFree(b->work.qual_compact);
 	delete b;
 }
 
-int pvc3_dbatch_create(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_dbatch **out)
+}	// extern "C"
+
+namespace {
+
+// Allocates every device array of a batch for up to `caps` (inputs, per-record work arrays, arenas): a batch object is
+// filled again and again by dbatch_load() without touching the allocator (hipMalloc / hipFree cost milliseconds each).
+int dbatch_alloc(pvc3_context *ctx, batch_caps const &caps, pvc3_dbatch **out)
 {
-	if (!ctx || !in || !out) return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: null argument");
 	*out = nullptr;
-	uint64_t const n = in->n;
-	if (n && (!in->src_pos || !in->src_entry || !in->dst_entry || !in->flags || !in->cigar_off || !in->seq_off || !in->l_seq))
-		return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: a required input array is null");
-	if (n >= (UINT64_C(1) << 32))
-		return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: at most 2^32 - 1 records per batch");
-	PVC3_TRY(check_device(ctx));
-	if (!ctx->d_entries) return set_error(PVC3_E_STATE, "pvc3_dbatch_create: no index has been uploaded to this context");
-
+	if (caps.n >= (UINT64_C(1) << 32))
+		return set_error(PVC3_E_INVALID, "at most 2^32 - 1 records per batch");
 	pvc3_dbatch *b = new (std::nothrow) pvc3_dbatch;
-	if (!b) return set_error(PVC3_E_NOMEM, "pvc3_dbatch_create: out of memory");
-	b->ctx = ctx; b->n = n;
+	if (!b) return set_error(PVC3_E_NOMEM, "pvc3_dbatch: out of memory");
+	b->ctx = ctx; b->caps = caps;
 	struct guard { pvc3_dbatch *p; ~guard() { if (p) pvc3_dbatch_destroy(p); } } g{b};
-
-	static uint64_t const zero_off[1] = {0};
-	uint64_t const n_cigar = n ? in->cigar_off[n] : 0;
-	uint64_t const n_seq = n ? in->seq_off[n] : 0;
-	bool const has_qual = n && in->qual_off && in->qual;
-	uint64_t const n_qual = has_qual ? in->qual_off[n] : 0;
-	bool const has_mates = n && in->mate_src_entry && in->mate_dst_entry && in->mate_pos;
-	if (n_cigar && !in->cigar) return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: cigar is null");
-	if (n_seq && !in->seq4) return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: seq4 is null");
-
-	hipStream_t const s = ctx->stream;
+	uint64_t const n = caps.n;
+	auto in_alloc = [&](auto **dst, uint64_t count, uint64_t pad) -> int {
+		uint8_t *p{};
+		typedef std::remove_const_t <std::remove_pointer_t <std::remove_pointer_t <decltype(dst)>>> t_value;
+		PVC3_TRY(dev_alloc(&p, count * sizeof(t_value) + pad, &b->allocs, &b->bytes));
+		*dst = (t_value *) p;
+		return PVC3_OK;
+	};
 	dev_batch_in &d = b->in;
-	d.n = n;
-	PVC3_TRY(dev_upload(&d.src_pos, in->src_pos, n, 0, s, &b->allocs, &b->bytes));
-	PVC3_TRY(dev_upload(&d.src_entry, in->src_entry, n, 0, s, &b->allocs, &b->bytes));
-	PVC3_TRY(dev_upload(&d.dst_entry, in->dst_entry, n, 0, s, &b->allocs, &b->bytes));
-	PVC3_TRY(dev_upload(&d.flags, in->flags, n, 0, s, &b->allocs, &b->bytes));
-	PVC3_TRY(dev_upload(&d.cigar_off, n ? in->cigar_off : zero_off, n + 1, 0, s, &b->allocs, &b->bytes));
-	PVC3_TRY(dev_upload(&d.cigar, in->cigar, n_cigar, 256, s, &b->allocs, &b->bytes));
-	PVC3_TRY(dev_upload(&d.seq_off, n ? in->seq_off : zero_off, n + 1, 0, s, &b->allocs, &b->bytes));
-	PVC3_TRY(dev_upload(&d.l_seq, in->l_seq, n, 0, s, &b->allocs, &b->bytes));
-	PVC3_TRY(dev_upload(&d.seq4, in->seq4, n_seq, 256, s, &b->allocs, &b->bytes));		// padded: whole-dword reads
-	if (has_qual)
+	PVC3_TRY(in_alloc(&d.src_pos, n, 0));
+	PVC3_TRY(in_alloc(&d.src_entry, n, 0));
+	PVC3_TRY(in_alloc(&d.dst_entry, n, 0));
+	PVC3_TRY(in_alloc(&d.flags, n, 0));
+	PVC3_TRY(in_alloc(&d.cigar_off, n + 1, 0));
+	PVC3_TRY(in_alloc(&d.cigar, caps.cigar, 256));		// padded: whole 16-byte reads of the first operations
+	PVC3_TRY(in_alloc(&d.seq_off, n + 1, 0));
+	PVC3_TRY(in_alloc(&d.l_seq, n, 0));
+	PVC3_TRY(in_alloc(&d.seq4, caps.seq, 256));			// padded: whole-dword reads
+	if (caps.qual)
 	{
-		PVC3_TRY(dev_upload(&d.qual_off, in->qual_off, n + 1, 0, s, &b->allocs, &b->bytes));
-		PVC3_TRY(dev_upload(&d.qual, in->qual, n_qual, 16, s, &b->allocs, &b->bytes));
+		PVC3_TRY(in_alloc(&b->up_qual_off, n + 1, 0));
+		PVC3_TRY(in_alloc(&b->up_qual, caps.qual, 16));
 	}
-	if (has_mates)
+	if (caps.mates)
 	{
-		PVC3_TRY(dev_upload(&d.mate_src_entry, in->mate_src_entry, n, 0, s, &b->allocs, &b->bytes));
-		PVC3_TRY(dev_upload(&d.mate_dst_entry, in->mate_dst_entry, n, 0, s, &b->allocs, &b->bytes));
-		PVC3_TRY(dev_upload(&d.mate_pos, in->mate_pos, n, 0, s, &b->allocs, &b->bytes));
+		PVC3_TRY(in_alloc(&b->up_mate_src_entry, n, 0));
+		PVC3_TRY(in_alloc(&b->up_mate_dst_entry, n, 0));
+		PVC3_TRY(in_alloc(&b->up_mate_pos, n, 0));
 	}
 
 	dev_batch_work &w = b->work;
@@ -563,21 +574,138 @@ int pvc3_dbatch_create(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_dbatch *
 	PVC3_TRY(dev_alloc(&b->packed.status, n, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->scan_tmp, pack_scan_tmp_words(n), &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->d_checksum, 1, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->d_invalid, 1, &b->allocs, &b->bytes));
+	w.first_bad = b->d_invalid;
+	if (caps.qual_compact)
+	{
+		PVC3_TRY(dev_alloc(&w.qual_off_dev, n, &b->allocs, &b->bytes));
+		PVC3_TRY(dev_alloc(&w.qual_compact, caps.qual_compact, nullptr, &b->bytes));
+		w.qual_compact_cap = caps.qual_compact;
+	}
 
 	// Arena sizing: twice the input operations + 8 per record + the chunk slack of every wave that may allocate.
 	uint64_t const realign_waves = (ctx->realign_waves < (n + 63) / 64) ? ctx->realign_waves : (n + 63) / 64;
 	uint64_t const chunk_slack = ((uint64_t) project_wave_count(n) + realign_waves) * 2048 * 2;
-	uint64_t arena_cap = ctx->arena_initial ? ctx->arena_initial : (2 * n_cigar + 8 * n + chunk_slack + 4096);
-	uint64_t runs_cap = ctx->runs_initial ? ctx->runs_initial : (n / 16 + realign_waves * 128 * 2 + 1024);
+	uint64_t const arena_cap = ctx->arena_initial ? ctx->arena_initial : (2 * caps.cigar + 8 * n + chunk_slack + 4096);
+	uint64_t const runs_cap = ctx->runs_initial ? ctx->runs_initial : (n / 16 + realign_waves * 128 * 2 + 1024);
 	PVC3_TRY(alloc_arenas(b, arena_cap, runs_cap));
-
-	b->sum_cigar = n_cigar;
-	b->sum_seq_bytes = n_seq;
-	for (uint64_t i = 0; has_mates && i < n; ++i)
-		b->n_mates += (0 != (in->flags[i] & PVC3_FLAG_HAS_MATE));
-
-	HIP_TRY(hipStreamSynchronize(s));
 	g.p = nullptr;
+	*out = b;
+	return PVC3_OK;
+}
+
+bool device_visible_host_pointer(void const *p)
+{
+	if (!p) return false;
+	hipPointerAttribute_t attr{};
+	if (hipSuccess != hipPointerGetAttributes(&attr, p)) { (void) hipGetLastError(); return false; }
+	return hipMemoryTypeHost == attr.type;
+}
+
+// Fills a batch object: asynchronous copies on `s` (page-locked source arrays must stay valid until the copies have run) and
+// the check of the variable-length layout on the device.  With lazy_qual QUAL is not copied: the kernels fetch it from the
+// caller's page-locked arrays for the records that are realigned (dev_batch_work::host_qual).
+int dbatch_load(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_in const *in, hipStream_t s, bool lazy_qual)
+{
+	uint64_t const n = in->n;
+	batch_caps const &caps = b->caps;
+	if (n && (!in->src_pos || !in->src_entry || !in->dst_entry || !in->flags || !in->cigar_off || !in->seq_off || !in->l_seq))
+		return set_error(PVC3_E_INVALID, "pvc3 batch: a required input array is null");
+	static uint64_t const zero_off[1] = {0};
+	uint64_t const n_cigar = n ? in->cigar_off[n] : 0;
+	uint64_t const n_seq = n ? in->seq_off[n] : 0;
+	bool const has_qual = n && in->qual_off && in->qual;
+	uint64_t const n_qual = has_qual ? in->qual_off[n] : 0;
+	bool const has_mates = n && in->mate_src_entry && in->mate_dst_entry && in->mate_pos;
+	if (n_cigar && !in->cigar) return set_error(PVC3_E_INVALID, "pvc3 batch: cigar is null");
+	if (n_seq && !in->seq4) return set_error(PVC3_E_INVALID, "pvc3 batch: seq4 is null");
+	lazy_qual = lazy_qual && has_qual && caps.qual_compact;
+	if (n > caps.n || n_cigar > caps.cigar || n_seq > caps.seq || (has_qual && !lazy_qual && n_qual > caps.qual) || (has_mates && !caps.mates))
+		return set_error(PVC3_E_CAPACITY, "pvc3 batch: %llu records, %llu CIGAR operations, %llu SEQ bytes, %llu QUAL bytes exceed the capacities %llu, %llu, %llu, %llu",
+			(unsigned long long) n, (unsigned long long) n_cigar, (unsigned long long) n_seq, (unsigned long long) ((has_qual && !lazy_qual) ? n_qual : 0),
+			(unsigned long long) caps.n, (unsigned long long) caps.cigar, (unsigned long long) caps.seq, (unsigned long long) caps.qual);
+
+	auto put = [&](auto const *dst, auto const *src, uint64_t count, uint64_t pad) -> int {
+		uint8_t *p = (uint8_t *) const_cast <void *>((void const *) dst);
+		if (count) HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(*src), hipMemcpyHostToDevice, s));
+		if (pad) HIP_TRY(hipMemsetAsync(p + count * sizeof(*src), 0, pad, s));
+		return PVC3_OK;
+	};
+	dev_batch_in &d = b->in;
+	d.n = n; b->n = n;
+	PVC3_TRY(put(d.src_pos, in->src_pos, n, 0));
+	PVC3_TRY(put(d.src_entry, in->src_entry, n, 0));
+	PVC3_TRY(put(d.dst_entry, in->dst_entry, n, 0));
+	PVC3_TRY(put(d.flags, in->flags, n, 0));
+	PVC3_TRY(put(d.cigar_off, n ? in->cigar_off : zero_off, n + 1, 0));
+	PVC3_TRY(put(d.cigar, in->cigar, n_cigar, 256));
+	PVC3_TRY(put(d.seq_off, n ? in->seq_off : zero_off, n + 1, 0));
+	PVC3_TRY(put(d.l_seq, in->l_seq, n, 0));
+	PVC3_TRY(put(d.seq4, in->seq4, n_seq, 256));
+	dev_batch_work &w = b->work;
+	d.qual = nullptr; d.qual_off = nullptr; w.host_qual = nullptr; w.host_qual_off = nullptr;
+	if (lazy_qual)
+	{
+		w.host_qual = in->qual; w.host_qual_off = in->qual_off;		// page-locked: the same addresses are valid on the device
+		d.qual = w.qual_compact; d.qual_off = w.qual_off_dev;
+	}
+	else if (has_qual)
+	{
+		PVC3_TRY(put(b->up_qual_off, in->qual_off, n + 1, 0));
+		PVC3_TRY(put(b->up_qual, in->qual, n_qual, 16));
+		d.qual = b->up_qual; d.qual_off = b->up_qual_off;
+	}
+	d.mate_src_entry = nullptr; d.mate_dst_entry = nullptr; d.mate_pos = nullptr;
+	if (has_mates)
+	{
+		PVC3_TRY(put(b->up_mate_src_entry, in->mate_src_entry, n, 0));
+		PVC3_TRY(put(b->up_mate_dst_entry, in->mate_dst_entry, n, 0));
+		PVC3_TRY(put(b->up_mate_pos, in->mate_pos, n, 0));
+		d.mate_src_entry = b->up_mate_src_entry; d.mate_dst_entry = b->up_mate_dst_entry; d.mate_pos = b->up_mate_pos;
+	}
+	// Offsets must not decrease and every record must own the SEQ / QUAL bytes its l_seq promises: the kernels read
+	// seq4 + seq_off and qual + qual_off without further checks.
+	HIP_TRY(hipMemsetAsync(b->d_invalid, 0xff, sizeof(uint32_t), s));
+	if (int const e = launch_validate(d, n_cigar, n_seq, lazy_qual ? 0 : n_qual, lazy_qual ? nullptr : d.qual_off, b->d_invalid, s)) return set_error(PVC3_E_HIP, "k_validate_batch launch: %s", hipGetErrorString((hipError_t) e));
+	b->projected = false; b->finished = false;
+	return PVC3_OK;
+}
+
+// `s`: the stream the batch was loaded on; null when the caller has already waited for it.
+int dbatch_check_valid(pvc3_dbatch *b, hipStream_t s)
+{
+	uint32_t bad = 0;
+	if (s) HIP_TRY(hipStreamSynchronize(s));
+	HIP_TRY(hipMemcpy(&bad, b->d_invalid, sizeof(bad), hipMemcpyDeviceToHost));
+	if (0xFFFFFFFFu != bad)
+		return set_error(PVC3_E_INVALID, "pvc3 batch: malformed variable-length layout (offsets decrease, run past the arrays, or a record's SEQ / QUAL slice is shorter than l_seq); first bad record %u", bad);
+	return PVC3_OK;
+}
+
+}	// anonymous namespace
+
+extern "C" {
+
+int pvc3_dbatch_create(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_dbatch **out)
+{
+	if (!ctx || !in || !out) return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: null argument");
+	*out = nullptr;
+	PVC3_TRY(check_device(ctx));
+	if (!ctx->d_entries) return set_error(PVC3_E_STATE, "pvc3_dbatch_create: no index has been uploaded to this context");
+	uint64_t const n = in->n;
+	if (n && (!in->cigar_off || !in->seq_off))
+		return set_error(PVC3_E_INVALID, "pvc3_dbatch_create: a required input array is null");
+	batch_caps caps;
+	caps.n = n;
+	caps.cigar = n ? in->cigar_off[n] : 0;
+	caps.seq = n ? in->seq_off[n] : 0;
+	caps.qual = (n && in->qual_off && in->qual) ? in->qual_off[n] : 0;
+	caps.mates = n && in->mate_src_entry && in->mate_dst_entry && in->mate_pos;
+	pvc3_dbatch *b{};
+	PVC3_TRY(dbatch_alloc(ctx, caps, &b));
+	int rc = dbatch_load(ctx, b, in, ctx->stream, false);
+	if (!rc) rc = dbatch_check_valid(b, ctx->stream);
+	if (rc) { pvc3_dbatch_destroy(b); return rc; }
 	*out = b;
 	return PVC3_OK;
 }
@@ -598,17 +726,20 @@ int pvc3_dbatch_project(pvc3_context *ctx, pvc3_dbatch *b, pvc3_params const *pa
 	return PVC3_OK;
 }
 
-int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stats)
+}	// extern "C"
+
+namespace {
+
+// Waits for the projection of `b` on the context's stream; grows whatever overflowed and repeats the batch on the GPU until
+// it fits.  Leaves the counters in b->counters and the packed totals in b->totals.
+int dbatch_complete(pvc3_context *ctx, pvc3_dbatch *b, bool already_waited = false)
 {
-	if (!ctx || !b) return set_error(PVC3_E_INVALID, "pvc3_dbatch_finish: null argument");
-	if (!b->projected) return set_error(PVC3_E_STATE, "pvc3_dbatch_finish: pvc3_dbatch_project has not been called");
-	PVC3_TRY(check_device(ctx));
-	for (;;)
+	for (;; already_waited = false)
 	{
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		if (!already_waited) HIP_TRY(hipStreamSynchronize(ctx->stream));
 		HIP_TRY(hipMemcpy(&b->counters, b->work.counters, sizeof(dev_counters), hipMemcpyDeviceToHost));
 		dev_counters const &c = b->counters;
-		if (!c.arena_overflow && !c.runs_overflow && !c.scratch_overflow)
+		if (!c.arena_overflow && !c.runs_overflow && !c.scratch_overflow && !c.qual_overflow)
 			break;
 		if (b->attempts >= 8)
 			return set_error(PVC3_E_NOMEM, "pvc3_dbatch_finish: workspaces still too small after %u attempts", b->attempts);
@@ -628,44 +759,65 @@ int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stat
 			uint64_t const runs_cap = c.runs_overflow ? (2 * (uint64_t) c.runs_head + 1024) : b->work.runs_cap;
 			PVC3_TRY(alloc_arenas(b, arena_cap, runs_cap));
 		}
+		if (c.qual_overflow)
+		{
+			(void) hipFree(b->work.qual_compact);
+			b->bytes -= b->work.qual_compact_cap;
+			b->work.qual_compact = nullptr;
+			uint64_t const cap = 2 * (uint64_t) c.qual_head + 4096;
+			PVC3_TRY(dev_alloc(&b->work.qual_compact, cap, nullptr, &b->bytes));
+			b->work.qual_compact_cap = cap;
+			b->in.qual = b->work.qual_compact;
+		}
 		++b->attempts;
 		PVC3_TRY(enqueue_projection(ctx, b));
 	}
+	HIP_TRY(hipMemcpy(&b->totals[0], b->packed.out_cigar_off + b->n, sizeof(uint64_t), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&b->totals[1], b->packed.run_off + b->n, sizeof(uint64_t), hipMemcpyDeviceToHost));
 	b->finished = true;
-	if (stats)
+	return PVC3_OK;
+}
+
+void fill_stats(pvc3_context *ctx, pvc3_dbatch const *b, pvc3_batch_stats *stats)
+{
+	dev_counters const &c = b->counters;
+	std::memset(stats, 0, sizeof(*stats));
+	stats->n_records = b->n;
+	stats->n_failed = c.n_failed;
+	stats->n_realigned_records = c.n_realigned_records;
+	stats->n_fast_path = c.n_fast;
+	stats->n_mid_path = c.n_mid;
+	stats->n_runs = b->totals[1];
+	stats->out_cigar_total = b->totals[0];
+	// Algorithmic bytes are accumulated per record by the kernels themselves: what one pass must read and
+	// write at minimum.  k_project_fast: descriptors, input CIGAR, select sample + rank word, mate fields (+ the mate's
+	// blocks when it is not the neighbouring record), results; for fast-path records also SEQ, gap-bit windows, text and
+	// the output CIGAR.  k_project_mid / k_project_general: SEQ, gap bits, text, output CIGAR of the records they walk.
+	// Realignment: QUAL of realigned records, 16 bytes per realigned range.  Packing traffic is not algorithmic.
+	stats->algorithmic_bytes_project = c.fast_bytes;
+	stats->algorithmic_bytes = c.fast_bytes + c.general_bytes + c.qual_bytes + sizeof(pvc3_run) * b->totals[1];
+	if (ctx->timing)
 	{
-		dev_counters const &c = b->counters;
-		std::memset(stats, 0, sizeof(*stats));
-		uint64_t totals[2] = {0, 0};
-		HIP_TRY(hipMemcpy(&totals[0], b->packed.out_cigar_off + b->n, sizeof(uint64_t), hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(&totals[1], b->packed.run_off + b->n, sizeof(uint64_t), hipMemcpyDeviceToHost));
-		stats->n_records = b->n;
-		stats->n_failed = c.n_failed;
-		stats->n_realigned_records = c.n_realigned_records;
-		stats->n_fast_path = c.n_fast;
-		stats->n_mid_path = c.n_mid;
-		stats->n_runs = totals[1];
-		stats->out_cigar_total = totals[0];
-		// Algorithmic bytes (DESIGN.md "Algorithmic bytes per alignment"): what one pass must read and write at minimum.
-		uint64_t const n = b->n;
-		// Algorithmic bytes are accumulated per record by the kernels themselves: what one pass must read and
-		// write at minimum.  k_project_fast: descriptors, input CIGAR, select sample + rank word, mate fields (+ the mate's
-		// blocks when it is not the neighbouring record), results; for fast-path records also SEQ, gap-bit windows, text and
-		// the output CIGAR.  k_project_general: SEQ, gap bits, text, output CIGAR of the records it walks.
-		// k_realign: QUAL of realigned records.  Realigned ranges: 16 bytes each.  Packing traffic is not algorithmic.
-		stats->algorithmic_bytes_project = c.fast_bytes;
-		stats->algorithmic_bytes = c.fast_bytes + c.general_bytes + c.qual_bytes + sizeof(pvc3_run) * totals[1];
-		(void) n;
-		if (ctx->timing)
-		{
-			(void) hipEventElapsedTime(&stats->ms_project, ctx->ev[0], ctx->ev[1]);
-			(void) hipEventElapsedTime(&stats->ms_mid, ctx->ev[1], ctx->ev[5]);
-			(void) hipEventElapsedTime(&stats->ms_general, ctx->ev[5], ctx->ev[2]);
-			(void) hipEventElapsedTime(&stats->ms_realign, ctx->ev[2], ctx->ev[3]);
-			(void) hipEventElapsedTime(&stats->ms_pack, ctx->ev[3], ctx->ev[4]);
-		}
-		stats->attempts = b->attempts;
+		(void) hipEventElapsedTime(&stats->ms_project, ctx->ev[0], ctx->ev[1]);
+		(void) hipEventElapsedTime(&stats->ms_mid, ctx->ev[1], ctx->ev[5]);
+		(void) hipEventElapsedTime(&stats->ms_general, ctx->ev[5], ctx->ev[2]);
+		(void) hipEventElapsedTime(&stats->ms_realign, ctx->ev[2], ctx->ev[3]);
+		(void) hipEventElapsedTime(&stats->ms_pack, ctx->ev[3], ctx->ev[4]);
 	}
+	stats->attempts = b->attempts;
+}
+
+}	// anonymous namespace
+
+extern "C" {
+
+int pvc3_dbatch_finish(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stats)
+{
+	if (!ctx || !b) return set_error(PVC3_E_INVALID, "pvc3_dbatch_finish: null argument");
+	if (!b->projected) return set_error(PVC3_E_STATE, "pvc3_dbatch_finish: pvc3_dbatch_project has not been called");
+	PVC3_TRY(check_device(ctx));
+	PVC3_TRY(dbatch_complete(ctx, b));
+	if (stats) fill_stats(ctx, b, stats);
 	return PVC3_OK;
 }
 
@@ -716,6 +868,190 @@ int pvc3_batch_project(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_batch_ou
 	if (!rc) rc = pvc3_dbatch_download(ctx, b, out);
 	pvc3_dbatch_destroy(b);
 	return rc;
+}
+
+
+// ---- pipelined entry point -----------------------------------------------------------------------------------------------
+// The reference's record loop reads, projects and writes one record at a time (project_alignments.cc:600-627).  Here batch
+// k + 1 is copied to the GPU while batch k is projected and the results of batch k - 1 travel back: three device batches
+// that are allocated once, three streams, events in between; QUAL stays in the caller's page-locked arrays and only the
+// records with an indel run have theirs fetched (k_gather_qual).
+}	// extern "C"
+
+struct pvc3_pipeline
+{
+	pvc3_context *ctx{};
+	hipStream_t s_h2d{}, s_kernels{}, s_d2h{};
+	struct slot
+	{
+		pvc3_dbatch *b{};
+		hipEvent_t loaded{}, projected{}, downloaded{};
+		pvc3_batch_out out{};
+		int state{};					// 0 free, 1 kernels enqueued, 2 download enqueued
+		int error{};
+		char message[256]{};
+	};
+	std::vector <slot> slots;
+	uint64_t submitted{}, retired{};	// batch numbers; slot = number % depth
+};
+
+namespace {
+
+// Kernels of the slot's batch have been enqueued: wait for them (the host learns the sizes of the variable-length results),
+// repeat the batch if a workspace overflowed, then enqueue the download into the caller's arrays.
+int pipeline_start_download(pvc3_pipeline *p, pvc3_pipeline::slot &sl)
+{
+	pvc3_context *ctx = p->ctx;
+	pvc3_dbatch *b = sl.b;
+	// Only this batch's kernels are waited for: later batches may already be queued on the same streams.
+	HIP_TRY(hipEventSynchronize(sl.projected));
+	hipStream_t const keep = ctx->stream;
+	ctx->stream = p->s_kernels;
+	int rc = dbatch_check_valid(b, nullptr);
+	if (!rc) rc = dbatch_complete(ctx, b, true);
+	ctx->stream = keep;
+	if (rc) return rc;
+	uint64_t const n = b->n, n_cig = b->totals[0], n_runs = b->totals[1];
+	pvc3_batch_out const &out = sl.out;
+	if (n_cig > out.out_cigar_cap || n_runs > out.run_cap)
+		return set_error(PVC3_E_CAPACITY, "pvc3_pipeline: need room for %llu CIGAR operations and %llu runs", (unsigned long long) n_cig, (unsigned long long) n_runs);
+	hipStream_t const s = p->s_d2h;		// the kernels have been waited for: no event needed
+	HIP_TRY(hipMemcpyAsync(out.out_cigar_off, b->packed.out_cigar_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(out.run_off, b->packed.run_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+	if (n)
+	{
+		HIP_TRY(hipMemcpyAsync(out.dst_pos, b->work.dst_pos, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(out.mate_dst_pos, b->work.mate_dst_pos, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(out.status, b->packed.status, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+	}
+	if (n_cig) HIP_TRY(hipMemcpyAsync(out.out_cigar, b->packed.out_cigar, n_cig * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	if (n_runs) HIP_TRY(hipMemcpyAsync(out.runs, b->packed.runs, n_runs * sizeof(pvc3_run), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipEventRecord(sl.downloaded, s));
+	sl.state = 2;
+	return PVC3_OK;
+}
+
+void pipeline_note_error(pvc3_pipeline::slot &sl, int rc)
+{
+	sl.error = rc;
+	std::snprintf(sl.message, sizeof(sl.message), "%s", pvc3_last_error());
+	sl.state = 2;		// nothing is in flight for it; pvc3_pipeline_wait reports the error
+}
+
+}	// anonymous namespace
+
+extern "C" {
+
+int pvc3_pipeline_create(pvc3_context *ctx, pvc3_pipeline_caps const *caps, pvc3_pipeline **out)
+{
+	if (!ctx || !caps || !out) return set_error(PVC3_E_INVALID, "pvc3_pipeline_create: null argument");
+	*out = nullptr;
+	PVC3_TRY(check_device(ctx));
+	if (!ctx->d_entries) return set_error(PVC3_E_STATE, "pvc3_pipeline_create: no index has been uploaded to this context");
+	uint32_t const depth = caps->depth ? caps->depth : 3;
+	if (depth < 2 || depth > 8) return set_error(PVC3_E_INVALID, "pvc3_pipeline_create: depth must be 2 .. 8");
+	pvc3_pipeline *p = new (std::nothrow) pvc3_pipeline;
+	if (!p) return set_error(PVC3_E_NOMEM, "pvc3_pipeline_create: out of memory");
+	p->ctx = ctx;
+	struct guard { pvc3_pipeline *p; ~guard() { if (p) pvc3_pipeline_destroy(p); } } g{p};
+	HIP_TRY(hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&p->s_kernels, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking));
+	p->slots.resize(depth);
+	batch_caps bc;
+	bc.n = caps->max_records; bc.cigar = caps->max_cigar_ops; bc.seq = caps->max_seq_bytes; bc.qual = caps->max_qual_bytes;
+	bc.mates = true;
+	// compact QUAL: 16 bytes per record (about one record in ten realigned at 150 bases); grows on demand
+	bc.qual_compact = caps->max_records * 16 + 65536;
+	for (auto &sl : p->slots)
+	{
+		PVC3_TRY(dbatch_alloc(ctx, bc, &sl.b));
+		HIP_TRY(hipEventCreateWithFlags(&sl.loaded, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&sl.projected, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&sl.downloaded, hipEventDisableTiming));
+	}
+	g.p = nullptr;
+	*out = p;
+	return PVC3_OK;
+}
+
+void pvc3_pipeline_destroy(pvc3_pipeline *p)
+{
+	if (!p) return;
+	(void) hipSetDevice(p->ctx->device);
+	for (hipStream_t s : {p->s_h2d, p->s_kernels, p->s_d2h}) if (s) (void) hipStreamSynchronize(s);
+	for (auto &sl : p->slots)
+	{
+		if (sl.b) pvc3_dbatch_destroy(sl.b);
+		for (hipEvent_t e : {sl.loaded, sl.projected, sl.downloaded}) if (e) (void) hipEventDestroy(e);
+	}
+	for (hipStream_t s : {p->s_h2d, p->s_kernels, p->s_d2h}) if (s) (void) hipStreamDestroy(s);
+	delete p;
+}
+
+int pvc3_pipeline_submit(pvc3_pipeline *p, pvc3_batch_in const *in, pvc3_batch_out const *out, pvc3_params const *params)
+{
+	if (!p || !in || !out || !params) return set_error(PVC3_E_INVALID, "pvc3_pipeline_submit: null argument");
+	uint64_t const depth = p->slots.size();
+	if (p->submitted - p->retired >= depth)
+		return set_error(PVC3_E_STATE, "pvc3_pipeline_submit: %llu batches in flight; call pvc3_pipeline_wait first", (unsigned long long) depth);
+	uint64_t const n = in->n;
+	if (!out->out_cigar_off || !out->run_off || (n && (!out->dst_pos || !out->mate_dst_pos || !out->status)))
+		return set_error(PVC3_E_INVALID, "pvc3_pipeline_submit: a required output array is null");
+	pvc3_context *ctx = p->ctx;
+	PVC3_TRY(check_device(ctx));
+	PVC3_TRY(upload_params(ctx, *params));
+	PVC3_TRY(ensure_scratch(ctx));
+	auto &sl = p->slots[p->submitted % depth];
+	pvc3_dbatch *b = sl.b;
+	// QUAL stays on the host when the kernels can read it there: both arrays page-locked (pvc3_host_alloc).
+	bool const lazy = in->qual && in->qual_off && device_visible_host_pointer(in->qual) && device_visible_host_pointer(in->qual_off);
+	PVC3_TRY(dbatch_load(ctx, b, in, p->s_h2d, lazy));
+	HIP_TRY(hipEventRecord(sl.loaded, p->s_h2d));
+	HIP_TRY(hipStreamWaitEvent(p->s_kernels, sl.loaded, 0));
+	hipStream_t const keep = ctx->stream;
+	ctx->stream = p->s_kernels;
+	b->params = *params; b->attempts = 1; b->finished = false;
+	int const rc = enqueue_projection(ctx, b);
+	ctx->stream = keep;
+	PVC3_TRY(rc);
+	b->projected = true;
+	HIP_TRY(hipEventRecord(sl.projected, p->s_kernels));
+	sl.out = *out; sl.state = 1; sl.error = 0;
+	++p->submitted;
+	// The copies of this batch are queued; now the previous batch (its kernels ran while the host prepared this one) can
+	// start its download, which overlaps this batch's upload and kernels.
+	if (p->submitted - p->retired >= 2)
+	{
+		auto &prev = p->slots[(p->submitted - 2) % depth];
+		if (1 == prev.state)
+			if (int const e = pipeline_start_download(p, prev)) pipeline_note_error(prev, e);
+	}
+	return PVC3_OK;
+}
+
+int pvc3_pipeline_wait(pvc3_pipeline *p, pvc3_batch_stats *stats)
+{
+	if (!p) return set_error(PVC3_E_INVALID, "pvc3_pipeline_wait: null argument");
+	if (p->submitted == p->retired) return set_error(PVC3_E_STATE, "pvc3_pipeline_wait: no batch in flight");
+	PVC3_TRY(check_device(p->ctx));
+	auto &sl = p->slots[p->retired % p->slots.size()];
+	if (1 == sl.state)
+		if (int const e = pipeline_start_download(p, sl)) pipeline_note_error(sl, e);
+	++p->retired;
+	sl.state = 0;
+	if (sl.error)
+		return set_error(sl.error, "%s", sl.message);
+	HIP_TRY(hipEventSynchronize(sl.downloaded));
+	if (stats) fill_stats(p->ctx, sl.b, stats);
+	return PVC3_OK;
+}
+
+int pvc3_pipeline_in_flight(pvc3_pipeline const *p, uint32_t *count)
+{
+	if (!p || !count) return set_error(PVC3_E_INVALID, "pvc3_pipeline_in_flight: null argument");
+	*count = (uint32_t) (p->submitted - p->retired);
+	return PVC3_OK;
 }
 
 int pvc3_project_positions(pvc3_context *ctx, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out)

@@ -32,6 +32,26 @@ __global__ __launch_bounds__(256) void k_project_positions(
 }
 
 
+// The kernels read cigar + cigar_off, seq4 + seq_off and qual + qual_off without further checks; a batch whose offsets decrease,
+// run past the arrays or leave a record fewer SEQ / QUAL bytes than its l_seq promises is refused as a whole.
+__global__ __launch_bounds__(256) void k_validate_batch(dev_batch_in const in, uint64_t n_cigar, uint64_t n_seq, uint64_t n_qual, uint64_t const *__restrict__ qual_off, uint32_t *first_bad)
+{
+	uint64_t const stride = (uint64_t) gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride)
+	{
+		uint64_t const c0 = in.cigar_off[i], c1 = in.cigar_off[i + 1], s0 = in.seq_off[i], s1 = in.seq_off[i + 1];
+		uint32_t const l_seq = in.l_seq[i];
+		bool bad = (c0 > c1) || (c1 > n_cigar) || (s0 > s1) || (s1 > n_seq) || (s1 - s0 < ((uint64_t) l_seq + 1) / 2);
+		if (qual_off && (in.flags[i] & PVC3_FLAG_HAS_QUAL))
+		{
+			uint64_t const q0 = qual_off[i], q1 = qual_off[i + 1];
+			bad = bad || (q0 > q1) || (q1 > n_qual) || (q1 - q0 < l_seq);
+		}
+		if (bad) atomicMin(first_bad, (uint32_t) i);
+	}
+}
+
+
 // ---- packing: exclusive scans of the per-record counts, then a gather into record order ------------------------------
 constexpr uint32_t SCAN_THREADS = 256;
 constexpr uint32_t SCAN_ITEMS = 8;
@@ -276,6 +296,13 @@ int launch_reduce_stats(uint64_t n, dev_batch_work const &work, void *stream)
 {
 	if (n)
 		hipLaunchKernelGGL(k_reduce_stats, dim3((project_wave_count(n) + 255) / 256, 3), dim3(256), 0, (hipStream_t) stream, project_wave_count(n), work);
+	return (int) hipGetLastError();
+}
+
+int launch_validate(dev_batch_in const &in, uint64_t n_cigar, uint64_t n_seq, uint64_t n_qual, uint64_t const *qual_off, uint32_t *first_bad, void *stream)
+{
+	if (in.n)
+		hipLaunchKernelGGL(k_validate_batch, dim3(grid_for(in.n, 256, 256 * 16)), dim3(256), 0, (hipStream_t) stream, in, n_cigar, n_seq, n_qual, qual_off, first_bad);
 	return (int) hipGetLastError();
 }
 

@@ -88,6 +88,9 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	u64x2 *my_desc = lds_desc[wave_in_block];
 	uint32_t *my_mask = lds_mask[wave_in_block];
 	auto get_entry = [&](uint32_t id) -> dev_entry { return (id < LDS_ENTRIES) ? lds_entries[id] : entries[id]; };
+	// A batch whose offsets are malformed (k_validate_batch; a pipelined batch is checked while its kernels are already
+	// queued) is not read at all: every record is rejected and the host reports PVC3_E_INVALID.
+	bool const batch_bad = 0xFFFFFFFFu != rfl(*W.first_bad);
 	uint64_t acc_bitvec = 0, acc_ref = 0, acc_bytes = 0;
 
 	for (uint64_t g = g_begin; g < g_end; ++g)
@@ -101,8 +104,8 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		uint32_t const src_e = in.src_entry[rl];
 		uint32_t const dst_e = in.dst_entry[rl];
 		uint32_t const fl = in.flags[rl];
-		uint64_t const cig_begin = in.cigar_off[rl];
-		uint32_t const n_cigar = (uint32_t) (in.cigar_off[rl + 1] - cig_begin);
+		uint64_t const cig_begin = batch_bad ? 0 : in.cigar_off[rl];
+		uint32_t const n_cigar = batch_bad ? 0 : (uint32_t) (in.cigar_off[rl + 1] - cig_begin);
 		uint64_t const seq_begin = in.seq_off[rl];
 		uint32_t const l_seq = in.l_seq[rl];
 		bool const has_mate = valid && in.mate_pos && (fl & PVC3_FLAG_HAS_MATE);
@@ -152,7 +155,8 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			step(ops[i]);
 
 		uint32_t status = PVC3_ST_OK;
-		if (!e_ok) status = PVC3_ST_SRC_RANGE;
+		if (batch_bad) status = PVC3_ST_QUERY_RANGE;
+		else if (!e_ok) status = PVC3_ST_SRC_RANGE;
 		else if (bad_op) status = PVC3_ST_CIGAR_OP;
 		else if (s_cols != d_cols || (uint64_t) src_pos + (ref_consumed ? ref_consumed : 1u) > s_zeros) status = PVC3_ST_SRC_RANGE;
 		else if (query_consumed > l_seq) status = PVC3_ST_QUERY_RANGE;

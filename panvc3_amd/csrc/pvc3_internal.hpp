@@ -112,6 +112,8 @@ struct dev_counters
 	unsigned long long general_bytes;	// algorithmic bytes of k_project_general (data the fast kernel had not read yet)
 	unsigned int dp_count[DP_CLASSES];	// indel runs per alignment class (k_realign_scan appends, the k_realign_dp launches consume)
 	unsigned int run_records;			// records with an indel run (sum of the per-region work lists, k_run_prefix)
+	unsigned int qual_overflow;			// the compact QUAL buffer of a pipelined batch was too small
+	unsigned long long qual_head;		// next free byte of that buffer
 };
 
 // Per-record results before packing.  flags: bits 0-7 status, bit 8 = has at least one indel run.
@@ -137,8 +139,17 @@ struct dev_batch_work
 	uint32_t *run_prefix;				// [waves of k_project_fast + 1] exclusive prefix sums of run_count (k_run_prefix)
 	run_work *run_items;				// [runs_cap], parallel to runs_arena
 	uint32_t *dp_list;					// [DP_CLASSES][runs_cap] indices into run_items
+	// Pipelined batches leave QUAL in the caller's page-locked host arrays; k_gather_qual fetches it over PCIe for the records
+	// with an indel run only (a fraction of a percent of them) into qual_compact and notes the place in qual_off_dev[record];
+	// dev_batch_in::qual / qual_off then point to these two.
+	uint8_t const *host_qual;			// device-visible host pointers, null when QUAL was uploaded with the batch
+	uint64_t const *host_qual_off;
+	uint8_t *qual_compact;
+	uint64_t qual_compact_cap;
+	uint64_t *qual_off_dev;				// [records]
 	unsigned long long *wave_stats;		// [3 kernels][waves][WAVE_STATS]: per-wave sums, folded into `counters` by k_reduce_stats
 	dev_counters *counters;
+	uint32_t const *first_bad;			// k_validate_batch: 0xFFFFFFFF, or the first record with a malformed layout (then nothing of the batch is read)
 };
 
 struct dev_batch_packed
@@ -181,6 +192,8 @@ int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &
 int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);
 int launch_pack_text4(uint8_t const *text, uint64_t len, uint8_t *out, void *stream);
 int launch_project_positions(dev_entry const *entries, uint32_t n_entries, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out, void *stream);
+// Layout check of a freshly loaded batch; *first_bad = smallest malformed record (left at 0xFFFFFFFF if there is none).
+int launch_validate(dev_batch_in const &in, uint64_t n_cigar, uint64_t n_seq, uint64_t n_qual, uint64_t const *qual_off, uint32_t *first_bad, void *stream);
 uint32_t realign_lds_bytes();
 uint32_t project_wave_count(uint64_t n);
 uint64_t pack_scan_tmp_words(uint64_t n);

@@ -32,6 +32,7 @@ constexpr uint32_t TR_DIAG = 0, TR_UP = 1, TR_LEFT = 2, TR_DIR_MASK = 3, TR_V_OP
 constexpr uint32_t MAX_PHRED = 41;
 constexpr uint32_t NO_QUAL = MAX_PHRED + 1;			// row of the score table for records without base qualities: 0 / -1
 constexpr uint32_t SCORE_ROWS = NO_QUAL + 1;
+constexpr uint32_t SCAN_STAGE = 256;				// work items per class a wave of k_realign_scan collects before it appends them
 
 // seqan3::dna5 ranks (A C G N T); assign_char is case-insensitive, U -> T, anything else -> N.
 __device__ __forceinline__ uint32_t dna5_rank_of_char(uint32_t c)
@@ -58,6 +59,16 @@ __device__ __forceinline__ double shfl_up_f64(double v)
 	a.d = v;
 	r.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], 0x138, 0xf, 0xf, false);
 	r.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], 0x138, 0xf, 0xf, false);
+	return r.d;
+}
+
+// The same, but lane 0 receives 0.0 (no dependency on the previous contents of the destination: one instruction per half).
+__device__ __forceinline__ double shfl_up_f64_zero(double v)
+{
+	union { double d; int i[2]; } a, r;
+	a.d = v;
+	r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x138, 0xf, 0xf, true);
+	r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x138, 0xf, 0xf, true);
 	return r.d;
 }
 
@@ -121,6 +132,62 @@ __device__ __forceinline__ uint32_t listed_record(dev_batch_work const &W, uint3
 	return W.run_list[64 * (n_groups * lo / n_regions) + (i - W.run_prefix[lo])];
 }
 
+// QUAL of the listed records from the caller's page-locked host arrays into the batch's compact device buffer (see
+// dev_batch_work::host_qual): lane = record for the bookkeeping, the whole wave copies one record at a time.
+__global__ __launch_bounds__(256) void k_gather_qual(dev_batch_in const in, dev_batch_work const W, uint32_t n_regions)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const wave = rfl((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	uint32_t const n_waves = (gridDim.x * blockDim.x) >> 6;
+	uint64_t const n_groups = (in.n + 63) / 64;
+	uint32_t const total = W.run_prefix[n_regions];
+	for (uint32_t base = 64 * wave; base < total; base += 64 * n_waves)
+	{
+		bool const mine = base + lane < total;
+		uint32_t rec = 0, len = 0;
+		uint64_t src_off = 0;
+		if (mine)
+		{
+			rec = listed_record(W, n_regions, n_groups, base + lane);
+			if (in.flags[rec] & PVC3_FLAG_HAS_QUAL)
+			{
+				len = in.l_seq[rec];
+				src_off = W.host_qual_off[rec];		// read over PCIe
+			}
+		}
+		uint32_t const rounded = (len + 3) & ~3u;
+		uint32_t const scan = wave_inclusive_scan(rounded, lane);
+		uint32_t const sum = readlane(scan, 63);
+		if (0 == sum) continue;
+		unsigned long long at = 0;
+		if (0 == lane) at = atomicAdd(&W.counters->qual_head, (unsigned long long) sum);
+		at = rfl64(at);
+		if (at + sum + 4 > W.qual_compact_cap)
+		{
+			W.counters->qual_overflow = 1;		// the host grows the buffer and repeats the batch
+			continue;
+		}
+		uint64_t const dst_off = at + (scan - rounded);
+		if (mine) W.qual_off_dev[rec] = dst_off;
+		uint64_t todo = ballot(len > 0);
+		while (todo)
+		{
+			uint32_t const r = ctz64(todo);
+			todo &= todo - 1;
+			uint8_t const *src = W.host_qual + rfl64(readlane((uint32_t) src_off, r) | ((uint64_t) readlane((uint32_t) (src_off >> 32), r) << 32));
+			uint8_t *dst = W.qual_compact + rfl64(readlane((uint32_t) dst_off, r) | ((uint64_t) readlane((uint32_t) (dst_off >> 32), r) << 32));
+			uint32_t const n = readlane(len, r);
+			for (uint32_t x = 4 * lane; x < n; x += 256)
+			{
+				// whole dwords where the record has them (the destination is 4-byte aligned and padded), single bytes at its end:
+				// nothing is read past the caller's array
+				if (x + 4 <= n) { uint32_t v; __builtin_memcpy(&v, src + x, 4); *(uint32_t *) (dst + x) = v; }
+				else for (uint32_t y = x; y < n; ++y) dst[y] = src[y];
+			}
+		}
+	}
+}
+
 // indel_run_checker (indel_run_checker.cc:13-121) over `n_ops` operations; calls on_run(first op, end op, reference start,
 // reference length, query start, query length, reference position at report time) for every run with both I and D.
 template <typename t_on_run>
@@ -174,6 +241,23 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 	arena_alloc arena{0, 0}, runs_alloc{0, 0};
 	uint32_t acc_runs = 0, acc_failed = 0;
 	uint64_t acc_qual = 0;
+	// The work items of a class are collected per wave in LDS and appended to the class list with one atomic per flush:
+	// an atomic per class and 64 records (half a million of them on the same cache line in config C5) made this kernel
+	// five times slower than the rest of its work.
+	__shared__ uint32_t lds_items[4][DP_CLASSES][SCAN_STAGE];
+	uint32_t (*stage)[SCAN_STAGE] = lds_items[rfl(threadIdx.x >> 6)];
+	uint32_t staged[DP_CLASSES];		// wave-uniform
+#pragma unroll
+	for (uint32_t c = 0; c < DP_CLASSES; ++c) staged[c] = 0;
+	auto flush = [&](uint32_t c) {
+		uint32_t const cnt = staged[c];
+		uint32_t at = 0;
+		if (0 == lane) at = atomicAdd(&W.counters->dp_count[c], cnt);
+		at = rfl(at);
+		for (uint32_t i = lane; i < cnt; i += 64)
+			W.dp_list[(uint64_t) c * W.runs_cap + at + i] = stage[c][i];
+		staged[c] = 0;
+	};
 
 	for (uint32_t base = 64 * wave; base < total; base += 64 * n_waves)
 	{
@@ -256,17 +340,21 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 		for (uint32_t r = 0; r < 2; ++r)
 		{
 			if (0 == ballot(cls[r] < DP_CLASSES)) continue;
+#pragma unroll
 			for (uint32_t c = 0; c < DP_CLASSES; ++c)
 			{
 				uint64_t const mk = ballot(cls[r] == c);
 				if (!mk) continue;
-				uint32_t at = 0;
-				if (0 == lane) at = atomicAdd(&W.counters->dp_count[c], popc64(mk));
-				at = rfl(at);
-				if ((mk >> lane) & 1) W.dp_list[(uint64_t) c * W.runs_cap + at + mbcnt64(mk)] = (uint32_t) (my_runs + r);
+				if (staged[c] + 64 > SCAN_STAGE) { wave_lds_fence(); flush(c); wave_lds_fence(); }
+				if ((mk >> lane) & 1) stage[c][staged[c] + mbcnt64(mk)] = (uint32_t) (my_runs + r);
+				staged[c] += popc64(mk);
 			}
 		}
 	}
+	wave_lds_fence();
+#pragma unroll
+	for (uint32_t c = 0; c < DP_CLASSES; ++c)
+		if (staged[c]) flush(c);
 	for (int off = 32; off; off >>= 1)
 	{
 		acc_runs += __shfl_xor(acc_runs, off);
@@ -292,7 +380,7 @@ struct dp_shared
 {
 	double score[SCORE_ROWS][2];					// [phred or NO_QUAL][0 match, 1 mismatch]
 	uint32_t trace[DP_MAX_STEPS / 8][64];			// 4 bits per cell: lane's nibble of step t in trace[t / 8][lane] at 4 (t % 8)
-	uint16_t stream[4][DP_MAX_STEPS];				// per run: the items along the longer side, dna5 rank | phred << 8
+	uint16_t stream[4][64 + DP_MAX_STEPS + 8];			// per run: the items along the longer side, dna5 rank | phred << 8, behind 64 unused entries
 };
 
 template <uint32_t t_width, bool t_ref_lanes>
@@ -346,7 +434,7 @@ __global__ __launch_bounds__(64, 7) void k_realign_dp(
 		if (l < n_short)
 			own = t_ref_lanes ? dna5_rank_of_char(text[l]) : query_item(l);
 		for (uint32_t x = l; x < n_long; x += t_width)
-			S.stream[g][x] = (uint16_t) (t_ref_lanes ? query_item(x) : dna5_rank_of_char(text[x]));
+			S.stream[g][64 + x] = (uint16_t) (t_ref_lanes ? query_item(x) : dna5_rank_of_char(text[x]));
 		uint32_t const own_rank = own & 7, own_q = own >> 8;
 
 		uint32_t steps = have ? (n_long + n_short - 1) : 0;
@@ -368,7 +456,10 @@ __global__ __launch_bounds__(64, 7) void k_realign_dp(
 		double cur_m = 0.0, cur_a = neg_inf;			// what the next lane receives: this line's M and its across-the-lines gap score
 		double bnd = 0.0;								// lane 0: gap(t + 1) while stepping
 		uint32_t acc = 0;
-		uint32_t item_next = S.stream[g][0];			// item of position 1 (index 0); lane l uses index t - l at step t
+		// Lane l uses item t - l in step t; the 64 entries in front of the stream make the index non-negative (whatever they
+		// hold is read by lanes that are not active yet).
+		uint16_t const *my_stream = &S.stream[g][64 - l];
+		uint32_t item_next = my_stream[0];
 		for (uint32_t t = 0; t < steps; ++t)
 		{
 			double nb_m, nb_a;
@@ -380,36 +471,35 @@ __global__ __launch_bounds__(64, 7) void k_realign_dp(
 			}
 			else
 			{
-				nb_m = shfl_up_f64(cur_m);
-				nb_a = shfl_up_f64(cur_a);
+				nb_m = shfl_up_f64_zero(cur_m);
+				nb_a = shfl_up_f64_zero(cur_a);
 				if (0 == l) { nb_m = bnd; nb_a = neg_inf; }
 			}
 			uint32_t const pos = t - l + 1;				// 1-based position along the longer side handled in this step
 			bool const active = line_ok && (t >= l) && (pos <= n_long);
 			uint32_t const item = item_next;
-			{
-				uint32_t const nx = (t + 1 >= l) ? (t + 1 - l) : 0;
-				item_next = S.stream[g][(nx < DP_MAX_STEPS) ? nx : 0];
-			}
+			item_next = my_stream[t + 1];				// t + 1 <= DP_MAX_STEPS: inside the array for every lane
 			uint32_t nib = 0;
 			if (active)
 			{
 				bool const is_match = (item & 7) == own_rank;
 				uint32_t const qi = t_ref_lanes ? (item >> 8) : own_q;
 				double const s = S.score[qi][is_match ? 0 : 1];
+				// The larger value wins and ties keep the extension: max() gives the value (equal operands are the same number, no
+				// NaN can arise from finite scores and -inf), the comparison only feeds the trace bit.
 				double const a_open = nb_m + go, a_ext = nb_a + ge;
-				double a; bool a_opened;
-				if (a_ext < a_open) { a = a_open; a_opened = true; } else { a = a_ext; a_opened = false; }
+				double const a = __builtin_fmax(a_ext, a_open); bool const a_opened = a_ext < a_open;
 				double const b_open = own_m + go, b_ext = own_b + ge;
-				double b; bool b_opened;
-				if (b_ext < b_open) { b = b_open; b_opened = true; } else { b = b_ext; b_opened = false; }
+				double const b = __builtin_fmax(b_ext, b_open); bool const b_opened = b_ext < b_open;
 				// lanes along the query: a = V (from the row above), b = H; lanes along the reference: a = H (from the column to the left), b = V
 				double const v = t_ref_lanes ? b : a, h = t_ref_lanes ? a : b;
 				bool const v_opened = t_ref_lanes ? b_opened : a_opened, h_opened = t_ref_lanes ? a_opened : b_opened;
-				double best = diag + s;
+				double const d = diag + s;
 				uint32_t state = is_match ? 0u : 1u;		// 0 diagonal match, 1 diagonal mismatch, 2 up, 3 left
-				if (best < v) { best = v; state = 2; }
-				if (best < h) { best = h; state = 3; }
+				double const dv = __builtin_fmax(d, v);
+				if (d < v) state = 2;
+				double const best = __builtin_fmax(dv, h);
+				if (dv < h) state = 3;
 				nib = state | (v_opened ? 4u : 0u) | (h_opened ? 8u : 0u);
 				own_m = best; own_b = b; cur_m = best; cur_a = a; diag = nb_m;
 			}
@@ -429,36 +519,28 @@ __global__ __launch_bounds__(64, 7) void k_realign_dp(
 		{
 			uint32_t *slot_end = W.arena + it.ops_loc + (it.m + it.n);
 			uint32_t n_out = 0, cur_op = 0xf, cur_cnt = 0;
-			auto emit = [&](uint32_t op) {
-				if (op == cur_op) { ++cur_cnt; return; }
-				if (cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
-				cur_op = op; cur_cnt = 1;
-			};
 			uint32_t i = it.n, j = it.m, st = 0;		// st: 0 = M, 1 = V (up), 2 = H (left)
-			while (i || j)
+			uint32_t const lane_base = g * t_width - 1;
+			// One cell per iteration, written as data flow (a branch per case costs more than the arithmetic when 1 - 4 lanes of
+			// the wave run this loop): the nibble of the cell, the direction taken, the operation, the next state.
+			while (i | j)
 			{
-				uint32_t nibble;
-				if (0 == i) nibble = 3 | ((1 == j) ? 8u : 0u);			// first row: left, opened at column 1
-				else if (0 == j) nibble = 2 | ((1 == i) ? 4u : 0u);		// first column
-				else
-				{
-					uint32_t const t = i + j - 2;
-					uint32_t const ln = g * t_width + (t_ref_lanes ? j : i) - 1;
-					nibble = (S.trace[t >> 3][ln] >> (4 * (t & 7))) & 0xf;
-				}
-				if (0 == st)
-				{
-					uint32_t const state = nibble & 3;
-					if (state < 2)
-					{
-						emit(state ? OP_X : OP_EQ);		// align.hh:103-106
-						--i; --j;
-						continue;
-					}
-					st = (2 == state) ? 1 : 2;
-				}
-				if (1 == st) { emit(OP_I); if (nibble & 4) st = 0; --i; }
-				else { emit(OP_D); if (nibble & 8) st = 0; --j; }
+				uint32_t const t = i + j - 2;
+				bool const inner = (0 != i) && (0 != j);
+				uint32_t const word = S.trace[inner ? (t >> 3) : 0][inner ? (lane_base + (t_ref_lanes ? j : i)) : 0];
+				uint32_t const edge = (0 == i) ? (3u | ((1 == j) ? 8u : 0u)) : (2u | ((1 == i) ? 4u : 0u));	// first row: left, opened at column 1; first column: up
+				uint32_t const nibble = inner ? ((word >> (4 * (t & 7))) & 0xfu) : edge;
+				uint32_t const state = nibble & 3;
+				uint32_t const dir = (0 == st) ? ((state < 2) ? 0u : (state - 1)) : st;		// 0 diagonal, 1 up, 2 left
+				uint32_t const op = (0 == dir) ? ((state & 1) ? OP_X : OP_EQ) : ((1 == dir) ? OP_I : OP_D);		// align.hh:99-106
+				bool const opened = 0 != (nibble & ((1 == dir) ? 4u : 8u));
+				st = (0 == dir || opened) ? 0u : dir;
+				i -= (2 != dir) ? 1u : 0u;
+				j -= (1 != dir) ? 1u : 0u;
+				bool const same = (op == cur_op);
+				if (!same && cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
+				cur_cnt = same ? (cur_cnt + 1) : 1u;
+				cur_op = op;
 			}
 			if (cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
 			W.run_items[item_idx].n_out = n_out;
@@ -743,6 +825,8 @@ int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in co
 	hipStream_t const s = (hipStream_t) stream;
 	uint32_t const list_blocks = (n_regions + 3) / 4 < 2048 ? (n_regions + 3) / 4 : 2048;
 	hipLaunchKernelGGL(k_run_prefix, dim3(1), dim3(1024), 0, s, n_regions, work);
+	if (work.host_qual)
+		hipLaunchKernelGGL(k_gather_qual, dim3(list_blocks), dim3(256), 0, s, in, work, n_regions);
 	hipLaunchKernelGGL(k_realign_scan, dim3(list_blocks), dim3(256), 0, s, entries, in, work, n_regions, packed);
 	if (n_waves < 1) n_waves = 1;
 	hipLaunchKernelGGL((k_realign_dp <16, false>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 0u);

@@ -544,6 +544,8 @@ public:
 			if (4 != got || block_size < 32) throw io_error("truncated BAM record");
 			r.data.resize((std::size_t) block_size);
 			if ((std::size_t) block_size != m_in.read(r.data.data(), (std::size_t) block_size)) throw io_error("truncated BAM record");
+			// l_read_name, n_cigar_op and l_seq must fit the record: everything downstream slices the buffer by them
+			if (r.aux_offset() > r.data.size()) throw io_error("malformed BAM record: its name, CIGAR, SEQ and QUAL exceed block_size");
 			return true;
 		}
 		while (m_in.getline(m_line))

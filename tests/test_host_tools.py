@@ -204,6 +204,23 @@ def test_io_round_trip_sam_bam(tools, tmp_path):
 	open(tmp_path / "cut.bam", "wb").write(raw[:len(raw) // 2])
 	p = _run([tools["panvc3_project_alignments"], "--io-only", "-a", "cut.bam", "-o", "cut.sam"], cwd=tmp_path, check=False)
 	assert p.returncode != 0 and b"ERROR" in p.stderr
+	# a record whose l_seq (or n_cigar_op, l_read_name) points past its block_size is an error, not an out-of-bounds read
+	import struct
+	ref_index2 = {n: i for i, n in enumerate(names)}
+	refs2 = [(n, 10000 + i) for i, n in enumerate(names)]
+	for field_off, fmt, value in ((16, "<I", 100000), (12, "<H", 60000), (8, "<B", 255)):
+		rawbam = b"BAM\1" + struct.pack("<i", len(header)) + header.encode() + struct.pack("<i", len(refs2))
+		for n, l in refs2:
+			rawbam += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+		good = bamio.bam_bytes(recs[0], ref_index2)
+		bad = bytearray(bamio.bam_bytes(recs[1], ref_index2))
+		struct.pack_into(fmt, bad, 4 + field_off, value)
+		rawbam += good + bytes(bad)
+		with open(tmp_path / "bad.bam", "wb") as f:
+			f.write(bamio._bgzf_block(rawbam))
+			f.write(bamio._bgzf_block(b""))
+		p = _run([tools["panvc3_project_alignments"], "--io-only", "-a", "bad.bam", "-o", "bad.sam"], cwd=tmp_path, check=False)
+		assert p.returncode != 0 and b"malformed BAM record" in p.stderr, (field_off, p.stderr)
 	# python-written BAM is read too (bgzf blocks written by another implementation)
 	bamio.write_bam(tmp_path / "py.bam", header, [(n, 10000 + i) for i, n in enumerate(names)], recs)
 	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "py.bam", "-o", "py.sam"], cwd=tmp_path)

@@ -488,3 +488,110 @@ def test_one_large_alignment_among_many_small(pvc3, oracle_mod):
 	assert stats["attempts"] == 2 and stats["n_runs"] == 300
 	_, workspace = ctx.hbm_bytes()
 	assert workspace <= (16 << 20) + (1 << 20)
+
+
+def test_pipeline_matches_batch_project(pvc3, oracle_mod, synth):
+	"""pvc3_pipeline_submit / _wait (uploads, kernels and downloads of consecutive batches overlapping; QUAL fetched from the
+	page-locked host arrays for the realigned records only) returns byte for byte what pvc3_batch_project returns, batch by
+	batch, in submission order; the same with pageable arrays (QUAL uploaded); full pipeline and capacity errors."""
+	gp, rp, _ = synth.config("C5", scale=0.004)
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	batch = reads.batch()
+	index = pvc3.Index()
+	genome.fill_index(index)
+	ctx = pvc3.Context(0)
+	ctx.upload_index(index)
+	o = oracle_mod.Oracle()
+	genome.fill_index(o)
+	n, per = reads.n, 20_000
+	slices = [synth.slice_batch(batch, lo, min(n, lo + per)) for lo in range(0, n, per)]
+	want = [o.batch_project(s, n_threads=8) for s in slices]
+	max_cig = max(int(s["cigar"].size) for s in slices)
+	max_seq = max(int(s["seq4"].size) for s in slices)
+	max_qual = max(int(s["qual"].size) for s in slices)
+	for pinned in (True, False):
+		depth = 3
+		pipe = pvc3.Pipeline(ctx, per, max_cig, max_seq, 0 if pinned else max_qual, depth)
+		outs = [pvc3.Pipeline.output_arrays(per, 8 * max_cig + 16 * per, per, pinned=pinned) for _ in range(depth)]
+		keep = []
+		got = []
+		subs = []
+		for s in slices:
+			if pinned:
+				s, own = pvc3.pinned_batch(s)
+				keep.append(own)
+			subs.append(s)
+		for i, s in enumerate(subs):
+			if pipe.in_flight() == depth:
+				res, st = pipe.wait()
+				got.append({k: v.copy() for k, v in res.items()})
+			pipe.submit(s, outs[i % depth])
+		assert pipe.in_flight() == depth		# three batches in flight: a fourth is refused
+		with pytest.raises(pvc3.Error) as ei:
+			pipe.submit(subs[0], outs[0])
+		assert ei.value.code == -6
+		while pipe.in_flight():
+			res, st = pipe.wait()
+			got.append({k: v.copy() for k, v in res.items()})
+		assert len(got) == len(slices)
+		for s, g, w in zip(slices, got, want):
+			assert_results_equal(s, g, w)
+		# a batch beyond the capacities is refused, results larger than the output arrays are reported by wait()
+		with pytest.raises(pvc3.Error) as ei:
+			pipe.submit(synth.slice_batch(batch, 0, per + 1), outs[0])
+		assert ei.value.code == -5
+		small = pvc3.Pipeline.output_arrays(per, 10, 1, pinned=False)
+		pipe.submit(subs[0], small)
+		with pytest.raises(pvc3.Error) as ei:
+			pipe.wait()
+		assert ei.value.code == -5
+		pipe.submit(subs[1], outs[1])		# the pipeline goes on after an error
+		res, st = pipe.wait()
+		assert_results_equal(slices[1], res, want[1])
+		pipe.close()
+	ctx.close()
+
+
+def test_malformed_batches_are_refused(pvc3, oracle_mod):
+	"""Offsets that decrease or run past their arrays, and records whose SEQ / QUAL slices are shorter than l_seq, make the
+	kernels read outside the batch: such a batch is refused as a whole (PVC3_E_INVALID), also in the pipeline."""
+	rng = np.random.default_rng(5)
+	text = "".join("ACGT"[x] for x in rng.integers(0, 4, size=500))
+	ctx, o, ids = _edge_index(pvc3, oracle_mod, [(text, text, text)])
+	s, d = ids[0]
+	bb = BatchBuilder()
+	for p in range(0, 300, 10):
+		bb.add(p, s, d, "100M", text[p:p + 100], qual=[30] * 100)
+	good = bb.build()
+	got, stats = pvc3.project_batch(ctx, good)
+	assert_results_equal(good, got, o.batch_project(good))
+
+	def broken(**changes):
+		b = {k: v.copy() for k, v in good.items()}
+		for k, (i, v) in changes.items():
+			b[k][i] = v
+		return b
+	cases = [
+		broken(cigar_off=(5, 3)),							# decreasing
+		broken(cigar_off=(30, 1000)),						# past the array
+		broken(seq_off=(7, int(good["seq_off"][8]) - 1)),	# decreasing start: record 6 loses a byte ... and 7 starts early (fine), 6 is short
+		broken(seq_off=(30, 10**9)),
+		broken(l_seq=(4, 5000)),							# l_seq promises more SEQ than the record owns
+		broken(qual_off=(9, int(good["qual_off"][9]) + 50)),	# record 8 keeps 150 bytes, record 9 only 50
+		broken(qual_off=(30, 10**9)),
+	]
+	for bad in cases:
+		with pytest.raises(pvc3.Error) as ei:
+			pvc3.project_batch(ctx, bad)
+		assert ei.value.code == -1, ei.value
+	pipe = pvc3.Pipeline(ctx, 64, 256, 4096, 8192)
+	out = pvc3.Pipeline.output_arrays(64, 4096, 64, pinned=False)
+	pipe.submit(cases[0], out)
+	pipe.submit(good, pvc3.Pipeline.output_arrays(64, 4096, 64, pinned=False))
+	with pytest.raises(pvc3.Error) as ei:
+		pipe.wait()
+	assert ei.value.code == -1
+	res, st = pipe.wait()
+	assert_results_equal(good, res, o.batch_project(good))
+	pipe.close()

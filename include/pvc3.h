@@ -14,6 +14,10 @@
  *                                        project_alignments.cc:575-594, :726
  *   pvc3_project_positions               msa_index::sequence_entry::project_position include/panvc3/msa_index.hh:253-258
  *                                        (call sites project_alignments.cc:900, convert-bed-positions/main.cc:60-73)
+ *   pvc3_rescore_alignments              cigar_alignment_scorer::calculate_score recalculate-mapq/main.cc:189-289
+ *   pvc3_recalculate_mapq                mapq_scorer::process_alignment_group recalculate-mapq/main.cc:962-1180 and
+ *                                        bowtie2_v2_score_calculator::calculate_mapq :441-566
+ *   pvc3_pipeline_*                      the record loop input_processor::process_input project_alignments.cc:484-655 (:600-627)
  *   pvc3_batch_project / pvc3_dbatch_*   alignment_projector::project_alignment include/panvc3/alignment_projector.hh:58-68
  *                                        + accessors :70-74 (alignment(), realigned_reference_ranges(),
  *                                        realigned_query_ranges()), libpanvc3/alignment_projector.cc:30-154
@@ -182,7 +186,7 @@ PVC3_API int pvc3_context_set_stream(pvc3_context *ctx, void *hip_stream);
 PVC3_API int pvc3_context_set_timing(pvc3_context *ctx, int enabled);	/* hipEvent pairs around each kernel group */
 PVC3_API int pvc3_context_synchronize(pvc3_context *ctx);
 /* Tuning / test knobs: "realign_waves", "big_waves", "realign_lds_bytes", "scratch_per_wave", "scratch_budget" (bytes: the
- * alignment scratch slots together never exceed it), "arena_initial", "runs_initial",
+ * alignment scratch slots together never exceed it), "trace_initial" (32-bit words of the alignment trace buffer), "arena_initial", "runs_initial",
  * "fast_path" (0: no lane-parallel compare in k_project_fast), "mid_path" (0: skip k_project_mid; with both at 0 every
  * record goes through the cooperative column walk of k_project_general), "packed_dp" (0: every indel run is aligned by the
  * striped one-run-per-wavefront kernel instead of the packed kernels). */
@@ -236,6 +240,54 @@ PVC3_API int pvc3_pipeline_in_flight(pvc3_pipeline const *pipeline, uint32_t *co
  * pvc3_dbatch_download run at about a third of the PCIe rate.  Any thread; free with pvc3_host_free. */
 PVC3_API int pvc3_host_alloc(uint64_t bytes, void **ptr);
 PVC3_API void pvc3_host_free(void *ptr);
+
+/* ---- recalculate_mapq (recalculate-mapq/main.cc; the step after project_alignments in both workflows) -------------------- */
+#define PVC3_NO_POS 0xFFFFFFFFu		/* a reference id / position field or tag that is not set */
+#define PVC3_MAPQ_NO_NEXT_RECORD 255	/* main.cc:51 */
+
+/* Alignment score from the CIGAR, the base qualities and the XN bit map (cigar_alignment_scorer, main.cc:155-289). */
+typedef struct pvc3_rescore_params
+{
+	int32_t min_mismatch_penalty;	/* --min-mismatch-penalty, default 2 */
+	int32_t max_mismatch_penalty;	/* --max-mismatch-penalty, default 6 */
+	int32_t n_penalty;				/* --n-penalty, default 1 */
+	int32_t gap_opening_penalty;	/* --gap-opening-penalty, default 5 */
+	int32_t gap_extension_penalty;	/* --gap-extension-penalty, default 3 */
+} pvc3_rescore_params;
+enum
+{
+	PVC3_RESCORE_OK = 0,
+	PVC3_RESCORE_CIGAR_OP = 1,		/* an M (or unknown) operation: the CIGAR must use = and X (main.cc:275-279 libbio_fail) */
+	PVC3_RESCORE_XN_RANGE = 2,		/* an X operation beyond the XN bit map (main.cc:266 libbio_always_assert_lt) */
+	PVC3_RESCORE_QUERY_RANGE = 3	/* the CIGAR consumes more bases than l_seq */
+};
+/* score[i] = alignment score of record i (a non-positive whole number as double); status[i] = PVC3_RESCORE_*.  The arrays are
+ * those of pvc3_batch_in (BAM-encoded CIGARs, 4-bit SEQ, raw phred QUAL; qual may be NULL: quality 0) plus xn / xn_off
+ * [n + 1]: the bytes of each record's XN tag (B:C array; bit rp % 8 of byte rp / 8 <=> reference N at alignment-relative rp). */
+PVC3_API int pvc3_rescore_alignments(pvc3_context *ctx, uint64_t n, uint64_t const *cigar_off, uint32_t const *cigar, uint64_t const *seq_off, uint8_t const *seq4,
+	uint32_t const *l_seq, uint64_t const *qual_off, uint8_t const *qual, uint64_t const *xn_off, uint8_t const *xn, pvc3_rescore_params const *params, double *score, int32_t *status);
+
+/* Records grouped by QNAME (consecutive records of one group), as mapq_scorer::process_alignment_group sees them
+ * (main.cc:962-1180).  Unmapped records are not part of the input (main.cc:1236-1238). */
+typedef struct pvc3_mapq_batch
+{
+	uint64_t n_groups;
+	uint64_t const *group_off;			/* [n_groups + 1] record ranges of the groups */
+	uint32_t const *ref_id, *pos;		/* [n] projected RNAME (numeric id) and 0-based POS; PVC3_NO_POS where unset */
+	uint32_t const *mate_ref_id, *mate_pos;				/* RNEXT / PNEXT */
+	uint32_t const *orig_ref_id, *orig_pos;				/* --original-rname-tag / --original-pos-tag (XR / XP); PVC3_NO_POS where missing */
+	uint32_t const *orig_mate_ref_id, *orig_mate_pos;	/* --original-rnext-tag / --original-pnext-tag (YR / YP) */
+	double const *score;				/* the AS value (or the rescored one); -DBL_MAX where the record has no AS tag (main.cc:177-178) */
+	uint32_t const *l_seq;
+	uint32_t const *seq_class;			/* equal inside a group <=> equal SEQ (consulted for groups of unpaired records only) */
+} pvc3_mapq_batch;
+typedef struct pvc3_mapq_stats			/* the counters the reference prints at the end (main.cc:1268-1276) */
+{
+	uint64_t total_alignments, unpaired_alignments, reads_with_and_without_mate, mate_not_found, reads_without_valid_position;
+} pvc3_mapq_stats;
+/* mapq[i] = new MAPQ of record i (PVC3_MAPQ_NO_NEXT_RECORD as in the reference); group_emitted[g] = 0 for the groups the
+ * reference skips (records with and without a mate under one name, main.cc:1039-1044), whose records are not written. */
+PVC3_API int pvc3_recalculate_mapq(pvc3_context *ctx, pvc3_mapq_batch const *in, uint8_t *mapq, uint8_t *group_emitted, pvc3_mapq_stats *stats);
 
 /* project_position for n independent positions: out[i] = rank0_dst(select0_src(1 + pos[i])); PVC3_NO_MATE if out of range. */
 PVC3_API int pvc3_project_positions(pvc3_context *ctx, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out);

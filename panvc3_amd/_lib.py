@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpvc3_hip.so")
+LIB_PATH = os.environ.get("PVC3_LIB_PATH") or os.path.join(HERE, "libpvc3_hip.so")		# the override is for diagnostic builds (tools/)
 
 _lib = None
 
@@ -48,6 +48,19 @@ class BatchStats(C.Structure):
 		("n_fast_path", C.c_uint64), ("n_mid_path", C.c_uint64), ("ms_project", C.c_float), ("ms_mid", C.c_float), ("ms_general", C.c_float),
 		("ms_realign", C.c_float), ("ms_pack", C.c_float), ("attempts", C.c_uint32),
 	]
+
+
+class RescoreParams(C.Structure):
+	_fields_ = [("min_mismatch_penalty", C.c_int32), ("max_mismatch_penalty", C.c_int32), ("n_penalty", C.c_int32), ("gap_opening_penalty", C.c_int32), ("gap_extension_penalty", C.c_int32)]
+
+
+class MapqBatch(C.Structure):
+	_fields_ = [("n_groups", C.c_uint64), ("group_off", C.c_void_p)] + [(k, C.c_void_p) for k in (
+		"ref_id", "pos", "mate_ref_id", "mate_pos", "orig_ref_id", "orig_pos", "orig_mate_ref_id", "orig_mate_pos", "score", "l_seq", "seq_class")]
+
+
+class MapqStats(C.Structure):
+	_fields_ = [(k, C.c_uint64) for k in ("total_alignments", "unpaired_alignments", "reads_with_and_without_mate", "mate_not_found", "reads_without_valid_position")]
 
 
 class PipelineCaps(C.Structure):
@@ -99,6 +112,8 @@ def lib():
 		"pvc3_dbatch_download": ([vp, vp, P(BatchOut)], i32),
 		"pvc3_dbatch_checksum": ([vp, vp, u64, P(u64)], i32),
 		"pvc3_project_positions": ([vp, u64, vp, vp, vp, vp], i32),
+		"pvc3_rescore_alignments": ([vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, P(RescoreParams), vp, vp], i32),
+		"pvc3_recalculate_mapq": ([vp, P(MapqBatch), vp, vp, P(MapqStats)], i32),
 		"pvc3_pipeline_create": ([vp, P(PipelineCaps), P(vp)], i32),
 		"pvc3_pipeline_destroy": ([vp], None),
 		"pvc3_pipeline_submit": ([vp, P(BatchIn), P(BatchOut), P(Params)], i32),

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BatchIn, BatchOut, BatchStats, Params, PipelineCaps, check
+from ._lib import BatchIn, BatchOut, BatchStats, MapqBatch, MapqStats, Params, PipelineCaps, RescoreParams, check
 
 CIGAR_OPS = "MIDNSHP=X"
 SCORE_FP64 = 0
@@ -295,6 +295,56 @@ def pinned_batch(batch):
 		out[k] = pa.array
 		owners.append(pa)
 	return out, owners
+
+
+NO_POS = 0xFFFFFFFF
+SCORE_MIN = -1.7976931348623157e308		# the score of a record without an AS tag (recalculate-mapq/main.cc:50)
+_MAPQ_FIELDS = ("ref_id", "pos", "mate_ref_id", "mate_pos", "orig_ref_id", "orig_pos", "orig_mate_ref_id", "orig_mate_pos", "l_seq", "seq_class")
+
+
+def rescore_alignments(ctx, batch, xn_off, xn, min_mismatch_penalty=2, max_mismatch_penalty=6, n_penalty=1, gap_opening_penalty=5, gap_extension_penalty=3):
+	"""pvc3_rescore_alignments: cigar_alignment_scorer::calculate_score (recalculate-mapq/main.cc:189-289) for every record of a
+	batch (cigar_off / cigar / seq_off / seq4 / l_seq / qual_off / qual as in pvc3_batch_in) -> (scores float64, status int32)."""
+	n = int(np.asarray(batch["l_seq"]).size)
+	a = {k: np.ascontiguousarray(batch[k], dtype=dt) for k, dt in (("cigar_off", np.uint64), ("cigar", np.uint32), ("seq_off", np.uint64), ("seq4", np.uint8), ("l_seq", np.uint32))}
+	has_qual = batch.get("qual") is not None and batch.get("qual_off") is not None
+	qo = np.ascontiguousarray(batch["qual_off"], dtype=np.uint64) if has_qual else None
+	q = np.ascontiguousarray(batch["qual"], dtype=np.uint8) if has_qual else None
+	xo = np.ascontiguousarray(xn_off, dtype=np.uint64)
+	x = np.ascontiguousarray(xn, dtype=np.uint8)
+	score = np.zeros(n, dtype=np.float64)
+	status = np.zeros(n, dtype=np.int32)
+	prm = RescoreParams(min_mismatch_penalty, max_mismatch_penalty, n_penalty, gap_opening_penalty, gap_extension_penalty)
+	ptr = lambda v: v.ctypes.data if v is not None and v.size else None
+	check(_lib.lib().pvc3_rescore_alignments(ctx._h, n, a["cigar_off"].ctypes.data, ptr(a["cigar"]), a["seq_off"].ctypes.data, ptr(a["seq4"]), ptr(a["l_seq"]),
+		qo.ctypes.data if has_qual else None, ptr(q) if has_qual else None, xo.ctypes.data, ptr(x), C.byref(prm), ptr(score), ptr(status)))
+	return score, status
+
+
+def recalculate_mapq(ctx, group_off, fields):
+	"""pvc3_recalculate_mapq: mapq_scorer::process_alignment_group (recalculate-mapq/main.cc:962-1180) for a batch of QNAME
+	groups.  fields: dict of per-record arrays (ref_id, pos, mate_ref_id, mate_pos, orig_ref_id, orig_pos, orig_mate_ref_id,
+	orig_mate_pos, l_seq, seq_class as uint32 with NO_POS for unset values; score as float64 with SCORE_MIN for a missing AS).
+	-> (mapq uint8 [records], group_emitted uint8 [groups], statistics dict)."""
+	go = np.ascontiguousarray(group_off, dtype=np.uint64)
+	ng = go.size - 1
+	n = int(go[-1]) if go.size else 0
+	mb = MapqBatch()
+	keep = [go]
+	mb.n_groups = ng
+	mb.group_off = go.ctypes.data
+	for k in _MAPQ_FIELDS:
+		v = np.ascontiguousarray(fields[k], dtype=np.uint32)
+		keep.append(v)
+		setattr(mb, k, v.ctypes.data if v.size else None)
+	sc = np.ascontiguousarray(fields["score"], dtype=np.float64)
+	keep.append(sc)
+	mb.score = sc.ctypes.data if sc.size else None
+	mapq = np.zeros(max(1, n), dtype=np.uint8)
+	emitted = np.zeros(max(1, ng), dtype=np.uint8)
+	st = MapqStats()
+	check(_lib.lib().pvc3_recalculate_mapq(ctx._h, C.byref(mb), mapq.ctypes.data, emitted.ctypes.data, C.byref(st)))
+	return mapq[:n], emitted[:ng], {k: getattr(st, k) for k, _ in MapqStats._fields_}
 
 
 class Pipeline:

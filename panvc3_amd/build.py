@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpvc3_hip.so")
-SOURCES = ["api.cpp", "index.cpp", "kernels.hip", "project_fast.hip", "project_mid.hip", "project_general.hip", "realign.hip"]
+SOURCES = ["api.cpp", "index.cpp", "kernels.hip", "project_fast.hip", "project_mid.hip", "project_general.hip", "realign.hip", "mapq.hip"]
 ARCH = "gfx950"
 
 
@@ -114,6 +114,7 @@ def build_host(force=False, verbose=False):
 		("panvc3_project_alignments", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
 		("panvc3_rewrite_cigar", ["-lz"]),
 		("panvc3_convert_bed_positions", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
+		("panvc3_recalculate_mapq", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
 	):
 		src = os.path.join(HOST, name.replace("panvc3_", "") + "_main.cpp")
 		dst = os.path.join(BIN, name)
@@ -128,6 +129,30 @@ def build_host(force=False, verbose=False):
 	return out
 
 
+def build_cpp_tests(force=False, verbose=False):
+	"""tests/cpp/*.cpp: programs that use the C++ mirror header include/pvc3.hpp (they link libpvc3_hip.so)."""
+	build(force=False, verbose=verbose)
+	src_dir = os.path.join(HERE, "..", "tests", "cpp")
+	os.makedirs(BIN, exist_ok=True)
+	out = []
+	for name in sorted(os.listdir(src_dir)):
+		if not name.endswith(".cpp"):
+			continue
+		src = os.path.join(src_dir, name)
+		dst = os.path.join(BIN, "test_" + os.path.splitext(name)[0])
+		out.append(dst)
+		cmd = [os.environ.get("CXX", "g++"), "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(HERE, "..", "include"), "-o", dst, src,
+			   "-L" + HERE, "-lpvc3_hip", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]
+		key = _key([src, os.path.join(HERE, "..", "include", "pvc3.hpp"), os.path.join(HERE, "..", "include", "pvc3.h"), os.path.join(OBJ, "libpvc3_hip.so.key")], cmd[1:])
+		if force or _stale(dst, key):
+			if verbose:
+				print(" ".join(cmd), file=sys.stderr)
+			subprocess.check_call(cmd)
+			_done(dst, key)
+	return out
+
+
 if __name__ == "__main__":
 	print(build(force="--force" in sys.argv, verbose=True))
 	print(build_host(force="--force" in sys.argv, verbose=True))
+	print(build_cpp_tests(force="--force" in sys.argv, verbose=True))

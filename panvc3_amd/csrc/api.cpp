@@ -65,6 +65,9 @@ struct pvc3_context
 	uint32_t packed_dp{1};
 	uint8_t *scratch{};
 	uint64_t scratch_alloc{};
+	uint32_t *trace{};					// trace words of the packed alignment kernels
+	uint64_t trace_cap{};				// in words
+	uint64_t trace_initial{};			// option: words to start with (0: sized by the batch)
 };
 
 namespace {
@@ -204,6 +207,18 @@ int ensure_scratch(pvc3_context *ctx)
 	return PVC3_OK;
 }
 
+// The packed alignment kernels leave 32 bytes of trace per anti-diagonal step of a task; config C5 (5 % of 250-base reads over
+// a 20 - 60 base event) needs about 95 bytes per record of the batch.  Kept by the context and reused by every batch.
+int ensure_trace(pvc3_context *ctx, uint64_t words)
+{
+	if (ctx->trace && ctx->trace_cap >= words)
+		return PVC3_OK;
+	if (ctx->trace) { (void) hipFree(ctx->trace); ctx->workspace_bytes -= ctx->trace_cap * sizeof(uint32_t); ctx->trace = nullptr; ctx->trace_cap = 0; }
+	PVC3_TRY(dev_alloc(&ctx->trace, words, nullptr, &ctx->workspace_bytes));
+	ctx->trace_cap = words;
+	return PVC3_OK;
+}
+
 int alloc_arenas(pvc3_dbatch *b, uint64_t arena_cap, uint64_t runs_cap)
 {
 	pvc3_context *ctx = b->ctx;
@@ -214,7 +229,7 @@ int alloc_arenas(pvc3_dbatch *b, uint64_t arena_cap, uint64_t runs_cap)
 		b->bytes -= (2 * sizeof(pvc3_run) + sizeof(run_work) + DP_CLASSES * sizeof(uint32_t)) * b->work.runs_cap;
 	}
 	b->work.arena = nullptr; b->packed.out_cigar = nullptr; b->work.runs_arena = nullptr; b->packed.runs = nullptr; b->work.run_items = nullptr; b->work.dp_list = nullptr;
-	PVC3_TRY(dev_alloc(&b->work.arena, arena_cap, nullptr, &b->bytes));
+	PVC3_TRY(dev_alloc(&b->work.arena, arena_cap + 16, nullptr, &b->bytes));		// 16-byte reads of a record's operations may pass its last one
 	PVC3_TRY(dev_alloc(&b->packed.out_cigar, arena_cap, nullptr, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->work.runs_arena, runs_cap, nullptr, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.runs, runs_cap, nullptr, &b->bytes));
@@ -231,6 +246,9 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	hipStream_t const s = ctx->stream;
 	b->work.scratch = ctx->scratch;
 	b->work.scratch_per_wave = ctx->scratch_per_wave;
+	PVC3_TRY(ensure_trace(ctx, ctx->trace_initial ? ctx->trace_initial : ((UINT64_C(16) << 20) + 25 * b->n)));		// 64 MB + 100 bytes per record
+	b->work.trace = ctx->trace;
+	b->work.trace_cap = ctx->trace_cap;
 	HIP_TRY(hipMemsetAsync(b->work.counters, 0, sizeof(dev_counters), s));
 	HIP_TRY(hipMemsetAsync(b->work.wave_stats, 0, 3 * (uint64_t) project_wave_count(b->n) * WAVE_STATS * sizeof(unsigned long long), s));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
@@ -378,6 +396,7 @@ void pvc3_context_destroy(pvc3_context *ctx)
 	free_index_replica(ctx);
 	if (ctx->d_params) (void) hipFree(ctx->d_params);
 	if (ctx->scratch) (void) hipFree(ctx->scratch);
+	if (ctx->trace) (void) hipFree(ctx->trace);
 	for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
 	if (ctx->own_stream) (void) hipStreamDestroy(ctx->own_stream);
 	delete ctx;
@@ -408,6 +427,7 @@ int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value)
 	else if ("realign_lds_bytes" == k) ctx->realign_lds_bytes = (uint32_t) value;
 	else if ("scratch_per_wave" == k) ctx->scratch_per_wave = (uint64_t) value;
 	else if ("scratch_budget" == k) ctx->scratch_budget = (uint64_t) value;
+	else if ("trace_initial" == k) ctx->trace_initial = (uint64_t) value;
 	else if ("big_waves" == k) { if (value < 1 || value > 65536) return set_error(PVC3_E_INVALID, "big_waves out of range"); ctx->big_waves = (uint32_t) value; }
 	else if ("arena_initial" == k) ctx->arena_initial = (uint64_t) value;
 	else if ("runs_initial" == k) ctx->runs_initial = (uint64_t) value;
@@ -739,7 +759,7 @@ int dbatch_complete(pvc3_context *ctx, pvc3_dbatch *b, bool already_waited = fal
 		if (!already_waited) HIP_TRY(hipStreamSynchronize(ctx->stream));
 		HIP_TRY(hipMemcpy(&b->counters, b->work.counters, sizeof(dev_counters), hipMemcpyDeviceToHost));
 		dev_counters const &c = b->counters;
-		if (!c.arena_overflow && !c.runs_overflow && !c.scratch_overflow && !c.qual_overflow)
+		if (!c.arena_overflow && !c.runs_overflow && !c.scratch_overflow && !c.qual_overflow && !c.trace_overflow)
 			break;
 		if (b->attempts >= 8)
 			return set_error(PVC3_E_NOMEM, "pvc3_dbatch_finish: workspaces still too small after %u attempts", b->attempts);
@@ -759,6 +779,8 @@ int dbatch_complete(pvc3_context *ctx, pvc3_dbatch *b, bool already_waited = fal
 			uint64_t const runs_cap = c.runs_overflow ? (2 * (uint64_t) c.runs_head + 1024) : b->work.runs_cap;
 			PVC3_TRY(alloc_arenas(b, arena_cap, runs_cap));
 		}
+		if (c.trace_overflow)
+			PVC3_TRY(ensure_trace(ctx, (uint64_t) c.trace_head + (UINT64_C(4) << 20)));		// the head counts every request, also the refused ones
 		if (c.qual_overflow)
 		{
 			(void) hipFree(b->work.qual_compact);
@@ -857,6 +879,15 @@ int pvc3_dbatch_checksum(pvc3_context *ctx, pvc3_dbatch *b, uint64_t first_recor
 	*checksum = v;
 	return PVC3_OK;
 }
+
+#ifdef PVC3_DP_STAMPS
+// Diagnostic build only (tools/dp_phase_cycles.py): the cycle sums the alignment kernels left in the wave statistics area.
+PVC3_API int pvc3_debug_wave_stats(pvc3_dbatch *b, unsigned long long *out, uint32_t count)
+{
+	HIP_TRY(hipMemcpy(out, b->work.wave_stats, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return PVC3_OK;
+}
+#endif
 
 int pvc3_batch_project(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_batch_out *out, pvc3_params const *params, pvc3_batch_stats *stats)
 {
@@ -1051,6 +1082,103 @@ int pvc3_pipeline_in_flight(pvc3_pipeline const *p, uint32_t *count)
 {
 	if (!p || !count) return set_error(PVC3_E_INVALID, "pvc3_pipeline_in_flight: null argument");
 	*count = (uint32_t) (p->submitted - p->retired);
+	return PVC3_OK;
+}
+
+// ---- recalculate_mapq ----------------------------------------------------------------------------------------------------
+int pvc3_rescore_alignments(pvc3_context *ctx, uint64_t n, uint64_t const *cigar_off, uint32_t const *cigar, uint64_t const *seq_off, uint8_t const *seq4,
+	uint32_t const *l_seq, uint64_t const *qual_off, uint8_t const *qual, uint64_t const *xn_off, uint8_t const *xn, pvc3_rescore_params const *params, double *score, int32_t *status)
+{
+	if (!ctx || !params || (n && (!cigar_off || !seq_off || !l_seq || !xn_off || !score || !status))) return set_error(PVC3_E_INVALID, "pvc3_rescore_alignments: null argument");
+	PVC3_TRY(check_device(ctx));
+	if (0 == n) return PVC3_OK;
+	for (uint64_t i = 0; i < n; ++i)		// the kernel reads the slices without further checks
+		if (cigar_off[i] > cigar_off[i + 1] || seq_off[i] > seq_off[i + 1] || xn_off[i] > xn_off[i + 1] || seq_off[i + 1] - seq_off[i] < ((uint64_t) l_seq[i] + 1) / 2 || (qual && qual_off && qual_off[i] > qual_off[i + 1]))
+			return set_error(PVC3_E_INVALID, "pvc3_rescore_alignments: malformed offsets at record %llu", (unsigned long long) i);
+	std::vector <void *> allocs;
+	struct guard { std::vector <void *> &a; ~guard() { for (void *p : a) (void) hipFree(p); } } g{allocs};
+	hipStream_t const s = ctx->stream;
+	uint64_t const *d_coff{}, *d_soff{}, *d_qoff{}, *d_xoff{};
+	uint32_t const *d_cig{}, *d_lseq{};
+	uint8_t const *d_seq{}, *d_qual{}, *d_xn{};
+	double *d_score{}; int32_t *d_status{};
+	bool const has_qual = qual && qual_off;
+	PVC3_TRY(dev_upload(&d_coff, cigar_off, n + 1, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d_cig, cigar, cigar_off[n], 16, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d_soff, seq_off, n + 1, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d_seq, seq4, seq_off[n], 16, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d_lseq, l_seq, n, 0, s, &allocs, nullptr));
+	if (has_qual)
+	{
+		PVC3_TRY(dev_upload(&d_qoff, qual_off, n + 1, 0, s, &allocs, nullptr));
+		PVC3_TRY(dev_upload(&d_qual, qual, qual_off[n], 16, s, &allocs, nullptr));
+	}
+	PVC3_TRY(dev_upload(&d_xoff, xn_off, n + 1, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d_xn, xn, xn_off[n], 16, s, &allocs, nullptr));
+	PVC3_TRY(dev_alloc(&d_score, n, &allocs, nullptr));
+	PVC3_TRY(dev_alloc(&d_status, n, &allocs, nullptr));
+	if (int const e = launch_rescore(n, d_coff, d_cig, d_soff, d_seq, d_lseq, d_qoff, d_qual, d_xoff, d_xn, *params, d_score, d_status, s)) return set_error(PVC3_E_HIP, "k_rescore_alignments launch: %s", hipGetErrorString((hipError_t) e));
+	HIP_TRY(hipMemcpyAsync(score, d_score, n * sizeof(double), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(status, d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	return PVC3_OK;
+}
+
+int pvc3_recalculate_mapq(pvc3_context *ctx, pvc3_mapq_batch const *in, uint8_t *mapq, uint8_t *group_emitted, pvc3_mapq_stats *stats)
+{
+	if (!ctx || !in) return set_error(PVC3_E_INVALID, "pvc3_recalculate_mapq: null argument");
+	PVC3_TRY(check_device(ctx));
+	uint64_t const ng = in->n_groups;
+	if (stats) std::memset(stats, 0, sizeof(*stats));
+	if (0 == ng) return PVC3_OK;
+	if (!in->group_off || !mapq || !group_emitted) return set_error(PVC3_E_INVALID, "pvc3_recalculate_mapq: null argument");
+	uint64_t const n = in->group_off[ng];
+	for (uint64_t g = 0; g < ng; ++g)
+		if (in->group_off[g] > in->group_off[g + 1]) return set_error(PVC3_E_INVALID, "pvc3_recalculate_mapq: group offsets decrease at group %llu", (unsigned long long) g);
+	if (n && (!in->ref_id || !in->pos || !in->mate_ref_id || !in->mate_pos || !in->orig_ref_id || !in->orig_pos || !in->orig_mate_ref_id || !in->orig_mate_pos || !in->score || !in->l_seq || !in->seq_class))
+		return set_error(PVC3_E_INVALID, "pvc3_recalculate_mapq: a required input array is null");
+	std::vector <void *> allocs;
+	struct guard { std::vector <void *> &a; ~guard() { for (void *p : a) (void) hipFree(p); } } g{allocs};
+	hipStream_t const s = ctx->stream;
+	pvc3_mapq_batch d{};
+	d.n_groups = ng;
+	PVC3_TRY(dev_upload(&d.group_off, in->group_off, ng + 1, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.ref_id, in->ref_id, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.pos, in->pos, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.mate_ref_id, in->mate_ref_id, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.mate_pos, in->mate_pos, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.orig_ref_id, in->orig_ref_id, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.orig_pos, in->orig_pos, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.orig_mate_ref_id, in->orig_mate_ref_id, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.orig_mate_pos, in->orig_mate_pos, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.score, in->score, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.l_seq, in->l_seq, n, 0, s, &allocs, nullptr));
+	PVC3_TRY(dev_upload(&d.seq_class, in->seq_class, n, 0, s, &allocs, nullptr));
+	double *d_pw{}, *d_bt{};
+	uint32_t *d_ml{};
+	uint8_t *d_mapq{}, *d_emitted{};
+	unsigned long long *d_stats{};
+	PVC3_TRY(dev_alloc(&d_pw, n, &allocs, nullptr));
+	PVC3_TRY(dev_alloc(&d_bt, n, &allocs, nullptr));
+	PVC3_TRY(dev_alloc(&d_ml, n, &allocs, nullptr));
+	PVC3_TRY(dev_alloc(&d_mapq, n, &allocs, nullptr));
+	PVC3_TRY(dev_alloc(&d_emitted, ng, &allocs, nullptr));
+	PVC3_TRY(dev_alloc(&d_stats, 4, &allocs, nullptr));
+	HIP_TRY(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), s));
+	if (int const e = launch_mapq_groups(d, d_pw, d_bt, d_ml, d_mapq, d_emitted, d_stats, s)) return set_error(PVC3_E_HIP, "k_mapq_groups launch: %s", hipGetErrorString((hipError_t) e));
+	if (n) HIP_TRY(hipMemcpyAsync(mapq, d_mapq, n, hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(group_emitted, d_emitted, ng, hipMemcpyDeviceToHost, s));
+	unsigned long long h_stats[4] = {0, 0, 0, 0};
+	HIP_TRY(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if (stats)
+	{
+		stats->total_alignments = n;
+		stats->unpaired_alignments = h_stats[0];
+		stats->reads_with_and_without_mate = h_stats[1];
+		stats->mate_not_found = h_stats[2];
+		stats->reads_without_valid_position = h_stats[3];
+	}
 	return PVC3_OK;
 }
 

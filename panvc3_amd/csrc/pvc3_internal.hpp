@@ -82,8 +82,13 @@ struct run_work
 	uint32_t op_first, op_end;	// the run's operations in the rewritten CIGAR: [op_first, op_end)
 	uint64_t ops_loc;			// arena offset of the first produced operation
 	uint64_t splice_loc;		// first run of a record: arena space reserved for the record's final CIGAR
+	uint8_t const *text;		// reference slice of the run (destination text + ref_loc)
+	uint8_t const *seq4;		// SEQ of the record (4-bit codes; the run's bases start at query_loc)
+	uint8_t const *qual;		// QUAL of the record or null
+	uint64_t trace_loc;			// k_realign_dp: where the task of this run left its trace words (TRACE_NONE: it did not)
 };
-static_assert(48 == sizeof(run_work), "run_work layout");
+static_assert(80 == sizeof(run_work), "run_work layout");
+constexpr uint64_t TRACE_NONE = ~UINT64_C(0);
 
 // Alignment classes: lanes per run W in {16, 32, 64} x orientation (0: lane = query row, 1: lane = reference column), plus the
 // runs that need the striped one-wave-per-run kernel (short side > 64 or more anti-diagonals than the LDS trace holds).
@@ -113,6 +118,8 @@ struct dev_counters
 	unsigned int dp_count[DP_CLASSES];	// indel runs per alignment class (k_realign_scan appends, the k_realign_dp launches consume)
 	unsigned int run_records;			// records with an indel run (sum of the per-region work lists, k_run_prefix)
 	unsigned int qual_overflow;			// the compact QUAL buffer of a pipelined batch was too small
+	unsigned int trace_overflow;		// the trace buffer of the packed alignment kernels was too small
+	unsigned long long trace_head;		// next free word of it
 	unsigned long long qual_head;		// next free byte of that buffer
 };
 
@@ -130,6 +137,8 @@ struct dev_batch_work
 	uint64_t arena_cap;
 	pvc3_run *runs_arena;
 	uint64_t runs_cap;
+	uint32_t *trace;					// trace words of the packed alignment kernels (context-wide, like the scratch)
+	uint64_t trace_cap;
 	uint8_t *scratch;					// DP scratch, scratch_per_wave bytes per realign wave
 	uint64_t scratch_per_wave;
 	uint32_t *slow_list;				// records left by the fast path: wave w of k_project_fast fills [64 * first group of w ...)
@@ -194,6 +203,10 @@ int launch_pack_text4(uint8_t const *text, uint64_t len, uint8_t *out, void *str
 int launch_project_positions(dev_entry const *entries, uint32_t n_entries, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out, void *stream);
 // Layout check of a freshly loaded batch; *first_bad = smallest malformed record (left at 0xFFFFFFFF if there is none).
 int launch_validate(dev_batch_in const &in, uint64_t n_cigar, uint64_t n_seq, uint64_t n_qual, uint64_t const *qual_off, uint32_t *first_bad, void *stream);
+int launch_rescore(
+	uint64_t n, uint64_t const *cigar_off, uint32_t const *cigar, uint64_t const *seq_off, uint8_t const *seq4, uint32_t const *l_seq,
+	uint64_t const *qual_off, uint8_t const *qual, uint64_t const *xn_off, uint8_t const *xn, pvc3_rescore_params const &prm, double *score, int32_t *status, void *stream);
+int launch_mapq_groups(pvc3_mapq_batch const &in, double *pw, double *best_total, uint32_t *mate_len, uint8_t *mapq, uint8_t *emitted, unsigned long long *stats, void *stream);
 uint32_t realign_lds_bytes();
 uint32_t project_wave_count(uint64_t n);
 uint64_t pack_scan_tmp_words(uint64_t n);

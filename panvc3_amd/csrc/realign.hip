@@ -11,7 +11,8 @@
 //                     alignment of the run's reference slice against its query slice (include/panvc3/align.hh:59-112;
 //                     seqan3::align_pairwise restated, see oracle/pvc3_oracle.c for the recurrence and the traceback
 //                     priority), anti-diagonal by anti-diagonal, fp64 adds / compares only (the score table comes from
-//                     the host's libm), four trace bits per cell in LDS, traceback by one lane per run
+//                     the host's libm), four trace bits per cell, written to the context's trace buffer
+//   k_realign_traceback   lane = run: walks the trace back and writes the run's operations run-length into its slot
 //   k_realign_big     the same alignment for runs that do not fit the packed kernel: one run per wavefront, lane = query row
 //                     in stripes of 64 rows, trace bytes in LDS or in a global scratch slot
 //   k_realign_splice  lane = record.  Copies the untouched operations, splices the realigned runs
@@ -188,10 +189,40 @@ __global__ __launch_bounds__(256) void k_gather_qual(dev_batch_in const in, dev_
 	}
 }
 
+// The operations of a lane's record: the first STAGED_OPS are fetched with four 16-byte loads and parked in LDS
+// (operation x of lane l at [x][l]: conflict-free), so that the replay loops below do not pay a global round trip per
+// operation; longer CIGARs read the rest from memory.
+constexpr uint32_t STAGED_OPS = 16;
+struct op_source
+{
+	uint32_t const *ops;		// global
+	uint32_t const *staged;		// LDS, this lane's column
+	__device__ __forceinline__ uint32_t operator[](uint32_t x) const { return (x < STAGED_OPS) ? staged[64 * x] : ops[x]; }
+};
+
+__device__ __forceinline__ op_source stage_ops(uint32_t const *ops, uint32_t n_ops, uint32_t *lds_wave, uint32_t lane)
+{
+	typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+	u32x4 v[STAGED_OPS / 4];
+#pragma unroll
+	for (uint32_t k = 0; k < STAGED_OPS / 4; ++k)
+	{
+		v[k] = u32x4{0, 0, 0, 0};
+		if (4 * k < n_ops) __builtin_memcpy(&v[k], ops + 4 * k, 16);		// the arena is padded: reading past the record's last operation is harmless
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < STAGED_OPS / 4; ++k)
+	{
+		lds_wave[64 * (4 * k + 0) + lane] = v[k].x; lds_wave[64 * (4 * k + 1) + lane] = v[k].y;
+		lds_wave[64 * (4 * k + 2) + lane] = v[k].z; lds_wave[64 * (4 * k + 3) + lane] = v[k].w;
+	}
+	return op_source{ops, lds_wave + lane};
+}
+
 // indel_run_checker (indel_run_checker.cc:13-121) over `n_ops` operations; calls on_run(first op, end op, reference start,
 // reference length, query start, query length, reference position at report time) for every run with both I and D.
-template <typename t_on_run>
-__device__ __forceinline__ void replay_runs(uint32_t const *ops, uint32_t n_ops, uint32_t dst_pos, t_on_run &&on_run)
+template <typename t_ops, typename t_on_run>
+__device__ __forceinline__ void replay_runs(t_ops const &ops, uint32_t n_ops, uint32_t dst_pos, t_on_run &&on_run)
 {
 	uint32_t ref_pos = dst_pos, query_pos = 0, run_type = 0;
 	uint32_t run_first = 0, run_ref_loc = dst_pos, run_query_loc = 0;
@@ -246,6 +277,8 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 	// five times slower than the rest of its work.
 	__shared__ uint32_t lds_items[4][DP_CLASSES][SCAN_STAGE];
 	uint32_t (*stage)[SCAN_STAGE] = lds_items[rfl(threadIdx.x >> 6)];
+	__shared__ uint32_t lds_ops[4][STAGED_OPS * 64];
+	uint32_t *my_ops = lds_ops[rfl(threadIdx.x >> 6)];
 	uint32_t staged[DP_CLASSES];		// wave-uniform
 #pragma unroll
 	for (uint32_t c = 0; c < DP_CLASSES; ++c) staged[c] = 0;
@@ -264,6 +297,7 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 		bool const mine = base + lane < total;
 		uint32_t rec = 0, n_ops = 0, dst_pos = 0, text_len = 0, l_seq = 0;
 		uint32_t const *ops = W.arena;
+		uint8_t const *text = nullptr, *seq4 = nullptr, *qual = nullptr;
 		bool has_text = false, has_qual = false;
 		if (mine)
 		{
@@ -272,14 +306,20 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 			n_ops = W.cig_n[rec];
 			dst_pos = W.dst_pos[rec];
 			dev_entry const *de = entries + in.dst_entry[rec];
-			has_text = nullptr != de->text; text_len = de->text_len;
+			text = de->text; text_len = de->text_len;
+			has_text = nullptr != text;
 			l_seq = in.l_seq[rec];
+			seq4 = in.seq4 + in.seq_off[rec];
 			has_qual = (in.flags[rec] & PVC3_FLAG_HAS_QUAL) && in.qual;
+			if (has_qual) qual = in.qual + in.qual_off[rec];
 		}
 
+		wave_lds_fence();		// the previous chunk's operations have been read
+		op_source const staged_ops = stage_ops(ops, n_ops, my_ops, lane);
+		wave_lds_fence();
 		// Pass 1: count the runs, the slots they need and check their ranges (alignment_projector.cc:76-137 slices both sequences).
 		uint32_t n3 = 0, slot_need = 0, status = PVC3_ST_OK;
-		replay_runs(ops, n_ops, dst_pos, [&](uint32_t, uint32_t, uint32_t r_loc, uint32_t m, uint32_t q_loc, uint32_t nq, uint32_t) {
+		replay_runs(staged_ops, n_ops, dst_pos, [&](uint32_t, uint32_t, uint32_t r_loc, uint32_t m, uint32_t q_loc, uint32_t nq, uint32_t) {
 			if (status) return;
 			if (!has_text || (uint64_t) r_loc + m > text_len) { status = PVC3_ST_REF_RANGE; return; }
 			if ((uint64_t) q_loc + nq > l_seq) { status = PVC3_ST_QUERY_RANGE; return; }
@@ -313,7 +353,7 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 		uint32_t cls[2] = {DP_CLASSES, DP_CLASSES};		// the first two runs of the lane go to the class lists wave-wide
 		if (mine && !status)
 		{
-			replay_runs(ops, n_ops, dst_pos, [&](uint32_t first, uint32_t end, uint32_t r_loc, uint32_t m, uint32_t q_loc, uint32_t nq, uint32_t ref_pos) {
+			replay_runs(staged_ops, n_ops, dst_pos, [&](uint32_t first, uint32_t end, uint32_t r_loc, uint32_t m, uint32_t q_loc, uint32_t nq, uint32_t ref_pos) {
 				pvc3_run rr;
 				rr.query_location = q_loc; rr.query_length = nq; rr.ref_position = ref_pos; rr.ref_length = m;		// alignment_projector.cc:69-73 (quirk Q7)
 				W.runs_arena[my_runs + k] = rr;
@@ -322,6 +362,7 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 				it.op_first = first; it.op_end = end;
 				it.ops_loc = my_arena + (first - run_ops) + slot;
 				it.splice_loc = my_arena;
+				it.text = text + r_loc; it.seq4 = seq4; it.qual = qual; it.trace_loc = TRACE_NONE;
 				W.run_items[my_runs + k] = it;
 				uint32_t const c = dp_class_of(m, nq, packed);
 				if (k < 2) cls[k] = c;
@@ -379,17 +420,15 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 struct dp_shared
 {
 	double score[SCORE_ROWS][2];					// [phred or NO_QUAL][0 match, 1 mismatch]
-	uint32_t trace[DP_MAX_STEPS / 8][64];			// 4 bits per cell: lane's nibble of step t in trace[t / 8][lane] at 4 (t % 8)
-	uint16_t stream[4][64 + DP_MAX_STEPS + 8];			// per run: the items along the longer side, dna5 rank | phred << 8, behind 64 unused entries
+	uint16_t stream[4][64 + DP_MAX_STEPS + 8];		// per run: the items along the longer side, dna5 rank | phred << 8, behind 64 unused entries
 };
+constexpr uint32_t TRACE_CHUNK = 16384;				// trace words a wave takes from the trace buffer at a time (16 - 64 tasks)
 
 template <uint32_t t_width, bool t_ref_lanes>
-__global__ __launch_bounds__(64, 7) void k_realign_dp(
-	dev_entry const *__restrict__ entries, dev_batch_in const in, dev_batch_work const W, dev_params const *__restrict__ prm, uint32_t cls
-)
+__device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_params const *__restrict__ prm, uint32_t cls, dp_shared &S)
 {
 	constexpr uint32_t G = 64 / t_width;
-	__shared__ dp_shared S;
+	constexpr uint32_t FILL = DP_MAX_STEPS / t_width;		// stream items a lane fetches at most
 	uint32_t const lane = lane_id();
 	uint32_t const g = lane / t_width, l = lane % t_width;
 	for (uint32_t i = lane; i < SCORE_ROWS; i += 64)
@@ -404,37 +443,73 @@ __global__ __launch_bounds__(64, 7) void k_realign_dp(
 	uint32_t const count = W.counters->dp_count[cls];
 	uint32_t const *list = W.dp_list + (uint64_t) cls * W.runs_cap;
 	uint32_t const n_tasks = (count + G - 1) / G;
+	arena_alloc trace_alloc{0, 0};
+	// A wave takes trace space for several tasks at a time (one atomic per chunk), but never much more than its own tasks can
+	// use: with few runs every wave has one or two tasks, and 8192 waves x 64 KB would be half a gigabyte of reservations.
+	uint32_t const my_tasks = (blockIdx.x < n_tasks) ? ((n_tasks - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+	uint32_t const trace_chunk = (my_tasks * (DP_MAX_STEPS / 8) * 64 < TRACE_CHUNK) ? (my_tasks * (DP_MAX_STEPS / 8) * 64) : TRACE_CHUNK;
+#ifdef PVC3_DP_STAMPS
+	unsigned long long stamp_acc[4] = {0, 0, 0, 0};		// set-up, alignment, -, tasks
+#define PVC3_STAMP(k) do { unsigned long long const now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - stamp_t; stamp_t = now_; } while (0)
+#else
+#define PVC3_STAMP(k) do {} while (0)
+#endif
 
 	for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x)
 	{
+#ifdef PVC3_DP_STAMPS
+		unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+		stamp_acc[3] += 1;
+#endif
 		wave_lds_fence();		// the previous task's LDS reads are done
 		uint32_t const slot_idx = task * G + g;
 		bool const have = slot_idx < count;
 		uint32_t const item_idx = have ? list[slot_idx] : 0;
-		run_work it{};
-		if (have) it = W.run_items[item_idx];
-		uint32_t const n_short = have ? (t_ref_lanes ? it.m : it.n) : 0;
-		uint32_t const n_long = have ? (t_ref_lanes ? it.n : it.m) : 0;
-		uint32_t const rec = it.rec;
-		uint8_t const *text = nullptr, *seq4 = in.seq4, *qual = nullptr;
+		uint32_t it_m = 0, it_n = 0, it_q0 = 0;
+		uint8_t const *text = nullptr, *seq4 = nullptr, *qual = nullptr;
 		if (have)
 		{
-			text = entries[in.dst_entry[rec]].text + it.ref_loc;
-			seq4 = in.seq4 + in.seq_off[rec];
-			if ((in.flags[rec] & PVC3_FLAG_HAS_QUAL) && in.qual) qual = in.qual + in.qual_off[rec];
+			run_work const *it = W.run_items + item_idx;
+			it_m = it->m; it_n = it->n; it_q0 = it->query_loc;
+			text = it->text; seq4 = it->seq4; qual = it->qual;
 		}
-		auto query_item = [&](uint32_t idx) -> uint32_t {		// rank | phred << 8 of query base idx of the run
-			uint32_t const q = it.query_loc + idx;
-			uint32_t ph = NO_QUAL;
-			if (qual) { ph = qual[q]; ph = (ph > MAX_PHRED) ? MAX_PHRED : ph; }		// phred42 saturates
-			return dna5_rank_of_seq4(seq4_at(seq4, q)) | (ph << 8);
+		uint32_t const n_short = t_ref_lanes ? it_m : it_n, n_long = t_ref_lanes ? it_n : it_m;
+
+		// The lane's own item (shorter side) and the run's stream (longer side): rank | phred << 8.  All loads are issued before
+		// any of them is used (one round trip instead of one per item).
+		uint32_t raw_a[FILL + 1], raw_b[FILL + 1];		// text byte, or SEQ byte and QUAL byte, of the items l, l + t_width, ... (last: the own item)
+#pragma unroll
+		for (uint32_t k = 0; k <= FILL; ++k)
+		{
+			bool const own = (FILL == k);
+			uint32_t const x = own ? l : (l + k * t_width);
+			bool const query_side = own ? !t_ref_lanes : t_ref_lanes;
+			bool const ok = x < (own ? n_short : n_long);
+			raw_a[k] = 0; raw_b[k] = 0x100;		// 0x100: no base quality
+			if (ok)
+			{
+				if (query_side)
+				{
+					raw_a[k] = seq4[(it_q0 + x) >> 1];
+					if (qual) raw_b[k] = qual[it_q0 + x];
+				}
+				else raw_a[k] = text[x];
+			}
+		}
+		auto item_of = [&](uint32_t k, bool query_side, uint32_t x) -> uint32_t {
+			if (!query_side) return dna5_rank_of_char(raw_a[k]) | (NO_QUAL << 8);
+			uint32_t const code = ((it_q0 + x) & 1) ? (raw_a[k] & 0xf) : (raw_a[k] >> 4);
+			uint32_t const ph = (0x100 == raw_b[k]) ? NO_QUAL : ((raw_b[k] > MAX_PHRED) ? MAX_PHRED : raw_b[k]);		// phred42 saturates
+			return dna5_rank_of_seq4(code) | (ph << 8);
 		};
-		// The lane's own item (shorter side) and the run's stream (longer side).
+#pragma unroll
+		for (uint32_t k = 0; k < FILL; ++k)
+		{
+			uint32_t const x = l + k * t_width;
+			if (x < n_long) S.stream[g][64 + x] = (uint16_t) item_of(k, t_ref_lanes, x);
+		}
 		uint32_t own = 3 | (NO_QUAL << 8);
-		if (l < n_short)
-			own = t_ref_lanes ? dna5_rank_of_char(text[l]) : query_item(l);
-		for (uint32_t x = l; x < n_long; x += t_width)
-			S.stream[g][64 + x] = (uint16_t) (t_ref_lanes ? query_item(x) : dna5_rank_of_char(text[x]));
+		if (l < n_short) own = item_of(FILL, !t_ref_lanes, l);
 		uint32_t const own_rank = own & 7, own_q = own >> 8;
 
 		uint32_t steps = have ? (n_long + n_short - 1) : 0;
@@ -445,7 +520,15 @@ __global__ __launch_bounds__(64, 7) void k_realign_dp(
 			steps = (o > steps) ? o : steps;
 		}
 		steps = rfl(steps);
+		// Trace words of this task: one row of 64 per 8 steps, in the context's trace buffer.
+		uint64_t trace_loc = 0;
+		bool const traced = arena_take_from(trace_alloc, ((steps + 7) / 8) * 64, trace_chunk, &W.counters->trace_head, W.trace_cap, &W.counters->trace_overflow, lane, trace_loc);
+		if (have && 0 == l) W.run_items[item_idx].trace_loc = traced ? trace_loc : TRACE_NONE;
+		if (!traced)
+			continue;		// the host grows the trace buffer and repeats the batch
+		uint32_t *trace = W.trace + trace_loc + lane;
 		wave_lds_fence();
+		PVC3_STAMP(0);
 
 		// Line 0 of the matrix (the first row, or the first column) feeds lane 0 of the run: M = the boundary gap, gap score -inf.
 		// gap(k) = k * (open + ext) when the opening score is positive, open + k * ext otherwise (small integers: exact).
@@ -506,46 +589,81 @@ __global__ __launch_bounds__(64, 7) void k_realign_dp(
 			acc |= nib << (4 * (t & 7));
 			if (7 == (t & 7) || t + 1 == steps)
 			{
-				S.trace[t >> 3][lane] = acc;
+				trace[(t >> 3) * 64] = acc;			// 256 contiguous bytes per wave
 				acc = 0;
 			}
 		}
-		wave_lds_fence();
+		PVC3_STAMP(1);
+	}
+#ifdef PVC3_DP_STAMPS
+	// diagnostic build only: cycle sums per phase and class into the wave statistics area (nothing else reads it afterwards)
+	if (0 == lane)
+		for (uint32_t k = 0; k < 4; ++k)
+			atomicAdd(&W.wave_stats[8 * cls + k], stamp_acc[k]);
+#endif
+}
 
-		// Traceback (trace_iterator_base) by the first lane of every run: diagonal > up > left where the direction is decided; a
-		// gap continues until the cell whose gap score was formed by opening.  Cell (i, j) was computed in step i + j - 2 by the
-		// lane of its line.  The operations come out last to first and are written run-length from the end of the run's slot.
-		if (have && 0 == l)
+// One launch for the six classes (blockIdx.y): their grids run side by side instead of one short kernel after the other.
+__global__ __launch_bounds__(64, 8) void k_realign_dp(dev_batch_work const W, dev_params const *__restrict__ prm)
+{
+	__shared__ dp_shared S;
+	switch (blockIdx.y)
+	{
+		case 0: realign_dp_class <16, false>(W, prm, 0, S); break;
+		case 1: realign_dp_class <16, true>(W, prm, 1, S); break;
+		case 2: realign_dp_class <32, false>(W, prm, 2, S); break;
+		case 3: realign_dp_class <32, true>(W, prm, 3, S); break;
+		case 4: realign_dp_class <64, false>(W, prm, 4, S); break;
+		default: realign_dp_class <64, true>(W, prm, 5, S); break;
+	}
+}
+
+// Traceback (trace_iterator_base) of the packed alignments, lane = run: diagonal > up > left where the direction is decided;
+// a gap continues until the cell whose gap score was formed by opening.  Cell (i, j) was computed in step i + j - 2 by the
+// lane of its line.  The operations come out last to first and are written run-length from the end of the run's slot.
+// One cell per iteration, written as data flow: the nibble of the cell, the direction taken, the operation, the next state.
+__global__ __launch_bounds__(256) void k_realign_traceback(dev_batch_work const W)
+{
+	uint32_t const cls = blockIdx.y;
+	uint32_t const width = 16u << (cls >> 1), per_task = 64 / width;
+	bool const ref_lanes = cls & 1;
+	uint32_t const count = W.counters->dp_count[cls];
+	uint32_t const *list = W.dp_list + (uint64_t) cls * W.runs_cap;
+	for (uint32_t at = blockIdx.x * blockDim.x + threadIdx.x; at < count; at += gridDim.x * blockDim.x)
+	{
+		uint32_t const item_idx = list[at];
+		run_work const *it = W.run_items + item_idx;
+		uint64_t const trace_loc = it->trace_loc;
+		if (TRACE_NONE == trace_loc)
+			continue;		// the trace buffer overflowed: the batch is repeated
+		uint32_t const m = it->m, n = it->n;
+		uint64_t const ops_loc = it->ops_loc;
+		uint32_t const *trace = W.trace + trace_loc + (at % per_task) * width - 1;
+		uint32_t *slot_end = W.arena + ops_loc + (m + n);
+		uint32_t n_out = 0, cur_op = 0xf, cur_cnt = 0;
+		uint32_t i = n, j = m, st = 0;		// st: 0 = M, 1 = V (up), 2 = H (left)
+		while (i | j)
 		{
-			uint32_t *slot_end = W.arena + it.ops_loc + (it.m + it.n);
-			uint32_t n_out = 0, cur_op = 0xf, cur_cnt = 0;
-			uint32_t i = it.n, j = it.m, st = 0;		// st: 0 = M, 1 = V (up), 2 = H (left)
-			uint32_t const lane_base = g * t_width - 1;
-			// One cell per iteration, written as data flow (a branch per case costs more than the arithmetic when 1 - 4 lanes of
-			// the wave run this loop): the nibble of the cell, the direction taken, the operation, the next state.
-			while (i | j)
-			{
-				uint32_t const t = i + j - 2;
-				bool const inner = (0 != i) && (0 != j);
-				uint32_t const word = S.trace[inner ? (t >> 3) : 0][inner ? (lane_base + (t_ref_lanes ? j : i)) : 0];
-				uint32_t const edge = (0 == i) ? (3u | ((1 == j) ? 8u : 0u)) : (2u | ((1 == i) ? 4u : 0u));	// first row: left, opened at column 1; first column: up
-				uint32_t const nibble = inner ? ((word >> (4 * (t & 7))) & 0xfu) : edge;
-				uint32_t const state = nibble & 3;
-				uint32_t const dir = (0 == st) ? ((state < 2) ? 0u : (state - 1)) : st;		// 0 diagonal, 1 up, 2 left
-				uint32_t const op = (0 == dir) ? ((state & 1) ? OP_X : OP_EQ) : ((1 == dir) ? OP_I : OP_D);		// align.hh:99-106
-				bool const opened = 0 != (nibble & ((1 == dir) ? 4u : 8u));
-				st = (0 == dir || opened) ? 0u : dir;
-				i -= (2 != dir) ? 1u : 0u;
-				j -= (1 != dir) ? 1u : 0u;
-				bool const same = (op == cur_op);
-				if (!same && cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
-				cur_cnt = same ? (cur_cnt + 1) : 1u;
-				cur_op = op;
-			}
-			if (cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
-			W.run_items[item_idx].n_out = n_out;
-			W.run_items[item_idx].ops_loc = it.ops_loc + (it.m + it.n) - n_out;
+			uint32_t const t = i + j - 2;
+			bool const inner = (0 != i) && (0 != j);
+			uint32_t const word = inner ? trace[(t >> 3) * 64 + (ref_lanes ? j : i)] : 0;
+			uint32_t const edge = (0 == i) ? (3u | ((1 == j) ? 8u : 0u)) : (2u | ((1 == i) ? 4u : 0u));	// first row: left, opened at column 1; first column: up
+			uint32_t const nibble = inner ? ((word >> (4 * (t & 7))) & 0xfu) : edge;
+			uint32_t const state = nibble & 3;
+			uint32_t const dir = (0 == st) ? ((state < 2) ? 0u : (state - 1)) : st;		// 0 diagonal, 1 up, 2 left
+			uint32_t const op = (0 == dir) ? ((state & 1) ? OP_X : OP_EQ) : ((1 == dir) ? OP_I : OP_D);		// align.hh:99-106
+			bool const opened = 0 != (nibble & ((1 == dir) ? 4u : 8u));
+			st = (0 == dir || opened) ? 0u : dir;
+			i -= (2 != dir) ? 1u : 0u;
+			j -= (1 != dir) ? 1u : 0u;
+			bool const same = (op == cur_op);
+			if (!same && cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
+			cur_cnt = same ? (cur_cnt + 1) : 1u;
+			cur_op = op;
 		}
+		if (cur_cnt) { ++n_out; *(slot_end - n_out) = (cur_cnt << 4) | cur_op; }
+		W.run_items[item_idx].n_out = n_out;
+		W.run_items[item_idx].ops_loc = ops_loc + (m + n) - n_out;
 	}
 }
 
@@ -712,9 +830,7 @@ __device__ __forceinline__ uint32_t align_global_striped(
 	return n_out;
 }
 
-__global__ __launch_bounds__(64, 8) void k_realign_big(
-	dev_entry const *__restrict__ entries, dev_batch_in const in, dev_batch_work const W, dev_params const *__restrict__ prm, uint32_t lds_budget
-)
+__global__ __launch_bounds__(64, 8) void k_realign_big(dev_batch_work const W, dev_params const *__restrict__ prm, uint32_t lds_budget)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t lds[REALIGN_LDS_BYTES];
 	__shared__ double lds_scores[2 * (MAX_PHRED + 1)];
@@ -730,11 +846,9 @@ __global__ __launch_bounds__(64, 8) void k_realign_big(
 	{
 		uint32_t const item_idx = rfl(list[task]);
 		run_work const it = W.run_items[item_idx];
-		uint32_t const rec = rfl(it.rec), m = rfl(it.m), nq = rfl(it.n), q_loc = rfl(it.query_loc), r_loc = rfl(it.ref_loc);
+		uint32_t const m = rfl(it.m), nq = rfl(it.n), q_loc = rfl(it.query_loc);
 		uint64_t const ops_loc = rfl64(it.ops_loc);
-		uint8_t const *text = rfl_ptr(entries[in.dst_entry[rec]].text) + r_loc;
-		uint8_t const *seq4 = in.seq4 + rfl64(in.seq_off[rec]);
-		uint8_t const *qual = ((rfl(in.flags[rec]) & PVC3_FLAG_HAS_QUAL) && in.qual) ? (in.qual + rfl64(in.qual_off[rec])) : nullptr;
+		uint8_t const *text = rfl_ptr(it.text), *seq4 = rfl_ptr(it.seq4), *qual = rfl_ptr(it.qual);
 		uint32_t *slot_end = W.arena + ops_loc + (m + nq);
 		uint64_t const need = dp_bytes(m, nq);
 		uint32_t n_out;
@@ -769,15 +883,21 @@ __global__ __launch_bounds__(256) void k_realign_splice(dev_batch_in const in, d
 	uint32_t const n_waves = (gridDim.x * blockDim.x) >> 6;
 	uint64_t const n_groups = (in.n + 63) / 64;
 	uint32_t const total = W.run_prefix[n_regions];
+	__shared__ uint32_t lds_ops[4][STAGED_OPS * 64];
+	uint32_t *my_ops = lds_ops[rfl(threadIdx.x >> 6)];
 	for (uint32_t base = 64 * wave; base < total; base += 64 * n_waves)
 	{
-		if (base + lane >= total) continue;
-		uint32_t const rec = listed_record(W, n_regions, n_groups, base + lane);
-		uint32_t const n_runs = W.run_n[rec];
-		if (0 == n_runs || (W.rec_flags[rec] & REC_STATUS_MASK))
-			continue;		// rejected by k_realign_scan (or left out by an arena overflow: the batch is repeated)
-		uint32_t const *ops = W.arena + W.cig_loc[rec];
-		uint32_t const n_ops = W.cig_n[rec];
+		bool const mine = base + lane < total;
+		uint32_t const rec = mine ? listed_record(W, n_regions, n_groups, base + lane) : 0;
+		uint32_t const n_runs = mine ? W.run_n[rec] : 0;
+		bool const work = mine && n_runs && !(W.rec_flags[rec] & REC_STATUS_MASK);		// not rejected by k_realign_scan, not left out by an arena overflow
+		uint32_t const *ops_global = W.arena + (work ? W.cig_loc[rec] : 0);
+		uint32_t const n_ops = work ? W.cig_n[rec] : 0;
+		wave_lds_fence();
+		op_source const ops = stage_ops(ops_global, n_ops, my_ops, lane);
+		wave_lds_fence();
+		if (!work)
+			continue;
 		run_work const *items = W.run_items + W.run_loc[rec];
 		uint64_t const out_loc = items[0].splice_loc;
 		uint32_t *out = W.arena + out_loc;
@@ -829,14 +949,10 @@ int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in co
 		hipLaunchKernelGGL(k_gather_qual, dim3(list_blocks), dim3(256), 0, s, in, work, n_regions);
 	hipLaunchKernelGGL(k_realign_scan, dim3(list_blocks), dim3(256), 0, s, entries, in, work, n_regions, packed);
 	if (n_waves < 1) n_waves = 1;
-	hipLaunchKernelGGL((k_realign_dp <16, false>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 0u);
-	hipLaunchKernelGGL((k_realign_dp <16, true>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 1u);
-	hipLaunchKernelGGL((k_realign_dp <32, false>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 2u);
-	hipLaunchKernelGGL((k_realign_dp <32, true>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 3u);
-	hipLaunchKernelGGL((k_realign_dp <64, false>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 4u);
-	hipLaunchKernelGGL((k_realign_dp <64, true>), dim3(n_waves), dim3(64), 0, s, entries, in, work, params, 5u);
+	hipLaunchKernelGGL(k_realign_dp, dim3(n_waves, DP_CLASS_BIG), dim3(64), 0, s, work, params);
+	hipLaunchKernelGGL(k_realign_traceback, dim3(1024, DP_CLASS_BIG), dim3(256), 0, s, work);
 	if (big_waves < 1) big_waves = 1;
-	hipLaunchKernelGGL(k_realign_big, dim3(big_waves), dim3(64), 0, s, entries, in, work, params, lds_budget);
+	hipLaunchKernelGGL(k_realign_big, dim3(big_waves), dim3(64), 0, s, work, params, lds_budget);
 	hipLaunchKernelGGL(k_realign_splice, dim3(list_blocks), dim3(256), 0, s, in, work, n_regions);
 	return (int) hipGetLastError();
 }

@@ -95,6 +95,8 @@ struct synth_genome_params
 	uint32_t long_min, long_max;
 	double carrier_prob;		// each founder carries each ALT with this probability
 	uint32_t lowercase_every;	// if non-zero, every n-th REF base is written in lower case (soft-masked reference)
+	double indel_mean_len;		// mean of the geometric part of an indel's length (0: 3)
+	uint32_t indel_max_len;		// its cap (0: 40)
 };
 
 struct synth_reads_params
@@ -176,7 +178,9 @@ void build_contig(synth_genome_params const &p, uint32_t ci, uint64_t len, conti
 		}
 		else if (u < p.snv_rate + p.indel_rate)
 		{
-			uint32_t const l = 1 + (uint32_t) std::min <uint64_t>(g.geometric(1.0 / 3.0), 40);
+			double const mean = (p.indel_mean_len > 0.0) ? p.indel_mean_len : 3.0;
+			uint32_t const cap = p.indel_max_len ? p.indel_max_len : 40;
+			uint32_t const l = 1 + (uint32_t) std::min <uint64_t>(g.geometric(1.0 / mean), cap);
 			if (g.next() & 1) e.ins_len = l; else e.del_len = l;
 		}
 		else if (u < p.snv_rate + p.indel_rate + p.complex_rate)

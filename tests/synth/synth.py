@@ -39,7 +39,7 @@ class GenomeParams(C.Structure):
 		("seed", C.c_uint64), ("genome_len", C.c_uint64), ("n_contigs", C.c_uint32), ("n_founders", C.c_uint32),
 		("snv_rate", C.c_double), ("indel_rate", C.c_double), ("complex_rate", C.c_double), ("complex_max", C.c_uint32),
 		("long_rate", C.c_double), ("long_min", C.c_uint32), ("long_max", C.c_uint32), ("carrier_prob", C.c_double),
-		("lowercase_every", C.c_uint32),
+		("lowercase_every", C.c_uint32), ("indel_mean_len", C.c_double), ("indel_max_len", C.c_uint32),
 	]
 
 
@@ -193,7 +193,7 @@ def config(name, scale=1.0, seed=None):
 	"""BASELINE.json configurations.  Returns (GenomeParams, ReadsParams, description)."""
 	name = name.upper()
 	base = dict(snv_rate=1e-3, indel_rate=1e-4, complex_rate=5e-5, complex_max=15, long_rate=0.0, long_min=20, long_max=60,
-				carrier_prob=0.5, lowercase_every=0)
+				carrier_prob=0.5, lowercase_every=0, indel_mean_len=0.0, indel_max_len=0)
 	reads = dict(read_len=150, paired=1, insert_mean=400.0, insert_sd=50.0, sub_rate=0.005, indel_read_frac=0.02, clip_read_frac=0.03,
 				 with_qual=1, n_base_rate=0.0)
 	if name == "C2":
@@ -202,6 +202,11 @@ def config(name, scale=1.0, seed=None):
 	elif name == "C3":
 		g = dict(genome_len=1_000_000_000, n_contigs=8, n_founders=8); r = dict(n_records=40_000_000); num = 3
 		desc = "C3: 20 M 2x150 bp pairs (40 M records), REF + 8 founders, 1 Gbp in 8 contigs"
+	elif name == "C3G":
+		# C3 on an MSA with the gap statistics of the reference's shipped test MSA (test-workflow/index-input: 21 - 26 % gap columns
+		# per row, gap runs of mean length 16, longest 63): an insertion or deletion of mean length 16 every 22 bases
+		g = dict(genome_len=1_000_000_000, n_contigs=8, n_founders=8, indel_rate=0.045, indel_mean_len=15.0, indel_max_len=62); r = dict(n_records=40_000_000); num = 3
+		desc = "C3G: 20 M 2x150 bp pairs (40 M records), REF + 8 founders, 1 Gbp in 8 contigs, gap-dense MSA (a gap run of mean length 16 every 22 bases)"
 	elif name == "C4":
 		g = dict(genome_len=1_000_000_000, n_contigs=8, n_founders=8); r = dict(n_records=400_000_000); num = 4
 		desc = "C4: 200 M 2x150 bp pairs sharded over 8 GPUs"

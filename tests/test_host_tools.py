@@ -370,3 +370,77 @@ def test_convert_bed_positions_cli(tools, built_index, oracle_mod):
 	(tmp_path / "bad.bed").write_text("test\t5\n")
 	bad = _run([tools["panvc3_convert_bed_positions"], "-m", "msa-index.dat", "-c", "test", "-s", "1", "-d", "3", "-b", "bad.bed"], cwd=tmp_path, check=False)
 	assert bad.returncode != 0 and b"Parse error in BED input on line 1." in bad.stderr
+
+
+@pytest.mark.gpu
+def test_recalculate_mapq_cli(tools, tmp_path):
+	"""bin/panvc3_recalculate_mapq (host I/O + the MAPQ kernels behind the C ABI) against the restatement of the reference
+	tool (oracle/recalculate_mapq_tool.py): QNAME groups of paired, unpaired and mixed records with XR / XP / YR / YP tags as
+	project_alignments writes them, with and without --rescore-alignments, SAM and BAM.  Parity with the reference binary is
+	unpinned (no fixture exists for this tool)."""
+	from oracle import recalculate_mapq_tool as tool
+	rng = np.random.default_rng(99)
+	names = ["chr1", "chr2", "chr3"]
+	refs = [(n, 100000) for n in names]
+	header = "@HD\tVN:1.6\tSO:unsorted\tGO:query\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs) + "@PG\tID:panvc3.project-alignments.1\tPN:PanVC 3 project_alignments\n"
+	recs = []
+	for gi in range(600):
+		kind = int(rng.integers(0, 10))
+		name = "read%d" % gi
+		seq1 = "".join("ACGTN"[x] for x in rng.choice(5, size=int(rng.integers(40, 120)), p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+		seq2 = "".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.integers(40, 120))))
+
+		def rec(flag, chrom, pos, seq, rnext, pnext, tags):
+			# a CIGAR in = / X form with an indel run now and then, covering the whole read
+			n = len(seq)
+			a = int(rng.integers(1, n - 4)); b = n - a
+			cigar = "%d=1X%d=" % (a, b - 1) if rng.random() < 0.6 else "%d=2I1D%d=" % (a, b - 2)
+			ref_len = sum(int(c[:-1]) for c in __import__("re").findall(r"\d+[=XD]", cigar))
+			bits = bytearray((ref_len + 7) // 8)
+			if rng.random() < 0.3:
+				bits[int(rng.integers(0, len(bits)))] |= 1 << int(rng.integers(0, 8))
+			qual = "".join(chr(33 + int(q)) for q in rng.integers(2, 42, size=n))
+			tags = sorted(tags + [("XN", "B", ("C", list(bits)))], key=lambda t: (ord(t[0][0]), ord(t[0][1])))
+			return bamio.Record(name, flag, chrom, pos, int(rng.integers(0, 43)), cigar, rnext, pnext, 0, seq, qual, tags)
+		k = int(rng.integers(1, 6))
+		if kind >= 2:
+			for a in range(k):
+				chrom = names[rng.integers(3)]
+				p1 = int(rng.integers(1, 400)) * 100; p2 = p1 + 300
+				t1 = [("AS", "i", -int(rng.integers(0, 40))), ("XR", "i", 10 + a), ("XP", "i", p1 + a), ("YR", "i", 10 + a), ("YP", "i", p2 + a), ("XI", "i", gi)]
+				t2 = [("AS", "i", -int(rng.integers(0, 40))), ("XR", "i", 10 + a), ("XP", "i", p2 + a), ("YR", "i", 10 + a), ("YP", "i", p1 + a), ("XI", "i", gi)]
+				if rng.random() < 0.05: t1 = [t for t in t1 if t[0] != "AS"]
+				recs.append(rec(99, chrom, p1, seq1, "=", p2, t1))
+				if rng.random() < 0.9: recs.append(rec(147, chrom, p2, seq2, "=", p1, t2))
+		else:
+			for a in range(k):
+				chrom = names[rng.integers(3)]
+				p1 = int(rng.integers(1, 400)) * 100
+				recs.append(rec(0, chrom, p1, seq1, "*", 0, [("AS", "i", -int(rng.integers(0, 40))), ("XR", "i", 10 + a), ("XP", "i", p1)]))
+			if kind == 1:
+				recs.append(rec(99, names[0], 500, seq1, "=", 800, [("AS", "i", 0), ("XR", "i", 1), ("XP", "i", 500), ("YR", "i", 1), ("YP", "i", 800)]))
+		if rng.random() < 0.1:
+			recs.append(bamio.Record(name, 4, "*", 0, 0, "*", "*", 0, 0, seq1, "*", []))		# unmapped: dropped
+	bamio.write_bam(tmp_path / "in.bam", header, refs, recs)
+	exe = os.path.join(BIN, "panvc3_recalculate_mapq")
+	for rescore in (False, True):
+		want, stats = tool.process(recs, names, rescore=rescore)
+		args = [exe, "--alignments=in.bam"] + (["--rescore-alignments"] if rescore else [])
+		p = _run(args + ["--output-path=out.sam"], cwd=tmp_path)
+		got = [l for l in open(tmp_path / "out.sam").read().split("\n") if l and not l.startswith("@")]
+		exp = []
+		for r, mapq, tags in want:
+			rnext = "=" if r.rnext == r.rname and r.rname != "*" else r.rnext
+			exp.append(bamio.Record(r.qname, r.flag, r.rname, r.pos, mapq, r.cigar, rnext, r.pnext, r.tlen, r.seq, r.qual, tags).sam_line())
+		assert len(got) == len(exp)
+		for a, b in zip(got, exp):
+			assert a == b
+		err = p.stderr.decode()
+		assert "Total alignments: %d" % stats["total_alignments"] in err and "Records with mate missing: %d" % stats["mate_not_found"] in err
+		assert "Reads with and without a mate: %d" % stats["reads_with_and_without_mate"] in err and stats["reads_with_and_without_mate"] > 10
+		head = [l for l in open(tmp_path / "out.sam").read().split("\n") if l.startswith("@PG")]
+		assert head[-1].startswith("@PG\tID:panvc3.recalculate-mapq.1\tPN:PanVC 3 recalculate_mapq") and "PP:panvc3.project-alignments.1" in head[-1]
+		# BAM out, small batches: the same records
+		_run(args + ["--output-bam", "--output-path=out.bam", "--batch-records=100"], cwd=tmp_path)
+		_, _, back = bamio.read_bam(tmp_path / "out.bam")
+		assert [(b["qname"], b["mapq"]) for b in back] == [(r.qname, mapq) for r, mapq, _ in want]

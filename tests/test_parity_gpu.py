@@ -88,3 +88,34 @@ def test_restated_rapidcheck_property_batch(pvc3, oracle_mod):
 	for go, ge in ((-3, -1), (-5, -2), (0, -4)):
 		got, _ = pvc3.project_batch(ctx, batch, go, ge, 0)
 		assert_results_equal(batch, got, o.batch_project(batch, go, ge, 0))
+
+
+@pytest.mark.parametrize("fixture", ["alignment_projector_inputs.tsv", "rewrite_cigar_inputs.tsv"])
+def test_cpp_mirror_header_on_reference_fixtures(pvc3, oracle_mod, fixture):
+	"""include/pvc3.hpp (the C++ mirror of panvc3::alignment_projector over the C ABI) compiled into a program and run: the
+	reference's tests/alignment_projector.cc:62-84 loop on the rows of its own fixtures, compared with the fixture's
+	expectations through the reference's comparator and with the oracle string for string."""
+	import os
+	import subprocess
+	from helpers import GOLDEN, ROOT
+	if "default" != pvc3.paths_mode:
+		pytest.skip("the program uses the library's default configuration")
+	exe = os.path.join(ROOT, "bin", "test_alignment_projector_fixture")
+	assert os.path.exists(exe), "bin/test_alignment_projector_fixture is built by __graft_entry__.build() / python -m panvc3_amd.build"
+	out = subprocess.run([exe, os.path.join(GOLDEN, fixture)], capture_output=True, text=True, timeout=300)
+	assert out.returncode == 0, out.stderr
+	got = {int(f[0]): f for f in (line.split("\t") for line in out.stdout.strip().split("\n"))}
+	cases = list(rewrite_cases(fixture))
+	assert sorted(got) == [c[0] for c in cases]
+	for ln, src, dst, query, src_pos, exp_pos, cin, cexp in cases:
+		f = got[ln]
+		o = oracle_mod.Oracle()
+		s, d = o.add_aligned(src), o.add_aligned(dst)
+		o.set_reference(d, dst.replace("-", ""))
+		opos, ocig, oruns = o.project_alignment(s, d, src_pos, cin, query, qual=[41] * len(query))
+		assert int(f[1]) == exp_pos == opos
+		assert f[2] == cigar_decode(ocig)
+		assert f[3] == "".join("%d,%d;" % (r["ref_position"], r["ref_length"]) for r in oruns)
+		assert f[4] == "".join("%d,%d;" % (r["query_location"], r["query_length"]) for r in oruns)
+		if not (fixture.startswith("alignment_projector") and ln == 10) and (fixture.startswith("alignment_projector") or len(oruns) == 0):
+			assert cigar_eq(cexp, f[2], count_padding=True)		# line 10 contradicts line 9 in the reference itself (SURVEY.md §4)

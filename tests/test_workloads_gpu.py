@@ -29,7 +29,7 @@ def _run_both(pvc3, oracle_mod, genome, batch, ctx=None, score_mode=0, gap=(0, -
 	return got, stats, ctx, o
 
 
-@pytest.mark.parametrize("name,scale", [("C2", 0.2), ("C3", 0.005), ("C5", 0.005)])
+@pytest.mark.parametrize("name,scale", [("C2", 0.2), ("C3", 0.005), ("C3G", 0.005), ("C5", 0.005)])
 def test_scaled_configs(pvc3, oracle_mod, synth, name, scale):
 	gp, rp, desc = synth.config(name, scale=scale)
 	genome = synth.Genome(gp)
@@ -290,7 +290,7 @@ def test_workspace_growth_and_scratch_paths(pvc3, oracle_mod, synth):
 	base, stats0, ctx, o = _run_both(pvc3, oracle_mod, genome, batch)
 	index = pvc3.Index()
 	genome.fill_index(index)
-	for opts in (dict(arena_initial=1000), dict(runs_initial=3), dict(realign_lds_bytes=64, packed_dp=0), dict(realign_lds_bytes=64, scratch_per_wave=512, packed_dp=0), dict(realign_waves=3), dict(big_waves=2, packed_dp=0), dict(packed_dp=1), dict(fast_path=0)):
+	for opts in (dict(arena_initial=1000), dict(runs_initial=3), dict(realign_lds_bytes=64, packed_dp=0), dict(realign_lds_bytes=64, scratch_per_wave=512, packed_dp=0), dict(realign_waves=3), dict(big_waves=2, packed_dp=0), dict(trace_initial=4096), dict(fast_path=0)):
 		c2 = pvc3.Context(0)
 		for k, v in opts.items():
 			c2.set_option(k, v)
@@ -298,7 +298,7 @@ def test_workspace_growth_and_scratch_paths(pvc3, oracle_mod, synth):
 		got, stats = pvc3.project_batch(c2, batch)
 		for k in ("status", "dst_pos", "mate_dst_pos", "out_cigar_off", "out_cigar", "run_off", "runs"):
 			assert np.array_equal(got[k], base[k]), (opts, k)
-		if "arena_initial" in opts or "runs_initial" in opts or "scratch_per_wave" in opts:
+		if "arena_initial" in opts or "runs_initial" in opts or "scratch_per_wave" in opts or ("trace_initial" in opts and "walk_only" != pvc3.paths_mode):
 			assert stats["attempts"] > 1, opts
 		c2.close()
 
@@ -479,6 +479,7 @@ def test_one_large_alignment_among_many_small(pvc3, oracle_mod):
 		recs.append(p + q + s)
 	ctx, o, ids = _edge_index(pvc3, oracle_mod, pairs)
 	ctx.set_option("scratch_budget", 16 << 20)
+	ctx.set_option("trace_initial", 1 << 20)		# 4 MB of trace words for the packed kernels (the default is sized for millions of records)
 	bb = BatchBuilder()
 	for (s, d), query in zip(ids, recs):
 		bb.add(0, s, d, "%dM" % len(query), query, qual=[int(x) for x in rng.integers(2, 42, size=len(query))])
@@ -487,7 +488,7 @@ def test_one_large_alignment_among_many_small(pvc3, oracle_mod):
 	assert_results_equal(batch, got, o.batch_project(batch))
 	assert stats["attempts"] == 2 and stats["n_runs"] == 300
 	_, workspace = ctx.hbm_bytes()
-	assert workspace <= (16 << 20) + (1 << 20)
+	assert workspace <= (16 << 20) + (4 << 20) + (1 << 20)
 
 
 def test_pipeline_matches_batch_project(pvc3, oracle_mod, synth):
@@ -574,12 +575,12 @@ def test_malformed_batches_are_refused(pvc3, oracle_mod):
 		return b
 	cases = [
 		broken(cigar_off=(5, 3)),							# decreasing
-		broken(cigar_off=(30, 1000)),						# past the array
+		broken(cigar_off=(12, 1000)),						# past the array (the last offset itself is the caller's statement of the array length)
 		broken(seq_off=(7, int(good["seq_off"][8]) - 1)),	# decreasing start: record 6 loses a byte ... and 7 starts early (fine), 6 is short
-		broken(seq_off=(30, 10**9)),
+		broken(seq_off=(20, 10**9)),
 		broken(l_seq=(4, 5000)),							# l_seq promises more SEQ than the record owns
 		broken(qual_off=(9, int(good["qual_off"][9]) + 50)),	# record 8 keeps 150 bytes, record 9 only 50
-		broken(qual_off=(30, 10**9)),
+		broken(qual_off=(17, 10**9)),
 	]
 	for bad in cases:
 		with pytest.raises(pvc3.Error) as ei:

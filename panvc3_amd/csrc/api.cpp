@@ -591,7 +591,7 @@ int dbatch_alloc(pvc3_context *ctx, batch_caps const &caps, pvc3_dbatch **out)
 	PVC3_TRY(dev_alloc(&w.wave_stats, 3 * (uint64_t) project_wave_count(n) * WAVE_STATS, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.out_cigar_off, n + 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->packed.run_off, n + 1, &b->allocs, &b->bytes));
-	PVC3_TRY(dev_alloc(&b->packed.status, n, &b->allocs, &b->bytes));
+	b->packed.status = (int32_t *) w.rec_flags;		// every record's flags end as its PVC3_ST_* value: no copy
 	PVC3_TRY(dev_alloc(&b->scan_tmp, pack_scan_tmp_words(n), &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->d_checksum, 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&b->d_invalid, 1, &b->allocs, &b->bytes));

@@ -146,7 +146,8 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *l
 }
 
 // Offsets of every record's operations / runs in the packed arrays (exclusive scan, tile prefix from k_scan_tile_sums) and,
-// in the same pass, the copy of the operations and runs out of the arenas and the status.  Thread t of a tile owns records
+// in the same pass, the copy of the operations and runs out of the arenas.  (The status output is the projection kernels'
+// flag array itself: every record ends with its PVC3_ST_* value there.)  Thread t of a tile owns records
 // base + 256 i + t: descriptor loads are coalesced and neighbouring lanes copy neighbouring pieces of the arenas.
 __global__ __launch_bounds__(SCAN_THREADS) void k_offsets_gather(uint64_t n, dev_batch_work const W, dev_batch_packed const P, uint64_t const *__restrict__ tile_sums, uint64_t const *__restrict__ totals)
 {
@@ -160,7 +161,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_offsets_gather(uint64_t n, dev
 		bool const valid = rec < n;
 		uint32_t const nc = valid ? W.cig_n[rec] : 0, nr = valid ? W.run_n[rec] : 0;
 		uint64_t const loc = valid ? W.cig_loc[rec] : 0;
-		uint32_t const fl = valid ? W.rec_flags[rec] : 0;
 		uint64_t total_a, total_b;
 		uint64_t const local_a = block_exclusive_scan(nc, lds, total_a);
 		uint64_t const off_a = carry_a + local_a;
@@ -172,7 +172,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_offsets_gather(uint64_t n, dev
 		{
 			P.out_cigar_off[rec] = off_a;
 			P.run_off[rec] = off_b;
-			P.status[rec] = (int32_t) (fl & REC_STATUS_MASK);
 			uint32_t const *src = W.arena + loc;
 			if (staged)
 				for (uint32_t k = 0; k < nc; ++k) stage[local_a + k] = src[k];

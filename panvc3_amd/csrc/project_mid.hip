@@ -138,6 +138,10 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 	uint32_t const count = W.slow_count[wave];
 	uint32_t *run_list = W.run_list + 64 * (n_groups * wave / n_waves);
 	uint32_t n_run = 0;		// wave-uniform
+	// The records this kernel leaves to k_project_general are written back to the front of the same list (never ahead of the
+	// entries still to be read: at most as many as have been read).
+	uint32_t *punt_list = W.slow_list + 64 * (n_groups * wave / n_waves);
+	uint32_t n_punt = 0;	// wave-uniform
 	__shared__ uint32_t lds_tok[4][64 * MID_TOKENS];
 	uint32_t *my_tok = lds_tok[rfl(threadIdx.x >> 6)] + lane;
 	arena_alloc arena{0, 0};
@@ -264,6 +268,12 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 		for (uint32_t k = 0; k < n_tok; ++k)
 			W.arena[loc + k] = my_tok[64 * k];
 		{
+			// What is left for k_project_general.  (The list is read 64 entries ahead of where it is written.)
+			uint64_t const m = ballot(mine && punt);
+			if ((m >> lane) & 1) punt_list[n_punt + mbcnt64(m)] = rec;
+			n_punt += popc64(m);
+		}
+		{
 			// Work list for k_realign.
 			uint64_t const m = ballot(done && ok && out.has_run);
 			if ((m >> lane) & 1) run_list[n_run + mbcnt64(m)] = rec;
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 		}
 		if (done)
 		{
-			W.rec_flags[rec] = status | ((ok && out.has_run) ? REC_HAS_RUN : 0);
+			W.rec_flags[rec] = status;		// the records with an indel run are in the work list for k_realign
 			W.cig_n[rec] = n_tok;
 			W.cig_loc[rec] = loc;
 			if (!ok) W.dst_pos[rec] = 0;		// a rejected record has empty outputs
@@ -287,7 +297,8 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 		}
 	}
 
-	W.run_count[wave] = n_run;		// wave-uniform store
+	W.run_count[wave] = n_run;		// wave-uniform stores
+	W.slow_count[wave] = n_punt;
 	for (int off = 32; off; off >>= 1)
 	{
 		acc_bitvec += __shfl_xor(acc_bitvec, off);

@@ -123,7 +123,8 @@ struct dev_counters
 	unsigned long long qual_head;		// next free byte of that buffer
 };
 
-// Per-record results before packing.  flags: bits 0-7 status, bit 8 = has at least one indel run.
+// Per-record results before packing.  rec_flags: bits 0-7 status; REC_SLOW while a record waits for k_project_mid /
+// k_project_general, which leave the plain status (the array then doubles as the status output).
 struct dev_batch_work
 {
 	uint32_t *dst_pos;

@@ -392,21 +392,44 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 			}
 		}
 	}
-	wave_lds_fence();
-#pragma unroll
-	for (uint32_t c = 0; c < DP_CLASSES; ++c)
-		if (staged[c]) flush(c);
+	// What is left goes out once per block: the four waves add up their counts, one thread per class reserves the block's
+	// piece of the class list (the counters of all classes share a cache line: thousands of atomics on it take longer than the
+	// rest of this kernel on a small batch), then every wave copies its items.
+	__shared__ uint32_t blk_cnt[4][DP_CLASSES], blk_base[DP_CLASSES];
+	__shared__ unsigned long long blk_acc[4][3];
 	for (int off = 32; off; off >>= 1)
 	{
 		acc_runs += __shfl_xor(acc_runs, off);
 		acc_failed += __shfl_xor(acc_failed, off);
 		acc_qual += __shfl_xor(acc_qual, off);
 	}
-	if (0 == lane && acc_failed) atomicAdd(&W.counters->n_failed, (unsigned long long) acc_failed);
-	if (0 == lane && acc_runs)
+	uint32_t const wv = rfl(threadIdx.x >> 6);
+	if (0 == lane)
 	{
-		atomicAdd(&W.counters->n_runs, (unsigned long long) acc_runs);
-		atomicAdd(&W.counters->qual_bytes, (unsigned long long) acc_qual);
+#pragma unroll
+		for (uint32_t c = 0; c < DP_CLASSES; ++c) blk_cnt[wv][c] = staged[c];
+		blk_acc[wv][0] = acc_failed; blk_acc[wv][1] = acc_runs; blk_acc[wv][2] = acc_qual;
+	}
+	__syncthreads();
+	if (threadIdx.x < DP_CLASSES)
+	{
+		uint32_t const tot = blk_cnt[0][threadIdx.x] + blk_cnt[1][threadIdx.x] + blk_cnt[2][threadIdx.x] + blk_cnt[3][threadIdx.x];
+		blk_base[threadIdx.x] = tot ? atomicAdd(&W.counters->dp_count[threadIdx.x], tot) : 0;
+	}
+	else if (threadIdx.x >= 64 && threadIdx.x < 67)
+	{
+		uint32_t const k = threadIdx.x - 64;
+		unsigned long long const tot = blk_acc[0][k] + blk_acc[1][k] + blk_acc[2][k] + blk_acc[3][k];
+		if (tot) atomicAdd((0 == k) ? &W.counters->n_failed : (1 == k) ? &W.counters->n_runs : &W.counters->qual_bytes, tot);
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t c = 0; c < DP_CLASSES; ++c)
+	{
+		uint32_t at = blk_base[c];
+		for (uint32_t w2 = 0; w2 < wv; ++w2) at += blk_cnt[w2][c];
+		for (uint32_t i = lane; i < staged[c]; i += 64)
+			W.dp_list[(uint64_t) c * W.runs_cap + at + i] = stage[c][i];
 	}
 }
 

@@ -45,7 +45,7 @@ inline void parallel_for(std::size_t n, unsigned n_threads, t_fn &&fn)
 inline unsigned default_io_threads()
 {
 	unsigned const hc = std::thread::hardware_concurrency();
-	return hc ? std::min(hc, 16u) : 4u;
+	return hc ? std::min(hc, 32u) : 4u;
 }
 
 // Sequential byte source: a file or stdin.  BGZF input (BAM, bgzip'ed SAM) is inflated block-parallel; plain gzip and

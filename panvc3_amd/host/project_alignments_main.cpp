@@ -14,7 +14,11 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <future>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -50,11 +54,12 @@ struct options
 {
 	char const *alignments{}, *msa_index{}, *reference{}, *reference_msa_id{}, *ref_order{}, *output_path{}, *realigned_ranges{};
 	std::string separator{"_"};
-	bool bam_input{}, output_bam{}, keep_duplicate_ranges{}, print_invocation{}, print_pid{}, io_only{};
+	bool bam_input{}, output_bam{}, keep_duplicate_ranges{}, print_invocation{}, print_pid{}, io_only{}, debugging_output{};
 	std::vector <std::string> preserve_tags;
 	std::string rname_tag{"XR"}, pos_tag{"XP"}, rnext_tag{"YR"}, pnext_tag{"YP"}, query_ranges_tag{"XB"}, ref_ranges_tag{"YB"}, rec_idx_tag;
-	int gap_open{0}, gap_ext{-1}, device{0};
-	uint64_t batch_size{UINT64_C(1) << 21};
+	int gap_open{0}, gap_ext{-1}, compression_level{6};
+	std::vector <int> devices{0};		// --device / --devices: batches go to the GPUs in turn, output stays in input order
+	uint64_t batch_size{UINT64_C(1) << 18};		// records per GPU batch: small enough for reading, projecting and writing of consecutive batches to overlap
 	unsigned threads{default_io_threads()};		// BGZF inflate / deflate
 };
 
@@ -78,7 +83,10 @@ void usage()
 		"      --realigned-query-ranges-tag=XB --realigned-ref-ranges-tag=YB --record-index-tag=TAG\n"
 		"  -q, --use-read-base-qualities        accepted, no effect (as in the reference)\n"
 		"  -g, --gap-opening-cost=INT           (default 0)     -e, --gap-extension-cost=INT (default -1)\n"
-		"      --device=INT                     GPU to use (default 0)\n";
+		"      --device=INT                     GPU to use (default 0)\n"
+		"      --devices=LIST                   GPUs to use, e.g. 0,1,2,3: batches go to them in turn (output order = input order)\n"
+		"      --threads=INT                    host threads for (de)compression, parsing and rewriting\n"
+		"      --compression-level=0..9         BGZF level of BAM output (default 6)\n";
 }
 
 // process_headers (project_alignments.cc:1092-1253)
@@ -156,10 +164,23 @@ void append_program_info(sam_header const &in, sam_header &out, int argc, char *
 	append_sam_program_info(in, out, "panvc3.project-alignments.", "PanVC 3 project_alignments", argc, argv);
 }
 
-struct pending_record
+// The records of one batch: their bytes back to back in one arena (no allocation per record).
+struct batch_store
 {
-	bam_record rec;
-	uint64_t input_index{};		// index among all input records, filtered ones included
+	std::vector <uint8_t> raw;
+	std::vector <uint64_t> off{0};			// [n + 1]
+	std::vector <uint64_t> input_index;		// index among all input records, filtered ones included
+	std::size_t size() const { return input_index.size(); }
+	bool empty() const { return input_index.empty(); }
+	bam_view operator[](std::size_t i) const { return bam_view{raw.data() + off[i], (std::size_t) (off[i + 1] - off[i])}; }
+	void clear() { raw.clear(); off.assign(1, 0); input_index.clear(); }
+	void swap(batch_store &o) { raw.swap(o.raw); off.swap(o.off); input_index.swap(o.input_index); }
+};
+
+// Finished batches on their way to the output file: the formatted bytes of the slices, in order.
+struct write_job
+{
+	std::vector <std::string> slices;
 };
 
 }	// anonymous namespace
@@ -181,6 +202,7 @@ int main(int argc, char **argv)
 		{"gap-opening-cost", required_argument, nullptr, 'g'}, {"gap-extension-cost", required_argument, nullptr, 'e'},
 		{"print-invocation", no_argument, nullptr, 1009}, {"print-pid", no_argument, nullptr, 1010}, {"debugging-output", no_argument, nullptr, 1011},
 		{"device", required_argument, nullptr, 1012}, {"batch-size", required_argument, nullptr, 1013}, {"io-only", no_argument, nullptr, 1014}, {"threads", required_argument, nullptr, 1015},
+		{"devices", required_argument, nullptr, 1016}, {"compression-level", required_argument, nullptr, 1017},
 		{"help", no_argument, nullptr, 'h'}, {"version", no_argument, nullptr, 'V'}, {nullptr, 0, nullptr, 0}};
 	int c;
 	while (-1 != (c = getopt_long(argc, argv, "a:Bm:r:d:s:u:o:bl:t:qg:e:hV", long_opts, nullptr)))
@@ -212,8 +234,16 @@ int main(int argc, char **argv)
 			case 'e': opt.gap_ext = std::atoi(optarg); break;
 			case 1009: opt.print_invocation = true; break;
 			case 1010: opt.print_pid = true; break;
-			case 1011: break;
-			case 1012: opt.device = std::atoi(optarg); break;
+			case 1011: opt.debugging_output = true; break;
+			case 1012: opt.devices.assign(1, std::atoi(optarg)); break;
+			case 1016:
+			{
+				opt.devices.clear();
+				for (char const *q = optarg; *q; ) { char *end{}; opt.devices.push_back((int) std::strtol(q, &end, 10)); if (end == q) die("--devices expects a comma-separated list of GPU numbers"); q = (',' == *end) ? end + 1 : end; }
+				if (opt.devices.empty()) die("--devices expects a comma-separated list of GPU numbers");
+				break;
+			}
+			case 1017: opt.compression_level = std::max(0, std::min(9, std::atoi(optarg))); break;
 			case 1013: opt.batch_size = std::strtoull(optarg, nullptr, 10); break;
 			case 1014: opt.io_only = true; break;
 			case 1015: opt.threads = (unsigned) std::max(1, std::atoi(optarg)); break;
@@ -316,13 +346,50 @@ int main(int argc, char **argv)
 				check(pvc3_index_set_reference(index, dst_entries[o], it->second.data(), it->second.size()), "pvc3_index_set_reference");
 			}
 		}
-		pvc3_context *ctx{};
-		check(pvc3_context_create(opt.device, &ctx), "pvc3_context_create");
-		check(pvc3_context_upload_index(ctx, index), "pvc3_context_upload_index");
+		double t_startup = 0.0;
+		std::vector <pvc3_context *> contexts;
+		for (int const dev : opt.devices)
+		{
+			pvc3_context *ctx{};
+			check(pvc3_context_create(dev, &ctx), "pvc3_context_create");
+			check(pvc3_context_upload_index(ctx, index), "pvc3_context_upload_index");		// the index is replicated on every GPU
+			contexts.push_back(ctx);
+		}
 
 		alignment_writer writer;
 		writer.set_threads(opt.threads);
-		writer.open(opt.output_path, opt.output_bam, out_header);
+		writer.open(opt.output_path, opt.output_bam, out_header, opt.compression_level);
+
+		// The output file is written by a thread of its own (BGZF deflate is most of the CPU time of a BAM-to-BAM run): batch k
+		// is compressed and written while batch k + 1 is rewritten and batch k + 2 is read.
+		std::mutex wq_mutex;
+		std::condition_variable wq_cv;
+		std::deque <write_job> wq;
+		bool wq_done = false;
+		std::exception_ptr writer_error;
+		double tm_write = 0.0;
+		std::thread writer_thread([&]() {
+			try
+			{
+				for (;;)
+				{
+					write_job job;
+					{
+						std::unique_lock <std::mutex> lock(wq_mutex);
+						wq_cv.wait(lock, [&]() { return wq_done || !wq.empty(); });
+						if (wq.empty()) break;
+						job = std::move(wq.front());
+						wq.pop_front();
+					}
+					wq_cv.notify_all();
+					auto const t_write = std::chrono::steady_clock::now();
+					for (auto const &bytes : job.slices) writer.write_formatted(bytes.data(), bytes.size());
+					tm_write += std::chrono::duration <double>(std::chrono::steady_clock::now() - t_write).count();
+				}
+			}
+			catch (...) { writer_error = std::current_exception(); std::lock_guard <std::mutex> lock(wq_mutex); wq.clear(); wq_done = true; wq_cv.notify_all(); }
+		});
+		struct join_writer { std::thread &t; std::mutex &m; std::condition_variable &cv; bool &done; ~join_writer() { { std::lock_guard <std::mutex> l(m); done = true; } cv.notify_all(); if (t.joinable()) t.join(); } } writer_joiner{writer_thread, wq_mutex, wq_cv, wq_done};
 
 		// ---- records ----------------------------------------------------------------------------------------------------------------
 		struct { uint64_t flags_not_matched{}, ref_id_missing{}, seq_missing{}, matched_reads{}; } st;
@@ -331,10 +398,15 @@ int main(int argc, char **argv)
 		uint64_t n_realigned_ranges = 0;
 		pvc3_params const params{opt.gap_open, opt.gap_ext, PVC3_SCORE_FP64, 0};
 
-		std::vector <pending_record> batch;
-		uint64_t input_index = 0;
+		// --debugging-output: where the wall clock goes (seconds, summed over the batches)
+		struct stage_times { double read{}, wait_read{}, fill{}, gpu{}, rewrite{}, wait_write{}, write{}; } tm;
+		auto now = []() { return std::chrono::steady_clock::now(); };
+		auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration <double>(std::chrono::steady_clock::now() - t0).count(); };
+		batch_store batch, next_batch;
+		t_startup = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+		uint64_t input_index = 0, batch_no = 0;
 		bool eof = false;
-		bam_record rec;
+		bam_record scratch;
 		std::vector <uint32_t> b_src_pos, b_src_entry, b_dst_entry, b_flags, b_cigar, b_l_seq, b_mate_se, b_mate_de, b_mate_pos;
 		std::vector <uint64_t> b_cigar_off, b_seq_off, b_qual_off;
 		std::vector <uint8_t> b_seq4, b_qual;
@@ -348,29 +420,37 @@ int main(int argc, char **argv)
 			std::map <uint16_t, std::vector <uint8_t>> tags;		// ordered by tag key, as seqan3's sam_tag_dictionary
 			std::vector <std::pair <uint32_t, uint32_t>> ranges;
 			std::map <uint16_t, uint64_t> removed;
+			bam_record w;
 			uint64_t n_ranges{};
 		};
 		std::vector <slice_state> slices;
 
 		// Fills a batch with records that pass the filters; a multiple of the reference's CHUNK_SIZE (4) unless the input ends.
-		// Runs on a helper thread while the previous batch is on the GPU / being rewritten / being written.
-		auto read_batch = [&](std::vector <pending_record> &dst) {
+		// Runs on a helper thread while the previous batch is on the GPU / being rewritten.
+		auto read_batch = [&](batch_store &dst) {
+			auto const t_read = now();
+			struct add_time { double &acc; std::chrono::steady_clock::time_point t0; ~add_time() { acc += std::chrono::duration <double>(std::chrono::steady_clock::now() - t0).count(); } } timer{tm.read, t_read};
 			dst.clear();
 			while (!eof && (dst.size() < opt.batch_size || (dst.size() & 3)))
 			{
-				if (!reader.next(rec)) { eof = true; break; }
+				std::size_t const at = dst.raw.size();
+				if (!reader.next_append(dst.raw, scratch)) { eof = true; break; }
+				bam_view const rec{dst.raw.data() + at, dst.raw.size() - at};
 				uint64_t const idx = input_index++;
 				uint16_t const fl = rec.flag();
-				if (fl & (0x4 | 0x200 | 0x400)) { ++st.flags_not_matched; continue; }		// unmapped, QC fail, duplicate (:528-537)
-				if (rec.ref_id() < 0) { ++st.ref_id_missing; continue; }						// :546-551
-				if (rec.pos() < 0) { ++st.flags_not_matched; continue; }						// :553-564
-				if (0 == rec.l_seq()) { ++st.seq_missing; continue; }							// :566-570
-				if ((std::size_t) rec.ref_id() >= src_entries.size()) throw std::runtime_error("record with a reference id outside the header");
+				bool keep = false;
+				if (fl & (0x4 | 0x200 | 0x400)) ++st.flags_not_matched;		// unmapped, QC fail, duplicate (:528-537)
+				else if (rec.ref_id() < 0) ++st.ref_id_missing;				// :546-551
+				else if (rec.pos() < 0) ++st.flags_not_matched;				// :553-564
+				else if (0 == rec.l_seq()) ++st.seq_missing;				// :566-570
+				else if ((std::size_t) rec.ref_id() >= src_entries.size()) throw std::runtime_error("record with a reference id outside the header");
+				else keep = true;
+				if (!keep) { dst.raw.resize(at); continue; }
 				++st.matched_reads;
-				dst.push_back({rec, idx});
+				dst.off.push_back(dst.raw.size());
+				dst.input_index.push_back(idx);
 			}
 		};
-		std::vector <pending_record> next_batch;
 		read_batch(batch);
 		while (!batch.empty())
 		{
@@ -378,42 +458,54 @@ int main(int argc, char **argv)
 			if (!eof) prefetch = std::async(std::launch::async, [&]() { read_batch(next_batch); });
 			struct join_prefetch { std::future <void> &f; ~join_prefetch() { if (f.valid()) f.wait(); } } joiner{prefetch};
 			uint64_t const n = batch.size();
+			pvc3_context *ctx = contexts[batch_no++ % contexts.size()];
+			auto t_stage = now();
 
-			// SoA batch (include/pvc3.h).
+			// SoA batch (include/pvc3.h): offsets first (one cheap pass), then the slices are filled by all threads.
 			b_src_pos.resize(n); b_src_entry.resize(n); b_dst_entry.resize(n); b_flags.resize(n); b_l_seq.resize(n);
-			b_mate_se.assign(n, 0); b_mate_de.assign(n, 0); b_mate_pos.assign(n, 0);
-			b_cigar_off.assign(1, 0); b_seq_off.assign(1, 0); b_qual_off.assign(1, 0);
-			b_cigar.clear(); b_seq4.clear(); b_qual.clear();
+			b_mate_se.resize(n); b_mate_de.resize(n); b_mate_pos.resize(n);
+			b_cigar_off.resize(n + 1); b_seq_off.resize(n + 1); b_qual_off.resize(n + 1);
+			b_cigar_off[0] = b_seq_off[0] = b_qual_off[0] = 0;
 			for (uint64_t i = 0; i < n; ++i)
 			{
-				bam_record const &r = batch[i].rec;
-				b_src_pos[i] = (uint32_t) r.pos();
-				b_src_entry[i] = src_entries[(std::size_t) r.ref_id()];
-				b_dst_entry[i] = dst_entries[ref_id_mapping[(std::size_t) r.ref_id()]];
-				b_l_seq[i] = r.l_seq();
-				uint32_t fl = r.has_qual() ? PVC3_FLAG_HAS_QUAL : 0;
-				if (r.next_ref_id() >= 0 && r.next_pos() >= 0)
-				{
-					if ((std::size_t) r.next_ref_id() >= src_entries.size()) die("record with a mate reference id outside the header");
-					fl |= PVC3_FLAG_HAS_MATE;
-					b_mate_se[i] = src_entries[(std::size_t) r.next_ref_id()];
-					b_mate_de[i] = dst_entries[ref_id_mapping[(std::size_t) r.next_ref_id()]];
-					b_mate_pos[i] = (uint32_t) r.next_pos();
-				}
-				b_flags[i] = fl;
-				uint8_t const *p = r.data.data();
-				for (uint16_t k = 0; k < r.n_cigar(); ++k) b_cigar.push_back(r.get <uint32_t>(r.cigar_offset() + 4u * k));
-				b_cigar_off.push_back(b_cigar.size());
-				b_seq4.insert(b_seq4.end(), p + r.seq_offset(), p + r.qual_offset());
-				b_seq_off.push_back(b_seq4.size());
-				if (r.has_qual()) b_qual.insert(b_qual.end(), p + r.qual_offset(), p + r.aux_offset());
-				b_qual_off.push_back(b_qual.size());
+				bam_view const r = batch[i];
+				b_cigar_off[i + 1] = b_cigar_off[i] + r.n_cigar();
+				b_seq_off[i + 1] = b_seq_off[i] + (r.l_seq() + 1) / 2;
+				b_qual_off[i + 1] = b_qual_off[i] + (r.has_qual() ? r.l_seq() : 0);
 			}
+			b_cigar.resize(b_cigar_off[n]); b_seq4.resize(b_seq_off[n]); b_qual.resize(b_qual_off[n]);
+			std::size_t const n_fill = std::min <std::size_t>(n, 4 * (std::size_t) opt.threads);
+			parallel_for(n_fill, opt.threads, [&](std::size_t si) {
+				for (uint64_t i = n * si / n_fill; i < n * (si + 1) / n_fill; ++i)
+				{
+					bam_view const r = batch[i];
+					b_src_pos[i] = (uint32_t) r.pos();
+					b_src_entry[i] = src_entries[(std::size_t) r.ref_id()];
+					b_dst_entry[i] = dst_entries[ref_id_mapping[(std::size_t) r.ref_id()]];
+					b_l_seq[i] = r.l_seq();
+					uint32_t fl = r.has_qual() ? PVC3_FLAG_HAS_QUAL : 0;
+					b_mate_se[i] = 0; b_mate_de[i] = 0; b_mate_pos[i] = 0;
+					if (r.next_ref_id() >= 0 && r.next_pos() >= 0)
+					{
+						if ((std::size_t) r.next_ref_id() >= src_entries.size()) throw std::runtime_error("record with a mate reference id outside the header");
+						fl |= PVC3_FLAG_HAS_MATE;
+						b_mate_se[i] = src_entries[(std::size_t) r.next_ref_id()];
+						b_mate_de[i] = dst_entries[ref_id_mapping[(std::size_t) r.next_ref_id()]];
+						b_mate_pos[i] = (uint32_t) r.next_pos();
+					}
+					b_flags[i] = fl;
+					uint8_t const *p = r.bytes();
+					std::memcpy(b_cigar.data() + b_cigar_off[i], p + r.cigar_offset(), 4 * (std::size_t) r.n_cigar());
+					std::memcpy(b_seq4.data() + b_seq_off[i], p + r.seq_offset(), (r.l_seq() + 1) / 2);
+					if (r.has_qual()) std::memcpy(b_qual.data() + b_qual_off[i], p + r.qual_offset(), r.l_seq());
+				}
+			});
 			pvc3_batch_in in{};
 			in.n = n; in.src_pos = b_src_pos.data(); in.src_entry = b_src_entry.data(); in.dst_entry = b_dst_entry.data(); in.flags = b_flags.data();
 			in.cigar_off = b_cigar_off.data(); in.cigar = b_cigar.data(); in.seq_off = b_seq_off.data(); in.l_seq = b_l_seq.data(); in.seq4 = b_seq4.data();
 			in.qual_off = b_qual_off.data(); in.qual = b_qual.data();
 			in.mate_src_entry = b_mate_se.data(); in.mate_dst_entry = b_mate_de.data(); in.mate_pos = b_mate_pos.data();
+			tm.fill += since(t_stage); t_stage = now();
 
 			pvc3_dbatch *db{};
 			pvc3_batch_stats stats{};
@@ -428,6 +520,7 @@ int main(int argc, char **argv)
 			out.run_off = o_run_off.data(); out.runs = o_runs.data(); out.run_cap = o_runs.size();
 			check(pvc3_dbatch_download(ctx, db, &out), "pvc3_dbatch_download");
 			pvc3_dbatch_destroy(db);
+			tm.gpu += since(t_stage); t_stage = now();
 
 			// Rewrite the records: contiguous slices of the batch on separate threads, each into its own byte string; the strings
 			// are written in slice order, so the output does not depend on the number of threads.
@@ -440,9 +533,9 @@ int main(int argc, char **argv)
 			std::string &oa = S.oa;
 			for (uint64_t i = n * si / n_slices; i < n * (si + 1) / n_slices; ++i)
 			{
-				bam_record const &r = batch[i].rec;
+				bam_view const r = batch[i];
 				if (o_status[i])
-					throw std::runtime_error(std::string("record ") + r.read_name() + " (input record " + std::to_string(batch[i].input_index) + ") cannot be projected: status " + std::to_string(o_status[i])
+					throw std::runtime_error(std::string("record ") + r.read_name() + " (input record " + std::to_string(batch.input_index[i]) + ") cannot be projected: status " + std::to_string(o_status[i])
 						+ " (the reference asserts here: position or CIGAR inconsistent with the index)");
 				int32_t const ref_id = r.ref_id();
 				uint32_t const *cig = o_cigar.data() + o_cigar_off[i];
@@ -458,7 +551,7 @@ int main(int argc, char **argv)
 				tags.clear();
 				bool have_nm = false; int64_t nm = 0;
 				std::string old_oa;
-				for (auto const &f : parse_aux(r.data.data() + r.aux_offset(), r.data.data() + r.data.size()))
+				for (auto const &f : parse_aux(r.bytes() + r.aux_offset(), r.bytes() + r.size()))
 				{
 					uint16_t const key = tag_key(f.tag);
 					if ('N' == f.tag[0] && 'M' == f.tag[1] && aux_scalar_size(f.type) && 'A' != f.type && 'f' != f.type)
@@ -517,7 +610,7 @@ int main(int argc, char **argv)
 				if (!opt.rec_idx_tag.empty())				// :864-869: the same value for the (up to) four records of a chunk
 				{
 					uint64_t const chunk_begin = i & ~UINT64_C(3), chunk_end = std::min <uint64_t>(chunk_begin + 4, n);
-					uint64_t const xi = batch[chunk_end - 1].input_index - (chunk_end - chunk_begin) + 1;
+					uint64_t const xi = batch.input_index[chunk_end - 1] - (chunk_end - chunk_begin) + 1;
 					if (xi <= INT32_MAX) put_int(opt.rec_idx_tag, (int64_t) xi);
 				}
 				put_int(opt.rname_tag, ref_id);				// :872-877
@@ -538,9 +631,9 @@ int main(int argc, char **argv)
 				}
 
 				// -- the new record (:915-918)
-				bam_record w;
+				bam_record &w = S.w;
 				std::size_t const name_end = 32 + r.l_read_name();
-				w.data.assign(r.data.begin(), r.data.begin() + (std::ptrdiff_t) name_end);
+				w.data.assign(r.bytes(), r.bytes() + name_end);
 				w.set <int32_t>(0, (int32_t) ref_id_mapping[(std::size_t) ref_id]);
 				w.set <int32_t>(4, (int32_t) o_dst_pos[i]);
 				w.set <uint16_t>(12, (uint16_t) n_cig);
@@ -567,24 +660,43 @@ int main(int argc, char **argv)
 				writer.format(w, S.bytes);
 			}
 			});
+			write_job job;
+			job.slices.resize(n_slices);
 			for (std::size_t si = 0; si < n_slices; ++si)
 			{
 				slice_state &S = slices[si];
-				writer.write_formatted(S.bytes.data(), S.bytes.size());
+				job.slices[si].swap(S.bytes);
 				n_realigned_ranges += S.n_ranges;
 				realigned_ranges.insert(realigned_ranges.end(), S.ranges.begin(), S.ranges.end());
 				for (auto const &kv : S.removed) removed_tag_counts[kv.first] += kv.second;
 			}
+			tm.rewrite += since(t_stage); t_stage = now();
+			{
+				std::unique_lock <std::mutex> lock(wq_mutex);
+				wq_cv.wait(lock, [&]() { return wq_done || wq.size() < 2; });		// at most two finished batches wait for the file
+				if (writer_error) std::rethrow_exception(writer_error);
+				wq.push_back(std::move(job));
+			}
+			wq_cv.notify_all();
+			tm.wait_write += since(t_stage); t_stage = now();
 			if (prefetch.valid())
 			{
 				prefetch.get();		// rethrows what the reader threw
+				tm.wait_read += since(t_stage);
 				batch.swap(next_batch);
 			}
 			else
 				batch.clear();
 		}
+		{
+			std::lock_guard <std::mutex> lock(wq_mutex);
+			wq_done = true;
+		}
+		wq_cv.notify_all();
+		writer_thread.join();
+		if (writer_error) std::rethrow_exception(writer_error);
 		writer.close();
-		pvc3_context_destroy(ctx);
+		for (pvc3_context *ctx : contexts) pvc3_context_destroy(ctx);
 		pvc3_index_destroy(index);
 
 		// ---- finish (:1033-1073) ---------------------------------------------------------------------------------------------------------
@@ -608,6 +720,9 @@ int main(int argc, char **argv)
 		std::cerr << "\tFlags not matched:     " << st.flags_not_matched << '\n';
 		std::cerr << "\tSequence missing:      " << st.seq_missing << '\n';
 		std::cerr << "\tRe-aligned ranges:     " << n_realigned_ranges << '\n';
+		if (opt.debugging_output)
+			std::cerr << "\tStages (s): start-up " << t_startup << ", reader thread " << tm.read << ", main: waiting for it " << tm.wait_read << ", batch arrays " << tm.fill
+					  << ", GPU " << tm.gpu << ", rewriting " << tm.rewrite << ", waiting for the writer " << tm.wait_write << ", writer thread " << tm_write << '\n';
 		if (!removed_tag_counts.empty())
 		{
 			std::cerr << "\tRemoved tags:\n";

@@ -185,6 +185,37 @@ struct bam_record
 	uint8_t const *seq4() const { return data.data() + seq_offset(); }
 	uint8_t const *qual() const { return data.data() + qual_offset(); }
 	bool has_qual() const { return l_seq() && 0xff != qual()[0]; }
+	uint8_t const *bytes() const { return data.data(); }
+	std::size_t size() const { return data.size(); }
+};
+
+// The same record layout over bytes owned by somebody else (a batch's arena): no allocation per record.
+struct bam_view
+{
+	uint8_t const *p{};
+	std::size_t n{};
+
+	template <typename t_value> t_value get(std::size_t off) const { t_value v; std::memcpy(&v, p + off, sizeof(v)); return v; }
+	int32_t ref_id() const { return get <int32_t>(0); }
+	int32_t pos() const { return get <int32_t>(4); }
+	uint8_t l_read_name() const { return p[8]; }
+	uint8_t mapq() const { return p[9]; }
+	uint16_t n_cigar() const { return get <uint16_t>(12); }
+	uint16_t flag() const { return get <uint16_t>(14); }
+	uint32_t l_seq() const { return get <uint32_t>(16); }
+	int32_t next_ref_id() const { return get <int32_t>(20); }
+	int32_t next_pos() const { return get <int32_t>(24); }
+	int32_t tlen() const { return get <int32_t>(28); }
+	char const *read_name() const { return (char const *) p + 32; }
+	std::size_t cigar_offset() const { return 32 + l_read_name(); }
+	std::size_t seq_offset() const { return cigar_offset() + 4 * (std::size_t) n_cigar(); }
+	std::size_t qual_offset() const { return seq_offset() + (l_seq() + 1) / 2; }
+	std::size_t aux_offset() const { return qual_offset() + l_seq(); }
+	uint8_t const *seq4() const { return p + seq_offset(); }
+	uint8_t const *qual() const { return p + qual_offset(); }
+	bool has_qual() const { return l_seq() && 0xff != qual()[0]; }
+	uint8_t const *bytes() const { return p; }
+	std::size_t size() const { return n; }
 };
 
 constexpr char const CIGAR_CHARS[] = "MIDNSHP=X";
@@ -321,7 +352,8 @@ inline void format_aux_sam(std::string &out, aux_field const &f)
 }
 
 // SAM text of one record (no trailing newline).
-inline void format_sam_record(std::string &out, bam_record const &r, sam_header const &hdr)
+template <typename t_record>
+inline void format_sam_record(std::string &out, t_record const &r, sam_header const &hdr)
 {
 	auto ref_name = [&](int32_t id) -> std::string { return (id >= 0 && (std::size_t) id < hdr.refs.size()) ? hdr.refs[(std::size_t) id].name : std::string("*"); };
 	out.append(r.read_name());
@@ -333,7 +365,7 @@ inline void format_sam_record(std::string &out, bam_record const &r, sam_header 
 	if (0 == r.n_cigar()) out += '*';
 	for (uint16_t i = 0; i < r.n_cigar(); ++i)
 	{
-		uint32_t const c = r.get <uint32_t>(r.cigar_offset() + 4u * i);
+		uint32_t const c = r.template get <uint32_t>(r.cigar_offset() + 4u * i);
 		out += std::to_string(c >> 4); out += CIGAR_CHARS[(c & 0xf) < 9 ? (c & 0xf) : 0];
 	}
 	out += '\t';
@@ -350,7 +382,7 @@ inline void format_sam_record(std::string &out, bam_record const &r, sam_header 
 	out += '\t';
 	if (!r.has_qual()) out += '*';
 	else for (uint32_t i = 0; i < l; ++i) out += (char) (33 + r.qual()[i]);
-	for (auto const &f : parse_aux(r.data.data() + r.aux_offset(), r.data.data() + r.data.size()))
+	for (auto const &f : parse_aux(r.bytes() + r.aux_offset(), r.bytes() + r.size()))
 		format_aux_sam(out, f);
 }
 
@@ -556,6 +588,27 @@ public:
 		}
 		return false;
 	}
+
+	// The next record's bytes appended to `arena` (no allocation per record); returns false at the end of the input.
+	bool next_append(std::vector <uint8_t> &arena, bam_record &scratch)
+	{
+		if (m_is_bam)
+		{
+			int32_t block_size;
+			std::size_t const got = m_in.read(&block_size, 4);
+			if (0 == got) return false;
+			if (4 != got || block_size < 32) throw io_error("truncated BAM record");
+			std::size_t const at = arena.size();
+			arena.resize(at + (std::size_t) block_size);
+			if ((std::size_t) block_size != m_in.read(arena.data() + at, (std::size_t) block_size)) throw io_error("truncated BAM record");
+			bam_view const v{arena.data() + at, (std::size_t) block_size};
+			if (v.aux_offset() > v.size()) throw io_error("malformed BAM record: its name, CIGAR, SEQ and QUAL exceed block_size");
+			return true;
+		}
+		if (!next(scratch)) return false;
+		arena.insert(arena.end(), scratch.data.begin(), scratch.data.end());
+		return true;
+	}
 };
 
 
@@ -570,10 +623,10 @@ class alignment_writer
 public:
 	void set_threads(unsigned n) { m_out.set_threads(n); }
 
-	void open(char const *path, bool bam, sam_header const &hdr)
+	void open(char const *path, bool bam, sam_header const &hdr, int compression_level = 6)
 	{
 		m_is_bam = bam; m_header = &hdr;
-		m_out.open(path, bam);
+		m_out.open(path, bam, compression_level);
 		std::string const text = hdr.to_text();
 		if (bam)
 		{
@@ -608,13 +661,14 @@ public:
 	}
 
 	// Appends to `out` exactly the bytes write(r) would emit (callable from several threads at once).
-	void format(bam_record const &r, std::string &out) const
+	template <typename t_record>
+	void format(t_record const &r, std::string &out) const
 	{
 		if (m_is_bam)
 		{
-			int32_t const bs = (int32_t) r.data.size();
+			int32_t const bs = (int32_t) r.size();
 			out.append((char const *) &bs, 4);
-			out.append((char const *) r.data.data(), r.data.size());
+			out.append((char const *) r.bytes(), r.size());
 		}
 		else
 		{

@@ -89,20 +89,40 @@ def main():
 		if p.returncode:
 			sys.stderr.write(p.stderr.decode())
 			raise SystemExit("command failed: " + " ".join(cmd))
-		return time.perf_counter() - t
+		dt = time.perf_counter() - t
+		for line in p.stderr.decode().split("\n"):
+			if "Stages" in line:
+				print("   ", " ".join(cmd[-3:]), "|", line.strip())
+		return dt
 
 	t_io = run([project, "--io-only", "-a", "in.bam", "-b", "-o", "io.bam"])
-	full = [project, "-a", "in.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-b", "-o", "out.bam"]
+	full = [project, "-a", "in.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-b", "-o", "out.bam", "--debugging-output"]
 	run(full)		# first run pays the page cache and the GPU start-up
 	t_full = run(full)
 	t_small = run(full + ["--batch-size=131072"])
 	t_sam = run([project, "-a", "in.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-o", "out.sam"])
+	t_thr = {}
+	for thr in (16, 64, 128):
+		t_thr[thr] = run(full + ["--batch-size=262144", "--threads=%d" % thr])
+	t_l1 = run(full + ["--batch-size=262144", "--threads=64", "--compression-level=1"])
+	# the fixed part (index file, FASTA, GPU start-up, index upload): the same command on an input without records
+	with open("empty.bam", "wb") as f:
+		head_len = 12 + len(header) + sum(8 + len(nm) + 1 for nm in names)
+		f.write(bamio._bgzf_block(blob[:head_len]))
+		f.write(bamio._bgzf_block(b""))
+	t_empty = run([project, "-a", "empty.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-b", "-o", "empty_out.bam"])
 	print("records %d, genome %d bp x %d rows, in.bam %.1f MB" % (n, lens[0], genome.n_entries, in_size / 1e6))
 	print("index_msa --build-index: %.2f s" % t_index)
 	print("project_alignments --io-only BAM->BAM: %.2f s = %.2f M records/s" % (t_io, n / t_io / 1e6))
 	print("project_alignments BAM->BAM: %.2f s = %.2f M records/s" % (t_full, n / t_full / 1e6))
 	print("project_alignments BAM->BAM, batches of 131072 (reading overlaps the GPU and the writing): %.2f s = %.2f M records/s" % (t_small, n / t_small / 1e6))
 	print("project_alignments BAM->SAM: %.2f s = %.2f M records/s" % (t_sam, n / t_sam / 1e6))
+	for thr, t in t_thr.items():
+		print("project_alignments BAM->BAM, batches of 262144, %d threads: %.2f s = %.2f M records/s" % (thr, t, n / t / 1e6))
+	print("project_alignments BAM->BAM, batches of 262144, 64 threads, BGZF level 1: %.2f s = %.2f M records/s" % (t_l1, n / t_l1 / 1e6))
+	print("the same command on an input without records (index file, FASTA, GPU start-up): %.2f s" % t_empty)
+	best = min(min(t_thr.values()), t_l1)
+	print("best run without that fixed part: %.2f M records/s" % (n / max(1e-9, best - t_empty) / 1e6))
 
 
 if __name__ == "__main__":

@@ -31,7 +31,9 @@ def _key(deps, cmd):
 		h.update(os.path.basename(d).encode())
 		with open(d, "rb") as f:
 			h.update(f.read())
-	h.update("\0".join(cmd).encode())
+	# The tree lives at another path on the GPU box: the key must not depend on where the repository is.
+	root = os.path.abspath(os.path.join(HERE, ".."))
+	h.update("\0".join(os.path.normpath(c).replace(root, "<repo>") if os.path.isabs(c) or root in c else c for c in cmd).encode())
 	return h.hexdigest()
 
 
@@ -63,7 +65,8 @@ def _plan():
 		keys.append(key)
 	objs = [s[0] for s in steps]
 	cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
-	h = hashlib.sha256("\0".join(keys + cmd[1:]).encode()).hexdigest()
+	root = os.path.abspath(os.path.join(HERE, ".."))
+	h = hashlib.sha256("\0".join(keys + [os.path.normpath(c).replace(root, "<repo>") if root in c else c for c in cmd[1:]]).encode()).hexdigest()
 	return steps, (os.path.join(OBJ, "libpvc3_hip.so"), h, cmd)
 
 

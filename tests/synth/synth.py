@@ -171,21 +171,28 @@ def slice_batch(batch, lo, hi):
 	return out
 
 
-def reorder_batch(batch, order):
-	"""The batch with its records permuted by `order` (variable-length fields are re-packed)."""
+def reorder_batch(batch, order, chunk=2_000_000):
+	"""The batch with its records permuted by `order` (variable-length fields are re-packed, a few million records at a time so
+	that the index arrays of the gather stay small next to the data)."""
 	order = np.asarray(order, dtype=np.int64)
 	out = {}
 	for name in ("src_pos", "src_entry", "dst_entry", "flags", "l_seq", "mate_src_entry", "mate_dst_entry", "mate_pos"):
 		out[name] = batch[name][order]
+	n = order.size
 	for off, data in (("cigar_off", "cigar"), ("seq_off", "seq4"), ("qual_off", "qual")):
 		o = batch[off].astype(np.int64)
 		lens = (o[1:] - o[:-1])[order]
 		new_off = np.concatenate([[0], np.cumsum(lens)])
-		# gather: for every output element its source index
 		starts = o[:-1][order]
-		idx = np.repeat(starts - new_off[:-1], lens) + np.arange(new_off[-1])
+		src = batch[data]
+		dst = np.empty(int(new_off[-1]), dtype=src.dtype)
+		for a in range(0, n, chunk):
+			b = min(n, a + chunk)
+			# for every output element of the chunk its source index
+			idx = np.repeat(starts[a:b] - new_off[a:b], lens[a:b]) + np.arange(new_off[a], new_off[b])
+			dst[new_off[a]:new_off[b]] = src[idx]
 		out[off] = new_off.astype(np.uint64)
-		out[data] = batch[data][idx]
+		out[data] = dst
 	return out
 
 

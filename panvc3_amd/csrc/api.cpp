@@ -209,12 +209,16 @@ int ensure_scratch(pvc3_context *ctx)
 
 // The packed alignment kernels leave 32 bytes of trace per anti-diagonal step of a task; config C5 (5 % of 250-base reads over
 // a 20 - 60 base event) needs about 95 bytes per record of the batch.  Kept by the context and reused by every batch.
+constexpr uint64_t TRACE_FRONT = 16;
+
 int ensure_trace(pvc3_context *ctx, uint64_t words)
 {
 	if (ctx->trace && ctx->trace_cap >= words)
 		return PVC3_OK;
-	if (ctx->trace) { (void) hipFree(ctx->trace); ctx->workspace_bytes -= ctx->trace_cap * sizeof(uint32_t); ctx->trace = nullptr; ctx->trace_cap = 0; }
-	PVC3_TRY(dev_alloc(&ctx->trace, words, nullptr, &ctx->workspace_bytes));
+	if (ctx->trace) { (void) hipFree(ctx->trace - TRACE_FRONT); ctx->workspace_bytes -= (ctx->trace_cap + 2 * TRACE_FRONT) * sizeof(uint32_t); ctx->trace = nullptr; ctx->trace_cap = 0; }
+	uint32_t *p{};
+	PVC3_TRY(dev_alloc(&p, words + 2 * TRACE_FRONT, nullptr, &ctx->workspace_bytes));		// k_realign_traceback reads 16-byte windows that may begin before a task's first word
+	ctx->trace = p + TRACE_FRONT;
 	ctx->trace_cap = words;
 	return PVC3_OK;
 }
@@ -396,7 +400,7 @@ void pvc3_context_destroy(pvc3_context *ctx)
 	free_index_replica(ctx);
 	if (ctx->d_params) (void) hipFree(ctx->d_params);
 	if (ctx->scratch) (void) hipFree(ctx->scratch);
-	if (ctx->trace) (void) hipFree(ctx->trace);
+	if (ctx->trace) (void) hipFree(ctx->trace - 16);
 	for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
 	if (ctx->own_stream) (void) hipStreamDestroy(ctx->own_stream);
 	delete ctx;

@@ -661,15 +661,31 @@ __global__ __launch_bounds__(256) void k_realign_traceback(dev_batch_work const 
 			continue;		// the trace buffer overflowed: the batch is repeated
 		uint32_t const m = it->m, n = it->n;
 		uint64_t const ops_loc = it->ops_loc;
-		uint32_t const *trace = W.trace + trace_loc + (at % per_task) * width - 1;
+		uint32_t const *trace = W.trace + trace_loc + (at % per_task) * width - 1;		// + line (1-based) of the run
 		uint32_t *slot_end = W.arena + ops_loc + (m + n);
 		uint32_t n_out = 0, cur_op = 0xf, cur_cnt = 0;
 		uint32_t i = n, j = m, st = 0;		// st: 0 = M, 1 = V (up), 2 = H (left)
+		// A load per cell would make the walk a chain of some hundred dependent memory round trips.  The path moves to the same
+		// or the previous line and one or two steps back per cell, so a window of 4 lines x 16 steps (two 16-byte loads) serves
+		// the next half dozen cells from registers.
+		typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+		u32x4 win_a{0, 0, 0, 0}, win_b{0, 0, 0, 0};		// lines win_line - 3 .. win_line of row win_row and of row win_row - 1
+		uint32_t win_row = 0xFFFFFFF0u, win_line = 0;
 		while (i | j)
 		{
 			uint32_t const t = i + j - 2;
 			bool const inner = (0 != i) && (0 != j);
-			uint32_t const word = inner ? trace[(t >> 3) * 64 + (ref_lanes ? j : i)] : 0;
+			uint32_t const line = ref_lanes ? j : i, row = t >> 3;
+			if (inner && !((row == win_row || row + 1 == win_row) && line <= win_line && line + 3 >= win_line))
+			{
+				win_row = row; win_line = line;
+				uint32_t const *p = trace + (uint64_t) row * 64 + line - 3;		// the trace buffer has room in front of its first word
+				__builtin_memcpy(&win_a, p, 16);
+				if (row) __builtin_memcpy(&win_b, p - 64, 16);
+			}
+			u32x4 const wv = (row == win_row) ? win_a : win_b;
+			uint32_t const k = line + 3 - win_line;		// 0 .. 3 inside the window
+			uint32_t const word = (0 == k) ? wv.x : (1 == k) ? wv.y : (2 == k) ? wv.z : wv.w;
 			uint32_t const edge = (0 == i) ? (3u | ((1 == j) ? 8u : 0u)) : (2u | ((1 == i) ? 4u : 0u));	// first row: left, opened at column 1; first column: up
 			uint32_t const nibble = inner ? ((word >> (4 * (t & 7))) & 0xfu) : edge;
 			uint32_t const state = nibble & 3;
@@ -940,7 +956,16 @@ __global__ __launch_bounds__(256) void k_realign_splice(dev_batch_in const in, d
 			{
 				run_work const it = items[k];
 				uint32_t const *src = W.arena + it.ops_loc;
-				for (uint32_t y = 0; y < it.n_out; ++y) push(src[y]);
+				typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+				for (uint32_t y = 0; y < it.n_out; y += 4)		// four operations per load (the arena is padded)
+				{
+					u32x4 v;
+					__builtin_memcpy(&v, src + y, 16);
+					push(v.x);
+					if (y + 1 < it.n_out) push(v.y);
+					if (y + 2 < it.n_out) push(v.z);
+					if (y + 3 < it.n_out) push(v.w);
+				}
 				x = it.op_end;
 				++k;
 				next_first = (k < n_runs) ? items[k].op_first : 0xFFFFFFFFu;

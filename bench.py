@@ -132,9 +132,13 @@ def main():
 		raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
 	torch.cuda.set_device(local_rank)
 	device = torch.device("cuda", local_rank)
-	if world > 1:
+	# PVC3_BENCH_FORCE_DIST=1: go through RCCL (process group, barriers, the three all-reduces) with a single rank too, so that
+	# the N > 1 code path can be exercised on a one-GPU box (tests/test_multiproc_gpu.py).
+	use_dist = world > 1 or "1" == os.environ.get("PVC3_BENCH_FORCE_DIST")
+	if use_dist:
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-		dist.init_process_group(backend="nccl", device_id=device)		# "nccl" is RCCL on ROCm
+		os.environ.setdefault("MASTER_PORT", "29533")
+		dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)		# "nccl" is RCCL on ROCm
 
 	import panvc3_amd
 	from panvc3_amd import build as pvc3_build
@@ -183,7 +187,7 @@ def main():
 		del reads, genome, index
 
 	def barrier():
-		if world > 1:
+		if use_dist:
 			dist.barrier()
 
 	# ---- warm-up (also sizes the workspaces) -------------------------------------------------------------------------------
@@ -209,7 +213,7 @@ def main():
 	barrier()
 	elapsed = time.perf_counter() - t_begin
 	checksum = db.checksum(first_record=rank * n_local)
-	elapsed_max, n_total, checksum_total = reduce_job(dist if world > 1 else None, device, elapsed, n_local, checksum)
+	elapsed_max, n_total, checksum_total = reduce_job(dist if use_dist else None, device, elapsed, n_local, checksum, force=use_dist)
 
 	result = None
 	if rank == 0:
@@ -334,7 +338,7 @@ def main():
 
 	db.close()
 	ctx.close()
-	if world > 1:
+	if use_dist:
 		dist.barrier()
 		dist.destroy_process_group()
 

@@ -10,9 +10,10 @@ def shard_range(n_total, rank, world_size):
 	return n_total * rank // world_size, n_total * (rank + 1) // world_size
 
 
-def reduce_job(dist, device, elapsed_s, n_records, checksum=0):
-	"""(max elapsed over ranks, total records, wrapping sum of checksums); `dist` is torch.distributed or None."""
-	if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def reduce_job(dist, device, elapsed_s, n_records, checksum=0, force=False):
+	"""(max elapsed over ranks, total records, wrapping sum of checksums); `dist` is torch.distributed or None.  With `force`
+	the collectives run even in a group of one rank (to exercise the backend)."""
+	if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
 		return elapsed_s, n_records, checksum & 0xFFFFFFFFFFFFFFFF
 	import torch
 	t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)

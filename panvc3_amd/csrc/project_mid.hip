@@ -127,6 +127,26 @@ __device__ __forceinline__ uint64_t compare_columns(uint64_t mC, uint64_t Z, uin
 	return mX;
 }
 
+// The same result, 16 columns at a time: one 16-byte load and one 16-base compare per piece of a run.  Cheaper when the
+// compared columns of a step fall into several short runs (gap-dense MSAs: a gap run every twenty columns), dearer for one
+// long run; the kernel chooses per wave.
+__device__ __forceinline__ uint64_t compare_columns_pieces(uint64_t mC, uint64_t Z, uint64_t dz, uint32_t q, uint32_t r, uint8_t const *seq, uint8_t const *text4)
+{
+	uint64_t mX = 0, left = mC;
+	while (left)
+	{
+		uint32_t const c0 = ctz64(left);
+		uint64_t const ones = ~(left >> c0);
+		uint32_t const run = ones ? ctz64(ones) : 64;
+		uint32_t const L = (run < 16) ? run : 16;
+		uint32_t const qi = q + popc64(Z & low_mask(c0)), ri = r + popc64(dz & low_mask(c0));
+		uint32_t const mm = mismatch16(load_query16(seq, qi), load_text16(text4, ri)) & (uint32_t) low_mask(L);
+		mX |= (uint64_t) mm << c0;
+		left &= ~(low_mask(L) << c0);
+	}
+	return mX;
+}
+
 __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W)
 {
 	uint32_t const lane = lane_id();
@@ -157,6 +177,16 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 		lane_sink out;
 		out.init(my_tok);
 		uint32_t cols = 0, ref_span = 0, l_seq = 0;
+
+		// Which form of the compare: by the gap density of the rows these records lie on (more than one gap column in 16 in
+		// either row means runs of compared columns of some twenty bases), decided for the wave.
+		bool dense = false;
+		if (mine)
+		{
+			dev_entry const *sp = entries + in.src_entry[rec], *dp = entries + in.dst_entry[rec];
+			dense = (16 * (sp->n_cols - sp->n_zeros) > sp->n_cols) || (16 * (dp->n_cols - dp->n_zeros) > dp->n_cols);
+		}
+		bool const short_runs = 2 * popc64(ballot(dense)) > popc64(ballot(mine));
 
 		if (mine)
 		{
@@ -234,7 +264,7 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 							uint32_t const hi = 63 - (uint32_t) __builtin_clzll(mC);
 							uint32_t const max_ri = r + popc64(dz & low_mask(hi));
 							if (!D.text4 || max_ri >= D.text_len) { status = PVC3_ST_REF_RANGE; break; }
-							mX = compare_columns(mC, Z, dz, q, r, seq, D.text4);
+							mX = short_runs ? compare_columns_pieces(mC, Z, dz, q, r, seq, D.text4) : compare_columns(mC, Z, dz, q, r, seq, D.text4);
 							mE = mC & ~mX;
 						}
 						q += consumed;

@@ -18,6 +18,8 @@
 
 #include "bgzf.hpp"
 
+#include <zlib.h>
+
 namespace pvc3host {
 
 struct msa_sequence_entry
@@ -114,6 +116,160 @@ struct msa_index_file
 
 // Whole FASTA (plain, gzip or bgzip) into memory: name (up to the first white space) -> raw sequence bytes, case preserved
 // (the reference reads the same bytes through .gzi / .fai random access, libpanvc3/compressed_fasta_reader.cc:94-143).
+// ---- random access to the contigs of a (BGZF-compressed) FASTA through its .fai and .gzi indexes ----------------------------
+// Replaces panvc3::compressed_fasta_reader (libpanvc3/compressed_fasta_reader.cc:94-248): the reference opens
+// <fasta>.gzi and <fasta>.fai and inflates, per contig, from the BGZF block that holds the contig's first base.  Here the
+// blocks that cover a contig are inflated in parallel.  Line terminators are dropped; bytes are kept as they are (case matters
+// downstream, quirk Q3).
+struct fai_entry { std::string name; uint64_t length{}, offset{}, line_bases{}, line_width{}; };
+
+inline bool file_exists(std::string const &p) { FILE *f = std::fopen(p.c_str(), "rb"); if (f) std::fclose(f); return nullptr != f; }
+
+inline std::vector <fai_entry> read_fai(std::string const &path)
+{
+	std::vector <fai_entry> out;
+	byte_reader in;
+	in.open(path.c_str());
+	std::string line;
+	while (in.getline(line))
+	{
+		if (line.empty()) continue;
+		std::vector <std::string> f(1);
+		for (char c : line) { if ('\t' == c) f.emplace_back(); else f.back().push_back(c); }
+		if (f.size() < 5) throw io_error("malformed .fai line: " + line);
+		fai_entry e;
+		e.name = f[0]; e.length = std::stoull(f[1]); e.offset = std::stoull(f[2]); e.line_bases = std::stoull(f[3]); e.line_width = std::stoull(f[4]);
+		if (0 == e.line_bases || e.line_width < e.line_bases) throw io_error("malformed .fai line: " + line);
+		out.push_back(std::move(e));
+	}
+	return out;
+}
+
+// Bytes [begin, end) of the uncompressed FASTA.
+class fasta_random_access
+{
+	FILE *m_file{};
+	bool m_bgzf{};
+	std::vector <std::pair <uint64_t, uint64_t>> m_blocks;		// (compressed offset, uncompressed offset) of every BGZF block, ascending
+	unsigned m_threads{1};
+
+public:
+	fasta_random_access(std::string const &path, unsigned threads): m_threads(threads ? threads : 1)
+	{
+		m_file = std::fopen(path.c_str(), "rb");
+		if (!m_file) throw io_error("unable to open " + path);
+		uint8_t magic[4]{};
+		std::size_t const got = std::fread(magic, 1, 4, m_file);
+		m_bgzf = (4 == got && 0x1f == magic[0] && 0x8b == magic[1] && 8 == magic[2] && (magic[3] & 4));
+		if (4 == got && 0x1f == magic[0] && 0x8b == magic[1] && !m_bgzf) throw io_error("plain gzip (not BGZF) cannot be read at random: " + path);
+		if (m_bgzf)
+		{
+			// <fasta>.gzi: u64 n, then n pairs (compressed offset, uncompressed offset) of the blocks after the first
+			FILE *g = std::fopen((path + ".gzi").c_str(), "rb");
+			if (!g) throw io_error("unable to open " + path + ".gzi");
+			uint64_t n = 0;
+			if (1 != std::fread(&n, 8, 1, g)) { std::fclose(g); throw io_error("truncated .gzi"); }
+			m_blocks.assign(1, {0, 0});
+			for (uint64_t i = 0; i < n; ++i)
+			{
+				uint64_t pr[2];
+				if (2 != std::fread(pr, 8, 2, g)) { std::fclose(g); throw io_error("truncated .gzi"); }
+				m_blocks.emplace_back(pr[0], pr[1]);
+			}
+			std::fclose(g);
+		}
+	}
+	fasta_random_access(fasta_random_access const &) = delete;
+	~fasta_random_access() { if (m_file) std::fclose(m_file); }
+
+	void read(uint64_t begin, uint64_t end, std::vector <char> &dst)
+	{
+		dst.clear();
+		if (end <= begin) return;
+		if (!m_bgzf)
+		{
+			dst.resize(end - begin);
+			if (0 != fseeko(m_file, (off_t) begin, SEEK_SET) || dst.size() != std::fread(dst.data(), 1, dst.size(), m_file)) throw io_error("FASTA shorter than its .fai says");
+			return;
+		}
+		// blocks b0 .. b1 cover [begin, end)
+		auto const cmp = [](uint64_t v, std::pair <uint64_t, uint64_t> const &b) { return v < b.second; };
+		std::size_t const b0 = (std::size_t) (std::upper_bound(m_blocks.begin(), m_blocks.end(), begin, cmp) - m_blocks.begin()) - 1;
+		std::size_t b1 = (std::size_t) (std::upper_bound(m_blocks.begin(), m_blocks.end(), end - 1, cmp) - m_blocks.begin()) - 1;
+		uint64_t const c_begin = m_blocks[b0].first;
+		std::vector <uint8_t> comp;
+		if (b1 + 1 < m_blocks.size()) comp.resize(m_blocks[b1 + 1].first - c_begin);
+		else
+		{
+			if (0 != fseeko(m_file, 0, SEEK_END)) throw io_error("seek error");
+			comp.resize((uint64_t) ftello(m_file) - c_begin);
+		}
+		if (0 != fseeko(m_file, (off_t) c_begin, SEEK_SET) || comp.size() != std::fread(comp.data(), 1, comp.size(), m_file)) throw io_error("read error");
+		std::size_t const nb = b1 - b0 + 1;
+		std::vector <std::vector <uint8_t>> plain(nb);
+		parallel_for(nb, m_threads, [&](std::size_t i) {
+			uint8_t const *p = comp.data() + (m_blocks[b0 + i].first - c_begin);
+			std::size_t const avail = comp.size() - (m_blocks[b0 + i].first - c_begin);
+			if (avail < 18 + 8) throw io_error("corrupt BGZF block");
+			std::size_t const xlen = p[10] | ((std::size_t) p[11] << 8);
+			std::size_t const bsize = (std::size_t) (p[16] | ((std::size_t) p[17] << 8)) + 1;		// bgzip writes the BC field first
+			if (bsize > avail || bsize < 12 + xlen + 8) throw io_error("corrupt BGZF block");
+			uint32_t isize; std::memcpy(&isize, p + bsize - 4, 4);
+			plain[i].resize(isize);
+			z_stream zs{};
+			if (Z_OK != inflateInit2(&zs, -15)) throw io_error("inflateInit2 failed");
+			zs.next_in = const_cast <uint8_t *>(p + 12 + xlen); zs.avail_in = (uInt) (bsize - 12 - xlen - 8);
+			zs.next_out = plain[i].data(); zs.avail_out = (uInt) isize;
+			int const rc = isize ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+			inflateEnd(&zs);
+			if (Z_STREAM_END != rc) throw io_error("corrupt BGZF block");
+		});
+		dst.reserve(end - begin);
+		for (std::size_t i = 0; i < nb; ++i)
+		{
+			uint64_t const u0 = m_blocks[b0 + i].second;
+			uint64_t const lo = std::max(begin, u0), hi = std::min <uint64_t>(end, u0 + plain[i].size());
+			if (lo < hi) dst.insert(dst.end(), plain[i].begin() + (std::ptrdiff_t) (lo - u0), plain[i].begin() + (std::ptrdiff_t) (hi - u0));
+		}
+		if (dst.size() != end - begin) throw io_error("FASTA shorter than its .fai says");
+	}
+};
+
+// The named contigs only, through <path>.fai (+ <path>.gzi for BGZF); returns false if there is no .fai (or no .gzi next to a
+// BGZF file), in which case the caller reads the file as a whole.
+inline bool read_fasta_contigs(char const *path, std::vector <std::string> const &names, unsigned threads, std::vector <std::pair <std::string, std::vector <char>>> &out)
+{
+	std::string const p(path);
+	if (!file_exists(p + ".fai")) return false;
+	{
+		FILE *f = std::fopen(path, "rb");
+		if (!f) throw io_error("unable to open " + p);
+		uint8_t m[2]{}; std::size_t const got = std::fread(m, 1, 2, f); std::fclose(f);
+		if (2 == got && 0x1f == m[0] && 0x8b == m[1] && !file_exists(p + ".gzi")) return false;
+	}
+	auto const fai = read_fai(p + ".fai");
+	fasta_random_access ra(p, threads);
+	std::vector <char> raw;
+	for (auto const &name : names)
+	{
+		auto const it = std::find_if(fai.begin(), fai.end(), [&](fai_entry const &e) { return e.name == name; });
+		if (fai.end() == it) continue;		// the caller reports what is missing
+		uint64_t const full_lines = it->length / it->line_bases, rest = it->length % it->line_bases;
+		uint64_t const bytes = full_lines * it->line_width + rest;
+		ra.read(it->offset, it->offset + bytes, raw);
+		std::vector <char> seq;
+		seq.reserve(it->length);
+		for (uint64_t at = 0; at < raw.size() && seq.size() < it->length; at += it->line_width)
+		{
+			uint64_t const n = std::min <uint64_t>(it->line_bases, std::min <uint64_t>(raw.size() - at, it->length - seq.size()));
+			seq.insert(seq.end(), raw.begin() + (std::ptrdiff_t) at, raw.begin() + (std::ptrdiff_t) (at + n));
+		}
+		if (seq.size() != it->length) throw io_error("contig " + name + " is shorter than its .fai entry says");
+		out.emplace_back(name, std::move(seq));
+	}
+	return true;
+}
+
 inline void read_fasta(char const *path, std::vector <std::pair <std::string, std::vector <char>>> &out)
 {
 	byte_reader in;

@@ -58,6 +58,7 @@ struct options
 	std::vector <std::string> preserve_tags;
 	std::string rname_tag{"XR"}, pos_tag{"XP"}, rnext_tag{"YR"}, pnext_tag{"YP"}, query_ranges_tag{"XB"}, ref_ranges_tag{"YB"}, rec_idx_tag;
 	int gap_open{0}, gap_ext{-1}, compression_level{6};
+	long status_interval{5};			// --status-output-interval, minutes; 0 disables
 	std::vector <int> devices{0};		// --device / --devices: batches go to the GPUs in turn, output stays in input order
 	uint64_t batch_size{UINT64_C(1) << 18};		// records per GPU batch: small enough for reading, projecting and writing of consecutive batches to overlap
 	unsigned threads{default_io_threads()};		// BGZF inflate / deflate
@@ -76,7 +77,7 @@ void usage()
 		"  -u, --reference-order-input=filename Read output reference order from the given path, one identifier per line\n"
 		"  -o, --output-path=path               Output path (stdout by default)\n"
 		"  -b, --output-bam                     Output BAM instead of SAM\n"
-		"      --status-output-interval=SHORT   accepted, ignored\n"
+		"      --status-output-interval=SHORT   Status output interval in minutes, zero to disable (default 5)\n"
 		"  -l, --output-realigned-ranges=filename  Output the re-aligned ranges as TSV to the given path\n"
 		"  -t, --preserve-tag=tag               Preserve the given SAM tag (may be repeated)\n"
 		"      --original-rname-tag=XR --original-pos-tag=XP --original-rnext-tag=YR --original-pnext-tag=YP\n"
@@ -218,7 +219,7 @@ int main(int argc, char **argv)
 			case 'u': opt.ref_order = optarg; break;
 			case 'o': opt.output_path = optarg; break;
 			case 'b': opt.output_bam = true; break;
-			case 1000: break;
+			case 1000: opt.status_interval = std::atol(optarg); break;
 			case 'l': opt.realigned_ranges = optarg; break;
 			case 1001: opt.keep_duplicate_ranges = true; break;
 			case 't': opt.preserve_tags.emplace_back(optarg); break;
@@ -336,8 +337,15 @@ int main(int argc, char **argv)
 			src_entries[i] = entry_for(chr_id, seq_id);
 		}
 		{
+			// The destination contigs only, through <reference>.fai (+ .gzi) when the indexes are there
+			// (libpanvc3/compressed_fasta_reader.cc:163-248 requires them); the whole file otherwise.
 			std::vector <std::pair <std::string, std::vector <char>>> fasta;
-			read_fasta(opt.reference, fasta);
+			std::vector <std::string> wanted;
+			for (std::size_t o = 0; o < out_header.refs.size(); ++o)
+				if (UINT32_MAX != dst_entries[o]) wanted.push_back(out_header.refs[o].name);
+			bool const indexed = read_fasta_contigs(opt.reference, wanted, opt.threads, fasta);
+			if (!indexed) read_fasta(opt.reference, fasta);
+			if (opt.debugging_output) std::cerr << "Reference: " << fasta.size() << " sequences read " << (indexed ? "through the .fai index" : "from the whole file") << ".\n";
 			for (std::size_t o = 0; o < out_header.refs.size(); ++o)
 			{
 				if (UINT32_MAX == dst_entries[o]) continue;
@@ -402,6 +410,8 @@ int main(int argc, char **argv)
 		struct stage_times { double read{}, wait_read{}, fill{}, gpu{}, rewrite{}, wait_write{}, write{}; } tm;
 		auto now = []() { return std::chrono::steady_clock::now(); };
 		auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration <double>(std::chrono::steady_clock::now() - t0).count(); };
+		uint64_t records_done = 0;
+		double next_status = 60.0 * (double) opt.status_interval;
 		batch_store batch, next_batch;
 		t_startup = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
 		uint64_t input_index = 0, batch_no = 0;
@@ -459,6 +469,19 @@ int main(int argc, char **argv)
 			struct join_prefetch { std::future <void> &f; ~join_prefetch() { if (f.valid()) f.wait(); } } joiner{prefetch};
 			uint64_t const n = batch.size();
 			pvc3_context *ctx = contexts[batch_no++ % contexts.size()];
+			// The reference's periodic status line (project_alignments.cc:446-481): time spent, records processed, µs per record.
+			if (opt.status_interval > 0)
+			{
+				double const running = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+				if (running >= next_status)
+				{
+					std::cerr << "Time spent processing: " << (uint64_t) running << " s; processed " << records_done << " records";
+					if (records_done) std::cerr << " (in " << (running * 1e6 / (double) records_done) << " µs / record)";
+					std::cerr << ".\n";
+					next_status = running + 60.0 * (double) opt.status_interval;
+				}
+			}
+			records_done += n;
 			auto t_stage = now();
 
 			// SoA batch (include/pvc3.h): offsets first (one cheap pass), then the slices are filled by all threads.

@@ -329,6 +329,31 @@ def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_m
 	assert open(tmp_path / "ranges.tsv").read() == "Location\tLength\n" + "".join("%d\t%d\n" % r for r in ranges)
 	assert b"Matched reads:" in p.stderr
 
+	# A BGZF-compressed multi-contig FASTA with its .gzi and .fai (what the reference requires: compressed_fasta_reader.cc:163-248):
+	# only the destination contig is read, through the indexes; the output does not change.  Also the uncompressed file + .fai.
+	decoy = "".join("ACGT"[x] for x in np.random.default_rng(1).integers(0, 4, size=30011))
+	fasta_text, fai_lines = "", []
+	for name, seq, width in (("decoy1", decoy, 61), ("test", ref_text, 70), ("decoy2", decoy[:999], 50)):
+		fasta_text += ">%s some description\n" % name
+		fai_lines.append("%s\t%d\t%d\t%d\t%d\n" % (name, len(seq), len(fasta_text), width, width + 1))
+		fasta_text += "".join(seq[i:i + width] + "\n" for i in range(0, len(seq), width))
+	raw = fasta_text.encode()
+	(tmp_path / "multi.fa").write_bytes(raw)
+	(tmp_path / "multi.fa.fai").write_text("".join(fai_lines))
+	blocks, gzi, c_off = [], [], 0
+	for u_off in range(0, len(raw), 4093):
+		if u_off: gzi.append((c_off, u_off))
+		blk = bamio._bgzf_block(raw[u_off:u_off + 4093])
+		blocks.append(blk); c_off += len(blk)
+	blocks.append(bamio._bgzf_block(b""))
+	(tmp_path / "multi.fa.gz").write_bytes(b"".join(blocks))
+	(tmp_path / "multi.fa.gz.gzi").write_bytes(struct.pack("<Q", len(gzi)) + b"".join(struct.pack("<QQ", a, b) for a, b in gzi))
+	(tmp_path / "multi.fa.gz.fai").write_text("".join(fai_lines))
+	for ref in ("multi.fa.gz", "multi.fa"):
+		p2 = _run([c.replace("--reference=genome.fa.gz", "--reference=" + ref) for c in cmd] + ["--debugging-output"], cwd=tmp_path)
+		assert [l for l in p2.stdout.decode().split("\n") if l and not l.startswith("@")] == expect
+		assert b"1 sequences read through the .fai index" in p2.stderr
+
 	# SAM in (gz), BAM out, one big batch: same records
 	subprocess.check_call(["gzip", "-k", "alignments.sam"], cwd=tmp_path)
 	_run([tools["panvc3_project_alignments"], "-a", "alignments.sam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-u", "order.txt", "--record-index-tag=XI", "-t", "XS", "-t", "YS", "-b", "-o", "out.bam"], cwd=tmp_path)

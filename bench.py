@@ -170,11 +170,11 @@ def main():
 	index = panvc3_amd.Index()
 	genome.fill_index(index)
 	ctx = panvc3_amd.Context(local_rank)
-	ctx.upload_index(index)
-	ctx.set_timing(True)
 	for kv in args.option:
 		k, v = kv.split("=", 1)
 		ctx.set_option(k, int(v))
+	ctx.upload_index(index)
+	ctx.set_timing(True)
 	t2 = time.time()
 	db = panvc3_amd.DeviceBatch(ctx, batch)
 	index_bytes, _ = ctx.hbm_bytes()

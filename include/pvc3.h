@@ -175,7 +175,8 @@ PVC3_API int pvc3_index_set_reference(pvc3_index *idx, uint32_t entry, char cons
 PVC3_API int pvc3_index_entry_count(pvc3_index const *idx, uint32_t *count);
 PVC3_API int pvc3_index_entry_info(pvc3_index const *idx, uint32_t entry, uint64_t *n_cols, uint64_t *n_non_gap);
 /* Host view of the HBM layout of one entry (for inspection and host-logic tests):
- * blocks = n_blocks x 8 uint64 {non-gap columns before the block, 7 x 64 gap bits}; sel[j] = column of non-gap #(4096 j). */
+ * blocks = n_blocks x 8 uint64 {bits 0-31 non-gap columns before the block, bits 32-40 / 41-49 / 50-58 non-gap columns in the
+ * block's data words 0 / 0..2 / 0..4; then 7 x 64 gap bits}; sel[j] = column of non-gap #(4096 j). */
 PVC3_API int pvc3_index_entry_layout(pvc3_index const *idx, uint32_t entry, uint64_t const **blocks, uint64_t *n_blocks, uint32_t const **sel, uint64_t *n_sel);
 
 /* ---- device context ------------------------------------------------------------------------------------------------ */

@@ -63,6 +63,7 @@ struct pvc3_context
 	uint32_t fast_path{1};
 	uint32_t mid_path{1};
 	uint32_t packed_dp{1};
+	uint32_t paired_blocks{1};			// upload_index: paired copies of the gap bit-vector blocks (dev_entry::paired)
 	uint8_t *scratch{};
 	uint64_t scratch_alloc{};
 	uint32_t *trace{};					// trace words of the packed alignment kernels
@@ -438,6 +439,7 @@ int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value)
 	else if ("fast_path" == k) ctx->fast_path = (0 != value);
 	else if ("mid_path" == k) ctx->mid_path = (0 != value);
 	else if ("packed_dp" == k) ctx->packed_dp = (0 != value);
+	else if ("paired_blocks" == k) ctx->paired_blocks = (0 != value);		// takes effect at the next pvc3_context_upload_index
 	else return set_error(PVC3_E_INVALID, "pvc3_context_set_option: unknown option %s", key);
 	return PVC3_OK;
 }
@@ -486,6 +488,35 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 		d.n_zeros = (uint32_t) e.n_zeros;
 		d.text_len = (uint32_t) e.text.size();
 		d.n_blocks = (uint32_t) e.n_blocks;
+		d.paired = nullptr;
+		d.partner = NO_PARTNER;
+		d.pad = 0;
+		// Partner: the nearest other entry of the same MSA (same number of columns) that carries a text, i.e. the destination of
+		// the projections from this entry.  Any choice is correct: the copy is used only for records whose destination it is.
+		if (ctx->paired_blocks)
+		{
+			size_t best = idx->entries.size();
+			for (size_t j = 0; j < idx->entries.size(); ++j)
+			{
+				host_entry const &o = idx->entries[j];
+				if (j == i || o.text.empty() || o.n_cols != e.n_cols) continue;
+				size_t const dist = (j > i) ? (j - i) : (i - j);
+				if (best == idx->entries.size() || dist < ((best > i) ? (best - i) : (i - best))) best = j;
+			}
+			if (best < idx->entries.size())
+			{
+				host_entry const &o = idx->entries[best];
+				std::vector <uint64_t> both(2 * e.blocks.size());
+				for (size_t b = 0; b < e.blocks.size() / BLOCK_WORDS; ++b)
+				{
+					std::memcpy(&both[2 * BLOCK_WORDS * b], &e.blocks[BLOCK_WORDS * b], BLOCK_WORDS * sizeof(uint64_t));
+					std::memcpy(&both[2 * BLOCK_WORDS * b + BLOCK_WORDS], &o.blocks[BLOCK_WORDS * b], BLOCK_WORDS * sizeof(uint64_t));
+				}
+				PVC3_TRY(dev_upload(&d.paired, both.data(), both.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
+				HIP_TRY(hipStreamSynchronize(ctx->stream));		// `both` is pageable and leaves scope
+				d.partner = (uint32_t) best;
+			}
+		}
 	}
 	dev_entry const *d_table{};
 	PVC3_TRY(dev_upload(&d_table, table.data(), table.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
@@ -883,6 +914,15 @@ int pvc3_dbatch_checksum(pvc3_context *ctx, pvc3_dbatch *b, uint64_t first_recor
 	*checksum = v;
 	return PVC3_OK;
 }
+
+#ifdef PVC3_FAST_STAMPS
+// Diagnostic build only (tools/fast_phase_cycles.py): the per-wave phase cycles k_project_fast left at the end of the trace buffer.
+PVC3_API int pvc3_debug_fast_stamps(pvc3_dbatch *b, unsigned long long *out, uint32_t n_waves)
+{
+	HIP_TRY(hipMemcpy(out, (unsigned long long *) (b->work.trace + b->work.trace_cap) - 16 * (uint64_t) n_waves, 16 * (uint64_t) n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return PVC3_OK;
+}
+#endif
 
 #ifdef PVC3_DP_STAMPS
 // Diagnostic build only (tools/dp_phase_cycles.py): the cycle sums the alignment kernels left in the wave statistics area.

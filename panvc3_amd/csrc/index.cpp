@@ -21,14 +21,16 @@ static void finish_entry(host_entry &e)
 		for (uint32_t w = 1; w < BLOCK_WORDS; ++w)
 			e.blocks[b * BLOCK_WORDS + w] = ~UINT64_C(0);
 
-	// Rank words + select samples in one pass.
+	// Rank words (with the in-block directory, see pvc3_internal.hpp) + select samples in one pass.
 	uint64_t zeros = 0;
 	e.sel.clear();
 	for (uint64_t b = 0; b < total_blocks; ++b)
 	{
-		e.blocks[b * BLOCK_WORDS] = zeros;
+		uint64_t const zeros_before_block = zeros;
+		uint64_t dir = 0;
 		for (uint32_t w = 0; w < BLOCK_DATA_WORDS; ++w)
 		{
+			if (1 == (w & 1)) dir |= (zeros - zeros_before_block) << (DIR_SHIFT + DIR_BITS * (w >> 1));		// before pairs 1, 2, 3
 			uint64_t z = ~e.blocks[b * BLOCK_WORDS + 1 + w];
 			uint32_t const cnt = (uint32_t) __builtin_popcountll(z);
 			// Samples falling into this word: zero numbers k with k % 64 == 0 and zeros <= k < zeros + cnt.
@@ -43,6 +45,7 @@ static void finish_entry(host_entry &e)
 			}
 			zeros += cnt;
 		}
+		e.blocks[b * BLOCK_WORDS] = zeros_before_block | dir;
 	}
 	e.n_zeros = zeros;
 	e.sel.push_back((uint32_t) e.n_cols);	// sentinel so that sel[n_zeros / SELECT_SAMPLE] is always readable

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_project_positions(
 	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
 	{
 		uint32_t const s = src_entry[i], d = dst_entry[i];
-		out[i] = (s < n_entries && d < n_entries) ? thread_project_position(entries[s], entries[d], pos[i]) : PVC3_NO_MATE;
+		out[i] = (s < n_entries && d < n_entries) ? thread_project_position(entries[s], entries[d], d, pos[i]) : PVC3_NO_MATE;
 	}
 }
 

@@ -27,6 +27,10 @@ constexpr uint32_t FAST_MAX_BASES = 256;
 constexpr uint32_t FAST_WORDS = FAST_MAX_BASES / 32;
 constexpr uint32_t LDS_ENTRIES = 256;
 constexpr uint32_t STAGE_TOKENS = 64 * FAST_WORDS;		// uint32 in a wave's LDS area (mismatch words, then output operations)
+#ifndef PVC3_FAST_PASSES
+#define PVC3_FAST_PASSES 4
+#endif
+constexpr uint32_t FAST_PASSES = PVC3_FAST_PASSES;	// passes of the cooperative compare whose loads are issued together
 #ifndef PVC3_FAST_MIN_WAVES
 #define PVC3_FAST_MIN_WAVES 4
 #endif
@@ -62,6 +66,15 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 	return rfl(v);
 }
 
+// Diagnostic build (tools/fast_phase_cycles.py): s_memtime stamps at the phase boundaries of a group, every stamp behind a
+// full wait so that a phase is charged with the latency of what it loads.  Sums per wave at the end of the trace buffer.
+#ifdef PVC3_FAST_STAMPS
+#define FAST_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); uint64_t const t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+	stamp_acc[k] += t_ - stamp_prev; stamp_prev = t_; } while (0)
+#else
+#define FAST_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W, uint32_t use_fast_path)
 {
 	uint32_t const lane = lane_id();
@@ -93,6 +106,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	bool const batch_bad = 0xFFFFFFFFu != rfl(*W.first_bad);
 	uint64_t acc_bitvec = 0, acc_ref = 0, acc_bytes = 0;
 
+#ifdef PVC3_FAST_STAMPS
+	uint64_t stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	uint64_t stamp_prev = __builtin_amdgcn_s_memtime();
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 	for (uint64_t g = g_begin; g < g_end; ++g)
 	{
 		uint64_t const rec = g * 64 + lane;
@@ -113,13 +131,15 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		uint32_t const mate_de = has_mate ? in.mate_dst_entry[rl] : 0;
 		uint32_t const mate_pos = has_mate ? in.mate_pos[rl] : 0;
 
+		FAST_STAMP(0);		// descriptors
 		bool const e_ok = (src_e < n_entries) && (dst_e < n_entries);
 		dev_entry const S = get_entry(e_ok ? src_e : 0);
 		dev_entry const D = get_entry(e_ok ? dst_e : 0);
-		uint64_t const *s_blocks = S.blocks;
+		row_pair const rows = rows_of(S, D, dst_e);
+		uint64_t const *s_blocks = rows.src, *d_blocks = rows.dst;
+		uint32_t const stride = rows.src_stride;		// the two strides are equal
 		uint32_t const *s_sel = S.sel;
 		uint32_t const s_zeros = S.n_zeros, s_cols = S.n_cols;
-		uint64_t const *d_blocks = D.blocks;
 		uint8_t const *d_text4 = D.text4;
 		uint32_t const d_text_len = D.text_len, d_cols = D.n_cols;
 
@@ -154,6 +174,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		for (uint32_t i = 4; i < n_cigar; ++i)
 			step(ops[i]);
 
+		FAST_STAMP(1);		// entries, CIGAR
 		uint32_t status = PVC3_ST_OK;
 		if (batch_bad) status = PVC3_ST_QUERY_RANGE;
 		else if (!e_ok) status = PVC3_ST_SRC_RANGE;
@@ -169,26 +190,27 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		uint32_t const phase = lead_q & 1;
 		if (ok)
 		{
-			block_regs Sc;
-			uint32_t sel_blk;
-			col = thread_select0(s_blocks, s_sel, src_pos, Sc, sel_blk);
+			// One select sample, then four probes (word 0 + one 16-byte pair of a block, wave.hpp) at the sample's guess for the
+			// start column and for the end column: both rows, all issued together.  A probe is fetched again when the guess
+			// did not hold (a gap column between the sample and the record).
+			uint32_t const guess = select_guess(s_sel, src_pos);
+			FAST_STAMP(2);		// select sample
+			col_pos const g0 = split_col(guess), g1 = split_col(guess + ref_consumed);
+			dir_probe const ps0 = dir_load(s_blocks, stride, g0.blk, pair_of(g0));
+			dir_probe const pd0 = dir_load(d_blocks, stride, g0.blk, pair_of(g0));
+			dir_probe const ps1 = dir_load(s_blocks, stride, g1.blk, pair_of(g1));
+			dir_probe const pd1 = dir_load(d_blocks, stride, g1.blk, pair_of(g1));
+			col = dir_select0(s_blocks, stride, src_pos, ps0);
 			col_pos const p0 = split_col(col);
 			col_pos const p1 = split_col(col + ref_consumed);
-			block_regs const Dc = load_block(d_blocks, p0.blk);
-			// The end column usually shares the block of the start column: reuse the registers, load only otherwise.
-			block_regs De = Dc, Se = Sc;
-			if (p1.blk != p0.blk)
-			{
-				De = load_block(d_blocks, p1.blk);
-				Se = load_block(s_blocks, p1.blk);
-			}
-			r0 = block_rank(Dc, p0.w, p0.bit);
+			r0 = dir_rank(d_blocks, stride, pd0, p0);
 			// No gap column in either row over the span <=> both ranks advance by exactly ref_consumed.
-			bool const gapless = (block_rank(Se, p1.w, p1.bit) == src_pos + ref_consumed) && (block_rank(De, p1.w, p1.bit) == r0 + ref_consumed);
+			bool const gapless = (dir_rank(s_blocks, stride, ps1, p1) == src_pos + ref_consumed) && (dir_rank(d_blocks, stride, pd1, p1) == r0 + ref_consumed);
 			bool const simple = (2 == shape || 3 == shape);
 			fast = use_fast_path && simple && gapless && (ref_consumed + phase < FAST_MAX_BASES) && d_text4 && ((uint64_t) r0 + ref_consumed <= d_text_len);
 		}
 
+		FAST_STAMP(3);		// probes, select, ranks
 		// ---- mate (project_alignments.cc:897-901) -----------------------------------------------------------------------------------
 		// project_position is a pure function of (entries, position).  When the mate is the neighbouring record of the batch
 		// (pairs stored back to back) its projected position has just been computed by the neighbouring lane.
@@ -202,15 +224,20 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				mate = n_r0;
 			else if (has_mate && mate_se < n_entries && mate_de < n_entries)
 			{
-				mate = thread_project_position(get_entry(mate_se), get_entry(mate_de), mate_pos);
+				mate = thread_project_position(get_entry(mate_se), get_entry(mate_de), mate_de, mate_pos);
 				acc_bytes += 4 + 64 + 64;		// select sample, one source block, one destination block
 			}
 		}
 
+		FAST_STAMP(4);		// mate
 		// ---- fast path ------------------------------------------------------------------------------------------------------------------
 		uint32_t f_n_out = 0;
 		uint64_t f_loc = 0;
+#ifdef PVC3_ABL_NO_COMPARE
+		if (false)
+#else
 		if (ballot(fast))
+#endif
 		{
 			uint32_t const R = fast ? ref_consumed : 0;
 			// Work in query-nibble positions u = t + phase counted from a byte boundary of SEQ, so that 32 positions are exactly
@@ -264,20 +291,30 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 					}
 					if (act) my_mask[rr * FAST_WORDS + w] = m;
 				};
-				for (uint32_t base = 0; base < 64; base += 2 * per)
+				// FAST_PASSES passes at a time: all their loads are in flight before the first word is compared (a pass per round
+				// trip made the compare three dependent round trips for 150-base reads, a quarter of the kernel's time).
+				for (uint32_t base = 0; base < 64; base += FAST_PASSES * per)
 				{
-					uint32_t const ra = base + sr, rb = base + per + sr;
-					bool const act_a = (sr < per) & (ra < 64), act_b = (sr < per) & (rb < 64);
-					u64x2 qa{}, qb{};
-					u32x4 ta{}, tb{};
-					uint32_t left_a, left_b, odd_a, odd_b;
-					fetch(ra, act_a, qa, ta, left_a, odd_a);
-					fetch(rb, act_b, qb, tb, left_b, odd_b);
-					finish(ra, act_a, qa, ta, left_a, odd_a);
-					finish(rb, act_b, qb, tb, left_b, odd_b);
+					u64x2 qv[FAST_PASSES];
+					u32x4 tv[FAST_PASSES];
+					uint32_t left_v[FAST_PASSES], odd_v[FAST_PASSES];
+#pragma unroll
+					for (uint32_t k = 0; k < FAST_PASSES; ++k)
+					{
+						uint32_t const rr = base + k * per + sr;
+						qv[k] = u64x2{0, 0}; tv[k] = u32x4{0, 0, 0, 0};
+						fetch(rr, (sr < per) & (rr < 64), qv[k], tv[k], left_v[k], odd_v[k]);
+					}
+#pragma unroll
+					for (uint32_t k = 0; k < FAST_PASSES; ++k)
+					{
+						uint32_t const rr = base + k * per + sr;
+						finish(rr, (sr < per) & (rr < 64), qv[k], tv[k], left_v[k], odd_v[k]);
+					}
 				}
 			}
 			wave_lds_sync();
+			FAST_STAMP(5);		// compare
 			uint32_t mu[FAST_WORDS + 1];
 			{
 				typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
@@ -320,6 +357,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			// copy by the whole wave) when the group's operations fit there, directly otherwise.
 			bool const staged = total <= STAGE_TOKENS;
 			wave_lds_sync();		// the mismatch words in this LDS area have been read
+			FAST_STAMP(6);		// run count, scan, arena
 			auto emit = [&](auto put) {
 				uint32_t k = 0;
 				if (lead) put(k++, lead);
@@ -360,6 +398,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				uint32_t *dst = W.arena + f_loc;
 				emit([&](uint32_t k, uint32_t v) { dst[k] = v; });
 			}
+			FAST_STAMP(7);		// emission
 			if (have && fast)
 			{
 				acc_bitvec += 2 * ((R + 8) / 8);
@@ -391,7 +430,16 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			// every record: 7 descriptor fields (28 + 4 flags), input CIGAR, select sample, destination rank word; 24 bytes of results
 			acc_bytes += 32 + 4 * n_cigar + (ok ? 12 : 0) + 24 + (has_mate ? 12 : 0);
 		}
+		FAST_STAMP(8);		// work list, outputs
 	}
+#ifdef PVC3_FAST_STAMPS
+	if (0 == lane)
+	{
+		unsigned long long *dst = (unsigned long long *) (W.trace + W.trace_cap) - 16 * (uint64_t) (wave + 1);
+		for (uint32_t k = 0; k < 12; ++k) dst[k] = stamp_acc[k];
+		dst[12] = g_end - g_begin;
+	}
+#endif
 
 	W.slow_count[wave] = n_slow;		// wave-uniform stores
 	W.run_count[wave] = 0;				// k_project_mid / k_project_general append the records with indel runs

@@ -11,7 +11,10 @@ namespace pvc3 {
 
 // ---- HBM layout of one gap bit-vector ---------------------------------------------------------------------------
 // A sequence entry (msa_index::sequence_entry, include/panvc3/msa_index.hh:47-74) is stored as 64-byte blocks:
-//   word 0      number of non-gap columns ("zeros") before the block  -> rank0 in one cache line
+//   word 0      bits 0-31: number of non-gap columns ("zeros") before the block  -> rank0 in one cache line
+//               bits 32-40 / 41-49 / 50-58: zeros in the block's data words 0 / 0..2 / 0..4 — the directory of the block's
+//               16-byte pairs (word 0 + data 0, data 1 + 2, data 3 + 4, data 5 + 6): a rank or a select inside the block
+//               needs word 0 and ONE pair (24 bytes in 6 registers instead of 64 bytes in 16)
 //   words 1..7  448 gap bits (1 = gap), bit (c & 63) of word 1 + ((c % 448) >> 6)
 // plus one select sample per SELECT_SAMPLE zeros (the column of zero number SELECT_SAMPLE * j).  Two all-gap padding blocks follow the
 // last real block so that a two-block window load never leaves the allocation.
@@ -19,6 +22,7 @@ constexpr uint32_t BLOCK_WORDS = 8;
 constexpr uint32_t BLOCK_DATA_WORDS = 7;
 constexpr uint32_t BLOCK_COLS = 448;
 constexpr uint32_t PAD_BLOCKS = 2;
+constexpr uint32_t DIR_SHIFT = 32, DIR_BITS = 9;	// directory fields of word 0: zeros before pair p (1, 2, 3) at bit 32 + 9 (p - 1)
 constexpr uint32_t SELECT_SAMPLE = 4096;	// one select sample per 4096 non-gap columns: the table (4 B per 4096 bases) stays cache resident
 constexpr uint32_t SELECT_SAMPLE_SHIFT = 12;
 constexpr uint32_t TEXT_PAD = 512;		// bytes readable past the end of a device text
@@ -45,7 +49,16 @@ struct dev_entry
 	uint32_t n_zeros;
 	uint32_t text_len;
 	uint32_t n_blocks;
+	// Paired copy (null if the entry has no partner): block b of this entry and block b of entry `partner` side by side in
+	// one aligned 128-byte line.  HBM is fetched in 128-byte lines, so a projection between the two entries reads ONE line
+	// per record for both rows instead of two (tools/calib/random_access: 12.7 instead of 10.2 G records/s for the
+	// access pattern of k_project_fast).  The partner is the entry with a text (a projection's destination) of the same MSA.
+	uint64_t const *paired;
+	uint32_t partner;
+	uint32_t pad;
 };
+static_assert(64 == sizeof(dev_entry), "dev_entry layout");
+constexpr uint32_t NO_PARTNER = 0xFFFFFFFFu;
 
 // ---- device batch ------------------------------------------------------------------------------------------------
 struct dev_batch_in

@@ -226,6 +226,92 @@ __device__ __forceinline__ bool block_select(block_regs const &B, uint32_t w_s, 
 	return found;
 }
 
+// ---- one lane, directory form: word 0 of a block + ONE of its 16-byte pairs ----------------------------------------------
+// Word 0 carries the zeros before the block and before its pairs 1, 2, 3 (pvc3_internal.hpp); pair p holds data words
+// 2 p - 1 and 2 p (pair 0: word 0 itself and data word 0).  A rank or a select inside the block therefore needs 24 bytes in
+// 6 registers and two popcounts instead of the whole block: k_project_fast keeps four probes in flight per record.
+typedef unsigned long long __attribute__((ext_vector_type(2))) dir_pair_t;
+
+struct dir_probe
+{
+	uint64_t head, first, second;
+	uint32_t blk, pair;
+};
+
+__device__ __forceinline__ uint32_t pair_of(col_pos const q) { return (q.w + 1) >> 1; }
+
+// `stride`: 64-bit words from one block of the row to the next (BLOCK_WORDS, or 2 BLOCK_WORDS in a paired copy).
+__device__ __forceinline__ void dir_load_pair(dir_probe &p, uint64_t const *__restrict__ blocks, uint32_t stride, uint32_t pair)
+{
+	dir_pair_t const v = *(dir_pair_t const *) (blocks + (uint64_t) p.blk * stride + 2 * pair);
+	p.first = v.x; p.second = v.y; p.pair = pair;
+}
+
+__device__ __forceinline__ dir_probe dir_load(uint64_t const *__restrict__ blocks, uint32_t stride, uint32_t blk, uint32_t pair)
+{
+	dir_probe p;
+	p.blk = blk;
+	p.head = blocks[(uint64_t) blk * stride];
+	dir_load_pair(p, blocks, stride, pair);
+	return p;
+}
+
+// Zeros of the block before pair `pair`.
+__device__ __forceinline__ uint32_t dir_before(uint64_t head, uint32_t pair)
+{
+	uint32_t const hi = (uint32_t) (head >> DIR_SHIFT);
+	return pair ? ((hi >> (DIR_BITS * (pair - 1))) & ((1u << DIR_BITS) - 1)) : 0;
+}
+
+// rank0 at column q; the probe is reloaded when it was fetched for another place (a guess that did not hold).
+__device__ __forceinline__ uint32_t dir_rank(uint64_t const *__restrict__ blocks, uint32_t stride, dir_probe p, col_pos const q)
+{
+	uint32_t const pair = pair_of(q);
+	if (p.blk != q.blk || p.pair != pair)
+		p = dir_load(blocks, stride, q.blk, pair);
+	bool const is_second = 0 == (q.w & 1);		// data word w is the second word of its pair iff w is even
+	uint64_t const z_first = pair ? ~p.first : UINT64_C(0);		// the first word of pair 0 is word 0, not data
+	uint64_t const word = is_second ? p.second : p.first;
+	uint32_t r = (uint32_t) p.head + dir_before(p.head, pair);
+	r += is_second ? popc64(z_first) : 0;
+	r += popc64(~word & low_mask(q.bit));
+	return r;
+}
+
+// Column of non-gap number pos (0-based, < n_zeros).  `p` is a probe of a block that is not past the target's block
+// (rank word <= pos), normally the block and pair of the select sample's guess.
+__device__ __forceinline__ uint32_t dir_select0(uint64_t const *__restrict__ blocks, uint32_t stride, uint32_t pos, dir_probe p)
+{
+	for (;;)
+	{
+		uint32_t const rem = pos - (uint32_t) p.head;
+		uint32_t const hi = (uint32_t) (p.head >> DIR_SHIFT), fm = (1u << DIR_BITS) - 1;
+		uint32_t const c1 = hi & fm, c3 = (hi >> DIR_BITS) & fm, c5 = (hi >> (2 * DIR_BITS)) & fm;
+		// the last pair whose zeros-before do not exceed rem holds the target, unless it lies beyond the block
+		uint32_t const pair = (rem >= c5) ? 3 : (rem >= c3) ? 2 : (rem >= c1) ? 1 : 0;
+		uint32_t const before = (rem >= c5) ? c5 : (rem >= c3) ? c3 : (rem >= c1) ? c1 : 0;
+		if (pair != p.pair)
+			dir_load_pair(p, blocks, stride, pair);
+		uint32_t const r2 = rem - before;
+		uint64_t const z1 = pair ? ~p.first : UINT64_C(0), z2 = ~p.second;
+		uint32_t const n1 = popc64(z1), n2 = popc64(z2);
+		if (r2 < n1 + n2)
+		{
+			bool const in_first = r2 < n1;
+			return p.blk * BLOCK_COLS + 64 * (2 * pair - (in_first ? 1 : 0)) + thread_select_in_word(in_first ? z1 : z2, in_first ? r2 : (r2 - n1));
+		}
+		// Only pair 3 runs out: the target is r2 - n1 - n2 non-gap columns past the end of this block, at least that many columns.
+		p = dir_load(blocks, stride, p.blk + 1 + (r2 - n1 - n2) / BLOCK_COLS, 0);
+	}
+}
+
+// The select sample's guess for non-gap number pos: the sample is the column of non-gap number SELECT_SAMPLE * (pos /
+// SELECT_SAMPLE), the target lies at least pos % SELECT_SAMPLE columns further; with no gap in between it is exactly there.
+__device__ __forceinline__ uint32_t select_guess(uint32_t const *__restrict__ sel, uint32_t pos)
+{
+	return sel[pos >> SELECT_SAMPLE_SHIFT] + (pos & (SELECT_SAMPLE - 1));
+}
+
 // One lane: column of non-gap number pos (0-based); requires pos < n_zeros.  The select sample is the column of non-gap
 // number SELECT_SAMPLE * (pos / SELECT_SAMPLE); the target lies at least rem = pos % SELECT_SAMPLE columns further, so the
 // block of (sample + rem) cannot be past the target's block and, gaps being rare, nearly always IS the target's block: one
@@ -261,11 +347,29 @@ __device__ __forceinline__ uint32_t thread_rank0(uint64_t const *__restrict__ bl
 }
 
 // One lane: project_position (msa_index.hh:253-258) = rank0_dst(select0_src(pos + 1)).
-__device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, dev_entry const &D, uint32_t pos)
+// The rows of a projection from entry S to entry number dst_id (= D): the paired copy when D is S's partner.
+struct row_pair
+{
+	uint64_t const *src, *dst;
+	uint32_t src_stride, dst_stride;
+};
+
+__device__ __forceinline__ row_pair rows_of(dev_entry const &S, dev_entry const &D, uint32_t dst_id)
+{
+	bool const paired = S.paired && S.partner == dst_id;
+	return row_pair{paired ? S.paired : S.blocks, paired ? S.paired + BLOCK_WORDS : D.blocks, paired ? 2 * BLOCK_WORDS : BLOCK_WORDS, paired ? 2 * BLOCK_WORDS : BLOCK_WORDS};
+}
+
+__device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, dev_entry const &D, uint32_t dst_id, uint32_t pos)
 {
 	if (pos >= S.n_zeros || S.n_cols != D.n_cols)
 		return PVC3_NO_MATE;
-	return thread_rank0(D.blocks, thread_select0(S.blocks, S.sel, pos));
+	row_pair const R = rows_of(S, D, dst_id);
+	// Both probes at the sample's guess: the destination's is right whenever no gap lies between the sample and the target.
+	col_pos const g = split_col(select_guess(S.sel, pos));
+	dir_probe const ps = dir_load(R.src, R.src_stride, g.blk, pair_of(g));
+	dir_probe const pd = dir_load(R.dst, R.dst_stride, g.blk, pair_of(g));
+	return dir_rank(R.dst, R.dst_stride, pd, split_col(dir_select0(R.src, R.src_stride, pos, ps)));
 }
 
 }

@@ -42,6 +42,8 @@ __global__ void k_random(uint8_t const *buf, uint64_t bytes, uint64_t per_thread
 // Cooperative variants: LANES_PER_REC lanes read one record's contiguous bytes with one 16-byte load each, so that one
 // wave instruction touches 64 / LANES_PER_REC records instead of 64.
 //   mode 5: 64 B block by 4 lanes      mode 6: 256 B by 16 lanes      mode 7: 64 + 64 (far apart) by 4+4 lanes, 256 B by 16 lanes
+//   mode 8: like 7 with the two 64-byte blocks next to each other in one aligned 128-byte line (the paired index layout)
+//   mode 9: 64 B by 4 lanes at 128-byte aligned places (is the other half of the line fetched as well?)
 template <int MODE>
 __global__ void k_coop(uint8_t const *buf, uint64_t bytes, uint64_t per_thread, uint64_t *sink)
 {
@@ -77,6 +79,26 @@ __global__ void k_coop(uint8_t const *buf, uint64_t bytes, uint64_t per_thread, 
 			acc += rd(buf + (h % (bytes / 16 - 64)) * 16 + 16 * (lane & 15), 1);
 		}
 	}
+	if (8 == MODE)
+	{
+		for (uint64_t i = 0; i < n_wave; i += 8)
+		{
+			uint64_t const h = mix(wave_base + i + lane / 8 + MODE * 1000003ull);
+			uint64_t const b = (h % (bytes / 128)) * 128;
+			acc += rd(buf + b + ((lane & 4) ? 64 : 0) + 16 * (lane & 3), 1);
+		}
+		for (uint64_t i = 0; i < n_wave; i += 4)
+		{
+			uint64_t const h = mix(mix(wave_base + i + lane / 16 + MODE * 1000003ull));
+			acc += rd(buf + (h % (bytes / 16 - 64)) * 16 + 16 * (lane & 15), 1);
+		}
+	}
+	if (9 == MODE)
+		for (uint64_t i = 0; i < n_wave; i += 16)
+		{
+			uint64_t const h = mix(wave_base + i + lane / 4 + MODE * 1000003ull);
+			acc += rd(buf + (h % (bytes / 128)) * 128 + 16 * (lane & 3), 1);
+		}
 	if (acc == 0x1234567) sink[0] = acc;
 }
 
@@ -90,10 +112,10 @@ int main()
 	dim3 const grid(8192), block(256);
 	uint64_t const n = 8192ull * 256 * per_thread;
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-	char const *names[8] = {"64 B", "128 B aligned", "64 B + 64 B far apart", "64 + 64 + 256 B in one 1 KiB region", "64 + 64 far apart + 256 B elsewhere", "coop: 64 B by 4 lanes", "coop: 256 B by 16 lanes", "coop: 64 + 64 far apart + 256 B elsewhere"};
-	uint64_t const useful[8] = {64, 128, 128, 384, 384, 64, 256, 384};
+	char const *names[10] = {"64 B", "128 B aligned", "64 B + 64 B far apart", "64 + 64 + 256 B in one 1 KiB region", "64 + 64 far apart + 256 B elsewhere", "coop: 64 B by 4 lanes", "coop: 256 B by 16 lanes", "coop: 64 + 64 far apart + 256 B elsewhere", "coop: 64 + 64 in one line + 256 B elsewhere", "coop: 64 B by 4 lanes, 128-B aligned"};
+	uint64_t const useful[10] = {64, 128, 128, 384, 384, 64, 256, 384, 384, 64};
 	for (int rep = 0; rep < 2; ++rep)
-		for (int mode = 0; mode < 8; ++mode)
+		for (int mode = 0; mode < 10; ++mode)
 		{
 			hipEventRecord(e0);
 			switch (mode)
@@ -105,7 +127,9 @@ int main()
 				case 4: hipLaunchKernelGGL(k_random <4>, grid, block, 0, 0, buf, bytes, per_thread, sink); break;
 				case 5: hipLaunchKernelGGL(k_coop <5>, grid, block, 0, 0, buf, bytes, per_thread, sink); break;
 				case 6: hipLaunchKernelGGL(k_coop <6>, grid, block, 0, 0, buf, bytes, per_thread, sink); break;
-				default: hipLaunchKernelGGL(k_coop <7>, grid, block, 0, 0, buf, bytes, per_thread, sink); break;
+				case 7: hipLaunchKernelGGL(k_coop <7>, grid, block, 0, 0, buf, bytes, per_thread, sink); break;
+				case 8: hipLaunchKernelGGL(k_coop <8>, grid, block, 0, 0, buf, bytes, per_thread, sink); break;
+				default: hipLaunchKernelGGL(k_coop <9>, grid, block, 0, 0, buf, bytes, per_thread, sink); break;
 			}
 			hipEventRecord(e1); hipEventSynchronize(e1);
 			float ms; hipEventElapsedTime(&ms, e0, e1);

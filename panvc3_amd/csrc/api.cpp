@@ -506,12 +506,8 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 			if (best < idx->entries.size())
 			{
 				host_entry const &o = idx->entries[best];
-				std::vector <uint64_t> both(2 * e.blocks.size());
-				for (size_t b = 0; b < e.blocks.size() / BLOCK_WORDS; ++b)
-				{
-					std::memcpy(&both[2 * BLOCK_WORDS * b], &e.blocks[BLOCK_WORDS * b], BLOCK_WORDS * sizeof(uint64_t));
-					std::memcpy(&both[2 * BLOCK_WORDS * b + BLOCK_WORDS], &o.blocks[BLOCK_WORDS * b], BLOCK_WORDS * sizeof(uint64_t));
-				}
+				std::vector <uint64_t> both;
+				build_paired_blocks(e, o, both);
 				PVC3_TRY(dev_upload(&d.paired, both.data(), both.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
 				HIP_TRY(hipStreamSynchronize(ctx->stream));		// `both` is pageable and leaves scope
 				d.partner = (uint32_t) best;

@@ -51,6 +51,38 @@ static void finish_entry(host_entry &e)
 	e.sel.push_back((uint32_t) e.n_cols);	// sentinel so that sel[n_zeros / SELECT_SAMPLE] is always readable
 }
 
+void build_paired_blocks(host_entry const &e, host_entry const &o, std::vector <uint64_t> &out)
+{
+	// Data word j of block b of the paired copy is word 4 b + j of the row's flat bit-vector (PAIRED_STEP = 4 x 64 columns).
+	static_assert(0 == PAIRED_STEP % 64, "paired blocks start at word boundaries");
+	uint64_t const words_per_step = PAIRED_STEP / 64;
+	uint64_t const n_flat = e.n_blocks * BLOCK_DATA_WORDS;
+	uint64_t const n_paired = e.n_cols / PAIRED_STEP + 1 + PAD_BLOCKS;
+	out.assign(n_paired * 2 * BLOCK_WORDS, 0);
+	host_entry const *rows[2] = {&e, &o};
+	for (uint32_t r = 0; r < 2; ++r)
+	{
+		host_entry const &h = *rows[r];
+		auto flat = [&](uint64_t i) -> uint64_t { return (i < n_flat) ? h.blocks[(i / BLOCK_DATA_WORDS) * BLOCK_WORDS + 1 + i % BLOCK_DATA_WORDS] : ~UINT64_C(0); };
+		uint64_t zeros = 0, next_word = 0;		// zeros before flat word next_word
+		for (uint64_t b = 0; b < n_paired; ++b)
+		{
+			for (; next_word < words_per_step * b; ++next_word)
+				zeros += (uint64_t) __builtin_popcountll(~flat(next_word));
+			uint64_t *dst = &out[(2 * b + r) * BLOCK_WORDS];
+			uint64_t dir = 0, in_block = 0;
+			for (uint32_t w = 0; w < BLOCK_DATA_WORDS; ++w)
+			{
+				if (1 == (w & 1)) dir |= in_block << (DIR_SHIFT + DIR_BITS * (w >> 1));
+				uint64_t const x = flat(words_per_step * b + w);
+				dst[1 + w] = x;
+				in_block += (uint64_t) __builtin_popcountll(~x);
+			}
+			dst[0] = zeros | dir;
+		}
+	}
+}
+
 static int new_entry(pvc3_index *idx, uint64_t n_cols, host_entry **out)
 {
 	if (n_cols + 3 * (uint64_t) BLOCK_COLS >= (UINT64_C(1) << 32))

@@ -136,8 +136,6 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		dev_entry const S = get_entry(e_ok ? src_e : 0);
 		dev_entry const D = get_entry(e_ok ? dst_e : 0);
 		row_pair const rows = rows_of(S, D, dst_e);
-		uint64_t const *s_blocks = rows.src, *d_blocks = rows.dst;
-		uint32_t const stride = rows.src_stride;		// the two strides are equal
 		uint32_t const *s_sel = S.sel;
 		uint32_t const s_zeros = S.n_zeros, s_cols = S.n_cols;
 		uint8_t const *d_text4 = D.text4;
@@ -195,17 +193,19 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			// did not hold (a gap column between the sample and the record).
 			uint32_t const guess = select_guess(s_sel, src_pos);
 			FAST_STAMP(2);		// select sample
-			col_pos const g0 = split_col(guess), g1 = split_col(guess + ref_consumed);
-			dir_probe const ps0 = dir_load(s_blocks, stride, g0.blk, pair_of(g0));
-			dir_probe const pd0 = dir_load(d_blocks, stride, g0.blk, pair_of(g0));
-			dir_probe const ps1 = dir_load(s_blocks, stride, g1.blk, pair_of(g1));
-			dir_probe const pd1 = dir_load(d_blocks, stride, g1.blk, pair_of(g1));
-			col = dir_select0(s_blocks, stride, src_pos, ps0);
-			col_pos const p0 = split_col(col);
-			col_pos const p1 = split_col(col + ref_consumed);
-			r0 = dir_rank(d_blocks, stride, pd0, p0);
+			uint32_t const step = rows.src.step;
+			col_pos const g0 = locate(step, guess), g1 = locate_in(step, guess + ref_consumed, g0.blk);
+			dir_probe const ps0 = dir_load(rows.src, g0.blk, pair_of(g0));
+			dir_probe const pd0 = dir_load(rows.dst, g0.blk, pair_of(g0));
+			dir_probe const ps1 = dir_load(rows.src, g1.blk, pair_of(g1));
+			dir_probe const pd1 = dir_load(rows.dst, g1.blk, pair_of(g1));
+			col = dir_select0(rows.src, src_pos, ps0);
+			// (If the paired copy's blocks overlap, PAIRED_STEP < 448, the end of the span is looked up in the block of its start.)
+			col_pos const p0 = locate_in(step, col, g0.blk);
+			col_pos const p1 = locate_in(step, col + ref_consumed, p0.blk);
+			r0 = dir_rank(rows.dst, pd0, p0);
 			// No gap column in either row over the span <=> both ranks advance by exactly ref_consumed.
-			bool const gapless = (dir_rank(s_blocks, stride, ps1, p1) == src_pos + ref_consumed) && (dir_rank(d_blocks, stride, pd1, p1) == r0 + ref_consumed);
+			bool const gapless = (dir_rank(rows.src, ps1, p1) == src_pos + ref_consumed) && (dir_rank(rows.dst, pd1, p1) == r0 + ref_consumed);
 			bool const simple = (2 == shape || 3 == shape);
 			fast = use_fast_path && simple && gapless && (ref_consumed + phase < FAST_MAX_BASES) && d_text4 && ((uint64_t) r0 + ref_consumed <= d_text_len);
 		}

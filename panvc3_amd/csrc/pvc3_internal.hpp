@@ -29,6 +29,10 @@ constexpr uint32_t TEXT_PAD = 512;		// bytes readable past the end of a device t
 constexpr uint32_t TEXT_FRONT_PAD = 16;	// bytes readable before its start
 constexpr uint32_t TEXT4_FRONT = 16;		// packed text: nibbles in front of base 0 (base i = nibble i + TEXT4_FRONT, low nibble first)
 
+struct host_entry;
+// dev_entry::paired for entry e and its partner o (same number of columns): blocks of 2 x 8 words.
+void build_paired_blocks(host_entry const &e, host_entry const &o, std::vector <uint64_t> &out);
+
 struct host_entry
 {
 	uint64_t n_cols{};
@@ -49,16 +53,24 @@ struct dev_entry
 	uint32_t n_zeros;
 	uint32_t text_len;
 	uint32_t n_blocks;
-	// Paired copy (null if the entry has no partner): block b of this entry and block b of entry `partner` side by side in
-	// one aligned 128-byte line.  HBM is fetched in 128-byte lines, so a projection between the two entries reads ONE line
-	// per record for both rows instead of two (tools/calib/random_access: 12.7 instead of 10.2 G records/s for the
-	// access pattern of k_project_fast).  The partner is the entry with a text (a projection's destination) of the same MSA.
+	// Paired copy (null if the entry has no partner): a block of this entry and the block of entry `partner` over the same
+	// columns side by side in one aligned 128-byte line, block b starting at column PAIRED_STEP * b.  HBM is fetched in
+	// 128-byte lines, so a projection between the two entries reads ONE line per record for both rows instead of two
+	// (tools/calib/random_access: 12.7 instead of 10.2 G records/s for the access pattern of k_project_fast).  The partner is
+	// the entry with a text (a projection's destination) of the same MSA.
 	uint64_t const *paired;
 	uint32_t partner;
 	uint32_t pad;
 };
 static_assert(64 == sizeof(dev_entry), "dev_entry layout");
 constexpr uint32_t NO_PARTNER = 0xFFFFFFFFu;
+// Columns between the starts of consecutive blocks of a paired copy; a multiple of 64.  Less than BLOCK_COLS makes the blocks
+// overlap, so that both ends of a span lie in one line; measured with 256 on config C3 (mates 250 columns apart): slower
+// than 448, because two mates then never share a line (3.88 against 3.70 ms).
+#ifndef PVC3_PAIRED_STEP
+#define PVC3_PAIRED_STEP 448
+#endif
+constexpr uint32_t PAIRED_STEP = PVC3_PAIRED_STEP;
 
 // ---- device batch ------------------------------------------------------------------------------------------------
 struct dev_batch_in

@@ -230,7 +230,37 @@ __device__ __forceinline__ bool block_select(block_regs const &B, uint32_t w_s, 
 // Word 0 carries the zeros before the block and before its pairs 1, 2, 3 (pvc3_internal.hpp); pair p holds data words
 // 2 p - 1 and 2 p (pair 0: word 0 itself and data word 0).  A rank or a select inside the block therefore needs 24 bytes in
 // 6 registers and two popcounts instead of the whole block: k_project_fast keeps four probes in flight per record.
+// A row is seen through a row_view: the plain array (blocks 64 bytes apart, block b = columns [448 b, 448 b + 448)) or the
+// row's half of a paired copy (dev_entry::paired: 128 bytes apart, block b = columns [PAIRED_STEP b, PAIRED_STEP b + 448)).
 typedef unsigned long long __attribute__((ext_vector_type(2))) dir_pair_t;
+
+struct row_view
+{
+	uint64_t const *blocks;
+	uint32_t stride;		// 64-bit words from one block to the next
+	uint32_t step;			// columns from one block's first column to the next block's
+};
+
+// The last block that starts at or before `col`.
+__device__ __forceinline__ col_pos locate(uint32_t step, uint32_t col)
+{
+	col_pos p;
+	p.blk = (PAIRED_STEP == step) ? (col / PAIRED_STEP) : (col / BLOCK_COLS);
+	uint32_t const r = col - p.blk * step;
+	p.w = r >> 6; p.bit = r & 63;
+	return p;
+}
+
+// `col` inside block `blk` if that block covers it (overlapping blocks: the end of a span in the block of its start).
+__device__ __forceinline__ col_pos locate_in(uint32_t step, uint32_t col, uint32_t blk)
+{
+	uint32_t const r = col - blk * step;		// wraps to a large number when col lies before the block
+	if (r >= BLOCK_COLS)
+		return locate(step, col);
+	col_pos p;
+	p.blk = blk; p.w = r >> 6; p.bit = r & 63;
+	return p;
+}
 
 struct dir_probe
 {
@@ -240,19 +270,18 @@ struct dir_probe
 
 __device__ __forceinline__ uint32_t pair_of(col_pos const q) { return (q.w + 1) >> 1; }
 
-// `stride`: 64-bit words from one block of the row to the next (BLOCK_WORDS, or 2 BLOCK_WORDS in a paired copy).
-__device__ __forceinline__ void dir_load_pair(dir_probe &p, uint64_t const *__restrict__ blocks, uint32_t stride, uint32_t pair)
+__device__ __forceinline__ void dir_load_pair(dir_probe &p, row_view const &v, uint32_t pair)
 {
-	dir_pair_t const v = *(dir_pair_t const *) (blocks + (uint64_t) p.blk * stride + 2 * pair);
-	p.first = v.x; p.second = v.y; p.pair = pair;
+	dir_pair_t const x = *(dir_pair_t const *) (v.blocks + (uint64_t) p.blk * v.stride + 2 * pair);
+	p.first = x.x; p.second = x.y; p.pair = pair;
 }
 
-__device__ __forceinline__ dir_probe dir_load(uint64_t const *__restrict__ blocks, uint32_t stride, uint32_t blk, uint32_t pair)
+__device__ __forceinline__ dir_probe dir_load(row_view const &v, uint32_t blk, uint32_t pair)
 {
 	dir_probe p;
 	p.blk = blk;
-	p.head = blocks[(uint64_t) blk * stride];
-	dir_load_pair(p, blocks, stride, pair);
+	p.head = v.blocks[(uint64_t) blk * v.stride];
+	dir_load_pair(p, v, pair);
 	return p;
 }
 
@@ -264,11 +293,11 @@ __device__ __forceinline__ uint32_t dir_before(uint64_t head, uint32_t pair)
 }
 
 // rank0 at column q; the probe is reloaded when it was fetched for another place (a guess that did not hold).
-__device__ __forceinline__ uint32_t dir_rank(uint64_t const *__restrict__ blocks, uint32_t stride, dir_probe p, col_pos const q)
+__device__ __forceinline__ uint32_t dir_rank(row_view const &v, dir_probe p, col_pos const q)
 {
 	uint32_t const pair = pair_of(q);
 	if (p.blk != q.blk || p.pair != pair)
-		p = dir_load(blocks, stride, q.blk, pair);
+		p = dir_load(v, q.blk, pair);
 	bool const is_second = 0 == (q.w & 1);		// data word w is the second word of its pair iff w is even
 	uint64_t const z_first = pair ? ~p.first : UINT64_C(0);		// the first word of pair 0 is word 0, not data
 	uint64_t const word = is_second ? p.second : p.first;
@@ -278,9 +307,9 @@ __device__ __forceinline__ uint32_t dir_rank(uint64_t const *__restrict__ blocks
 	return r;
 }
 
-// Column of non-gap number pos (0-based, < n_zeros).  `p` is a probe of a block that is not past the target's block
+// Column of non-gap number pos (0-based, < n_zeros).  `p` is a probe of a block that does not start past the target
 // (rank word <= pos), normally the block and pair of the select sample's guess.
-__device__ __forceinline__ uint32_t dir_select0(uint64_t const *__restrict__ blocks, uint32_t stride, uint32_t pos, dir_probe p)
+__device__ __forceinline__ uint32_t dir_select0(row_view const &v, uint32_t pos, dir_probe p)
 {
 	for (;;)
 	{
@@ -291,17 +320,17 @@ __device__ __forceinline__ uint32_t dir_select0(uint64_t const *__restrict__ blo
 		uint32_t const pair = (rem >= c5) ? 3 : (rem >= c3) ? 2 : (rem >= c1) ? 1 : 0;
 		uint32_t const before = (rem >= c5) ? c5 : (rem >= c3) ? c3 : (rem >= c1) ? c1 : 0;
 		if (pair != p.pair)
-			dir_load_pair(p, blocks, stride, pair);
+			dir_load_pair(p, v, pair);
 		uint32_t const r2 = rem - before;
 		uint64_t const z1 = pair ? ~p.first : UINT64_C(0), z2 = ~p.second;
 		uint32_t const n1 = popc64(z1), n2 = popc64(z2);
 		if (r2 < n1 + n2)
 		{
 			bool const in_first = r2 < n1;
-			return p.blk * BLOCK_COLS + 64 * (2 * pair - (in_first ? 1 : 0)) + thread_select_in_word(in_first ? z1 : z2, in_first ? r2 : (r2 - n1));
+			return p.blk * v.step + 64 * (2 * pair - (in_first ? 1 : 0)) + thread_select_in_word(in_first ? z1 : z2, in_first ? r2 : (r2 - n1));
 		}
 		// Only pair 3 runs out: the target is r2 - n1 - n2 non-gap columns past the end of this block, at least that many columns.
-		p = dir_load(blocks, stride, p.blk + 1 + (r2 - n1 - n2) / BLOCK_COLS, 0);
+		p = dir_load(v, locate(v.step, p.blk * v.step + BLOCK_COLS + (r2 - n1 - n2)).blk, 0);
 	}
 }
 
@@ -350,14 +379,14 @@ __device__ __forceinline__ uint32_t thread_rank0(uint64_t const *__restrict__ bl
 // The rows of a projection from entry S to entry number dst_id (= D): the paired copy when D is S's partner.
 struct row_pair
 {
-	uint64_t const *src, *dst;
-	uint32_t src_stride, dst_stride;
+	row_view src, dst;
 };
 
 __device__ __forceinline__ row_pair rows_of(dev_entry const &S, dev_entry const &D, uint32_t dst_id)
 {
 	bool const paired = S.paired && S.partner == dst_id;
-	return row_pair{paired ? S.paired : S.blocks, paired ? S.paired + BLOCK_WORDS : D.blocks, paired ? 2 * BLOCK_WORDS : BLOCK_WORDS, paired ? 2 * BLOCK_WORDS : BLOCK_WORDS};
+	uint32_t const stride = paired ? 2 * BLOCK_WORDS : BLOCK_WORDS, step = paired ? PAIRED_STEP : BLOCK_COLS;
+	return row_pair{row_view{paired ? S.paired : S.blocks, stride, step}, row_view{paired ? S.paired + BLOCK_WORDS : D.blocks, stride, step}};
 }
 
 __device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, dev_entry const &D, uint32_t dst_id, uint32_t pos)
@@ -366,10 +395,10 @@ __device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, 
 		return PVC3_NO_MATE;
 	row_pair const R = rows_of(S, D, dst_id);
 	// Both probes at the sample's guess: the destination's is right whenever no gap lies between the sample and the target.
-	col_pos const g = split_col(select_guess(S.sel, pos));
-	dir_probe const ps = dir_load(R.src, R.src_stride, g.blk, pair_of(g));
-	dir_probe const pd = dir_load(R.dst, R.dst_stride, g.blk, pair_of(g));
-	return dir_rank(R.dst, R.dst_stride, pd, split_col(dir_select0(R.src, R.src_stride, pos, ps)));
+	col_pos const g = locate(R.src.step, select_guess(S.sel, pos));
+	dir_probe const ps = dir_load(R.src, g.blk, pair_of(g));
+	dir_probe const pd = dir_load(R.dst, g.blk, pair_of(g));
+	return dir_rank(R.dst, pd, locate_in(R.dst.step, dir_select0(R.src, pos, ps), g.blk));
 }
 
 }

@@ -64,6 +64,7 @@ struct pvc3_context
 	uint32_t mid_path{1};
 	uint32_t packed_dp{1};
 	uint32_t paired_blocks{1};			// upload_index: paired copies of the gap bit-vector blocks (dev_entry::paired)
+	uint32_t text_window{1};			// upload_index: windowed copies of the packed texts (dev_entry::text4w)
 	uint8_t *scratch{};
 	uint64_t scratch_alloc{};
 	uint32_t *trace{};					// trace words of the packed alignment kernels
@@ -440,6 +441,7 @@ int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value)
 	else if ("mid_path" == k) ctx->mid_path = (0 != value);
 	else if ("packed_dp" == k) ctx->packed_dp = (0 != value);
 	else if ("paired_blocks" == k) ctx->paired_blocks = (0 != value);		// takes effect at the next pvc3_context_upload_index
+	else if ("text_window" == k) ctx->text_window = (0 != value);			// likewise
 	else return set_error(PVC3_E_INVALID, "pvc3_context_set_option: unknown option %s", key);
 	return PVC3_OK;
 }
@@ -467,6 +469,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 		PVC3_TRY(dev_upload(&d.sel, e.sel.data(), e.sel.size(), 64, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
 		d.text = nullptr;
 		d.text4 = nullptr;
+		d.text4w = nullptr;
 		if (!e.text.empty())
 		{
 			// Front and back padding: the kernels read whole 16 / 32-byte pieces around the bases they need.
@@ -483,6 +486,16 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 			HIP_TRY(hipMemsetAsync(p4, 0, bytes4, ctx->stream));
 			HIP_TRY((hipError_t) launch_pack_text4(d.text, e.text.size(), p4, ctx->stream));
 			d.text4 = p4;
+			if (ctx->text_window)
+			{
+				// Every line the kernel can address: line k for a run that starts at nibble n has k = n / STEP <= nibbles / STEP.
+				uint64_t const n_lines = (TEXT4_FRONT + e.text.size()) / TEXT_WINDOW_STEP + 1;
+				static_assert(TEXT_PAD >= 128 + 16, "the last lines are cut from the packed text's padding");
+				uint8_t *pw{};
+				PVC3_TRY(dev_alloc(&pw, 128 * n_lines + 16, &ctx->index_allocs, &ctx->index_bytes));
+				HIP_TRY((hipError_t) launch_window_text4(p4, n_lines, pw, ctx->stream));
+				d.text4w = pw;
+			}
 		}
 		d.n_cols = (uint32_t) e.n_cols;
 		d.n_zeros = (uint32_t) e.n_zeros;

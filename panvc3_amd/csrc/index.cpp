@@ -145,7 +145,7 @@ int index_set_reference(pvc3_index *idx, uint32_t entry, char const *text, uint6
 	if (len < e.n_zeros)
 		return set_error(PVC3_E_INVALID, "pvc3_index_set_reference: text of entry %u has %llu characters but the entry has %llu non-gap columns",
 			entry, (unsigned long long) len, (unsigned long long) e.n_zeros);
-	if (len >= (UINT64_C(1) << 32))
+	if (len + 1024 >= (UINT64_C(1) << 32))		// nibble numbers of the packed text (TEXT4_FRONT + position) stay 32-bit
 		return set_error(PVC3_E_INVALID, "pvc3_index_set_reference: text too long");
 	e.text.assign(text, text + len);
 	return PVC3_OK;

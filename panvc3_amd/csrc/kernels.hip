@@ -257,6 +257,19 @@ __global__ __launch_bounds__(256) void k_pack_text4(uint8_t const *__restrict__ 
 	}
 }
 
+// dev_entry::text4w: 16 bytes per thread.
+__global__ __launch_bounds__(256) void k_window_text4(uint8_t const *__restrict__ text4, uint64_t n_lines, uint8_t *__restrict__ out)
+{
+	uint64_t const stride = (uint64_t) gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < 8 * n_lines; i += stride)
+	{
+		uint64_t const k = i >> 3, j = 16 * (i & 7);
+		uint64_t v[2];
+		__builtin_memcpy(v, text4 + (TEXT_WINDOW_STEP / 2) * k + j, 16);
+		__builtin_memcpy(out + 128 * k + j, v, 16);
+	}
+}
+
 // Folds the per-wave statistics of k_project_fast / k_project_mid / k_project_general (blockIdx.y) into the counters:
 // one thread per wave row, one atomic per block and counter.
 __global__ __launch_bounds__(256) void k_reduce_stats(uint32_t n_waves, dev_batch_work const W)
@@ -315,6 +328,13 @@ int launch_project_positions(dev_entry const *entries, uint32_t n_entries, uint6
 {
 	if (0 == n) return 0;
 	hipLaunchKernelGGL(k_project_positions, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t) stream, entries, n_entries, n, src_entry, dst_entry, pos, out);
+	return (int) hipGetLastError();
+}
+
+int launch_window_text4(uint8_t const *text4, uint64_t n_lines, uint8_t *out, void *stream)
+{
+	if (n_lines)
+		hipLaunchKernelGGL(k_window_text4, dim3(grid_for(8 * n_lines, 256, 256 * 32)), dim3(256), 0, (hipStream_t) stream, text4, n_lines, out);
 	return (int) hipGetLastError();
 }
 

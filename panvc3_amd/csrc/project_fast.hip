@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		row_pair const rows = rows_of(S, D, dst_e);
 		uint32_t const *s_sel = S.sel;
 		uint32_t const s_zeros = S.n_zeros, s_cols = S.n_cols;
-		uint8_t const *d_text4 = D.text4;
+		uint8_t const *d_text4 = D.text4, *d_text4w = D.text4w;
 		uint32_t const d_text_len = D.text_len, d_cols = D.n_cols;
 
 		// ---- CIGAR: validation + shape automaton of the fast path (first four operations from one 16-byte load) ----------------
@@ -254,7 +254,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			{
 				u64x2 d;
 				d.x = (uint64_t) qp | ((uint64_t) U << 48);
-				d.y = (uint64_t) (d_text4 + (tn >> 1)) | ((tn & 1) << 63);
+				// From the windowed copy when the run fits a line of it (reads of up to 150 bases): one 128-byte line of text.
+				uint32_t const tn32 = (uint32_t) tn;				// text_len + TEXT4_FRONT < 2^32 (pvc3_index_set_reference)
+				uint32_t const line = tn32 / TEXT_WINDOW_STEP, in_line = tn32 - line * TEXT_WINDOW_STEP;
+				uint8_t const *tp = (d_text4w && U <= TEXT_WINDOW_MAX) ? (d_text4w + 128 * (uint64_t) line + (in_line >> 1)) : (d_text4 + (tn >> 1));
+				d.y = (uint64_t) tp | ((tn & 1) << 63);
 				my_desc[lane] = d;
 			}
 			wave_lds_sync();

@@ -61,8 +61,16 @@ struct dev_entry
 	uint64_t const *paired;
 	uint32_t partner;
 	uint32_t pad;
+	// Windowed copy of text4 (null without a text): 128-byte lines, line k = the 256 nibbles of text4 from nibble
+	// TEXT_WINDOW_STEP * k on (the lines overlap).  Any run of up to TEXT_WINDOW_MAX nibbles lies inside ONE line, so the
+	// compare of a read of up to 150 bases fetches one 128-byte line of text instead of 1.6 on average.
+	uint8_t const *text4w;
 };
-static_assert(64 == sizeof(dev_entry), "dev_entry layout");
+static_assert(72 == sizeof(dev_entry), "dev_entry layout");
+// The compare reads the run in 16-byte pieces from the byte of its first nibble: piece floor(U / 32) is the last one, so a
+// run of U <= 159 nibbles that starts in the first 96 nibbles of a line ends at byte 47 + 80 = 127 of it.
+constexpr uint32_t TEXT_WINDOW_STEP = 96;		// nibbles
+constexpr uint32_t TEXT_WINDOW_MAX = 159;		// longest run (query positions, including the phase nibble) served from the windowed copy
 constexpr uint32_t NO_PARTNER = 0xFFFFFFFFu;
 // Columns between the starts of consecutive blocks of a paired copy; a multiple of 64.  Less than BLOCK_COLS makes the blocks
 // overlap, so that both ends of a span lie in one line; measured with 256 on config C3 (mates 250 columns apart): slower
@@ -226,6 +234,7 @@ int launch_reduce_stats(uint64_t n, dev_batch_work const &work, void *stream);
 int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &packed, uint64_t *scan_tmp, void *stream);
 int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);
 int launch_pack_text4(uint8_t const *text, uint64_t len, uint8_t *out, void *stream);
+int launch_window_text4(uint8_t const *text4, uint64_t n_lines, uint8_t *out, void *stream);	// out[128 k + j] = text4[TEXT_WINDOW_STEP / 2 * k + j]
 int launch_project_positions(dev_entry const *entries, uint32_t n_entries, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out, void *stream);
 // Layout check of a freshly loaded batch; *first_bad = smallest malformed record (left at 0xFFFFFFFF if there is none).
 int launch_validate(dev_batch_in const &in, uint64_t n_cigar, uint64_t n_seq, uint64_t n_qual, uint64_t const *qual_off, uint32_t *first_bad, void *stream);

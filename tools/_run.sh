@@ -1,8 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python -m pytest tests/test_parity_gpu.py -m gpu -x -q 2>&1 | tail -2 &&
-for n in main nopair; do
-  if [ $n = main ]; then O=; else O="--option paired_blocks=0"; fi
-  timeout -k 10 200 python3 bench.py --no-build --steps 10 --warmup 2 --cpu-baseline-seconds 0 --skip-host-buffers $O 2>gpurun_out/run_$n.err | python3 -c "
+timeout -k 10 500 python -m pytest tests/test_parity_gpu.py tests/test_workloads_gpu.py -m gpu -x -q 2>&1 | tail -2 &&
+for n in main nowin; do
+  if [ $n = main ]; then O=; else O="--option text_window=0"; fi
+  timeout -k 10 200 python3 bench.py --no-build --steps 10 --warmup 2 --cpu-baseline-seconds 0 --skip-host-buffers --skip-sorted-leg $O 2>gpurun_out/run_$n.err | python3 -c "
 import sys,json
-d=json.loads(sys.stdin.readline()); print('$n', d['ms_per_step'], d.get('kernel_ms'), d['roofline']['frac'], [ (k, v.get('ms_per_step'), v.get('kernel_ms')) for k,v in d.items() if isinstance(v, dict) and 'ms_per_step' in v])" || echo "$n failed"
+d=json.loads(sys.stdin.readline()); print('$n', d['ms_per_step'], d.get('kernel_ms'), d['roofline']['frac'])" || echo "$n failed"
 done

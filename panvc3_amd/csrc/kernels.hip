@@ -53,10 +53,28 @@ __global__ __launch_bounds__(256) void k_validate_batch(dev_batch_in const in, u
 
 
 // ---- packing: exclusive scans of the per-record counts, then a gather into record order ------------------------------
+// A tile is 1024 consecutive records; thread t of the tile's block owns records 4 t .. 4 t + 3, so that a thread's counts and
+// offsets are single 16-byte (32-byte) accesses, everything a thread needs is requested before anything is used, and
+// neighbouring threads copy neighbouring pieces of the arenas.
 constexpr uint32_t SCAN_THREADS = 256;
-constexpr uint32_t SCAN_ITEMS = 8;
+constexpr uint32_t SCAN_ITEMS = 4;
 constexpr uint32_t SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
-constexpr uint32_t GATHER_STAGE = 4096;		// uint32 of LDS staging in k_offsets_gather (16 operations per record on average)
+constexpr uint32_t GATHER_STAGE = 8192;		// uint32 of LDS staging in k_offsets_gather (8 operations per record on average; more: direct copies)
+
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4_t;
+typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2_t;
+
+// The counts of a thread's four records: one 16-byte load inside the array (it is a multiple of 4 long only by accident).
+__device__ __forceinline__ u32x4_t load_counts(uint32_t const *__restrict__ a, uint64_t first, uint64_t n)
+{
+	if (first + SCAN_ITEMS <= n)
+		return *(u32x4_t const *) (a + first);
+	u32x4_t v{0, 0, 0, 0};
+	if (first < n) v.x = a[first];
+	if (first + 1 < n) v.y = a[first + 1];
+	if (first + 2 < n) v.z = a[first + 2];
+	return v;
+}
 
 __device__ __forceinline__ uint64_t block_reduce_add(uint64_t v, uint64_t *lds)
 {
@@ -71,53 +89,82 @@ __device__ __forceinline__ uint64_t block_reduce_add(uint64_t v, uint64_t *lds)
 	return total;
 }
 
-// tile_sums[2 t + k] = sum of counts k (0 = cigar, 1 = runs) over tile t
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(uint64_t n, uint32_t const *__restrict__ a, uint32_t const *__restrict__ b, uint64_t *__restrict__ tile_sums)
+// A block sums SUPER_TILES consecutive tiles: tile_sums[2 t + k] = sum of counts k (0 = cigar, 1 = runs) over the tiles of the
+// same super-tile before tile t, super_sums[2 s + k] = sum over super-tile s.  (Two levels keep the single-block scan below short:
+// 4 883 entries for 40 M records.)
+constexpr uint32_t SUPER_TILES = 8;
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tiles(uint64_t n, uint64_t n_tiles, uint32_t const *__restrict__ a, uint32_t const *__restrict__ b, uint64_t *__restrict__ tile_sums, uint64_t *__restrict__ super_sums)
 {
-	__shared__ uint64_t lds[8];
-	uint64_t const base = (uint64_t) blockIdx.x * SCAN_TILE;
-	uint64_t sa = 0, sb = 0;
-	for (uint32_t i = 0; i < SCAN_ITEMS; ++i)
+	__shared__ uint64_t lds[SCAN_THREADS / 64][2 * SUPER_TILES];
+	uint64_t const tile0 = (uint64_t) blockIdx.x * SUPER_TILES;
+	u32x4_t va[SUPER_TILES], vb[SUPER_TILES];
+#pragma unroll
+	for (uint32_t j = 0; j < SUPER_TILES; ++j)
 	{
-		uint64_t const idx = base + (uint64_t) i * SCAN_THREADS + threadIdx.x;
-		if (idx < n) { sa += a[idx]; sb += b[idx]; }
+		uint64_t const first = (tile0 + j) * SCAN_TILE + SCAN_ITEMS * threadIdx.x;
+		va[j] = load_counts(a, first, n); vb[j] = load_counts(b, first, n);
 	}
-	sa = block_reduce_add(sa, lds);
-	sb = block_reduce_add(sb, lds);
-	if (0 == threadIdx.x) { tile_sums[2 * (uint64_t) blockIdx.x] = sa; tile_sums[2 * (uint64_t) blockIdx.x + 1] = sb; }
+	uint32_t const lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+	for (uint32_t j = 0; j < SUPER_TILES; ++j)
+	{
+		uint64_t sa = (uint64_t) va[j].x + va[j].y + va[j].z + va[j].w, sb = (uint64_t) vb[j].x + vb[j].y + vb[j].z + vb[j].w;
+		for (int off = 32; off; off >>= 1) { sa += __shfl_xor(sa, off); sb += __shfl_xor(sb, off); }
+		if (0 == lane) { lds[w][2 * j] = sa; lds[w][2 * j + 1] = sb; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 2)
+	{
+		uint64_t run = 0;
+		for (uint32_t j = 0; j < SUPER_TILES; ++j)
+		{
+			uint64_t t = 0;
+			for (uint32_t x = 0; x < SCAN_THREADS / 64; ++x) t += lds[x][2 * j + threadIdx.x];
+			if (tile0 + j < n_tiles) tile_sums[2 * (tile0 + j) + threadIdx.x] = run;
+			run += t;
+		}
+		super_sums[2 * (uint64_t) blockIdx.x + threadIdx.x] = run;
+	}
 }
 
-// In-place exclusive scan of the tile sums by one block (tile counts are small: n / 4096).
+// In-place exclusive scan of the tile sums by one block of 16 wavefronts: wave w owns a contiguous range of tiles and walks
+// it 64 tiles at a time (coalesced); first the ranges' totals, then the scan with the carry of the ranges before.
 __global__ __launch_bounds__(1024) void k_scan_tile_sums(uint64_t n_tiles, uint64_t *__restrict__ tile_sums, uint64_t *__restrict__ totals)
 {
-	__shared__ uint64_t lds_a[1024], lds_b[1024];
-	__shared__ uint64_t carry[2];
-	if (0 == threadIdx.x) { carry[0] = 0; carry[1] = 0; }
+	typedef unsigned long long __attribute__((ext_vector_type(2))) pair_t;
+	__shared__ uint64_t wave_a[16], wave_b[16];
+	uint32_t const lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	uint64_t const per = ((n_tiles + 15) / 16 + 63) / 64 * 64;		// tiles per wave, a multiple of 64
+	uint64_t const begin = per * w, end = (begin + per < n_tiles) ? (begin + per) : n_tiles;
+	pair_t const *in = (pair_t const *) tile_sums;
+	pair_t *out = (pair_t *) tile_sums;
+	uint64_t sa = 0, sb = 0;
+	for (uint64_t i = begin + lane; i < end; i += 64) { pair_t const v = in[i]; sa += v.x; sb += v.y; }
+	for (int off = 32; off; off >>= 1) { sa += __shfl_xor(sa, off); sb += __shfl_xor(sb, off); }
+	if (0 == lane) { wave_a[w] = sa; wave_b[w] = sb; }
 	__syncthreads();
-	for (uint64_t base = 0; base < n_tiles; base += 1024)
+	uint64_t ca = 0, cb = 0, ta = 0, tb = 0;
+	for (uint32_t i = 0; i < 16; ++i)
 	{
-		uint64_t const idx = base + threadIdx.x;
-		uint64_t va = (idx < n_tiles) ? tile_sums[2 * idx] : 0, vb = (idx < n_tiles) ? tile_sums[2 * idx + 1] : 0;
-		lds_a[threadIdx.x] = va; lds_b[threadIdx.x] = vb;
-		__syncthreads();
-		for (uint32_t off = 1; off < 1024; off <<= 1)	// Hillis-Steele inclusive scan
-		{
-			uint64_t ta = 0, tb = 0;
-			if (threadIdx.x >= off) { ta = lds_a[threadIdx.x - off]; tb = lds_b[threadIdx.x - off]; }
-			__syncthreads();
-			lds_a[threadIdx.x] += ta; lds_b[threadIdx.x] += tb;
-			__syncthreads();
-		}
-		if (idx < n_tiles)
-		{
-			tile_sums[2 * idx] = carry[0] + lds_a[threadIdx.x] - va;
-			tile_sums[2 * idx + 1] = carry[1] + lds_b[threadIdx.x] - vb;
-		}
-		__syncthreads();
-		if (1023 == threadIdx.x) { carry[0] += lds_a[1023]; carry[1] += lds_b[1023]; }
-		__syncthreads();
+		ca += (i < w) ? wave_a[i] : 0; cb += (i < w) ? wave_b[i] : 0;
+		ta += wave_a[i]; tb += wave_b[i];
 	}
-	if (0 == threadIdx.x) { totals[0] = carry[0]; totals[1] = carry[1]; }
+	for (uint64_t base = begin; base < end; base += 64)
+	{
+		uint64_t const i = base + lane;
+		pair_t v{0, 0};
+		if (i < end) v = in[i];
+		uint64_t ia = v.x, ib = v.y;
+#pragma unroll
+		for (uint32_t off = 1; off < 64; off <<= 1)
+		{
+			uint64_t const xa = __shfl_up(ia, off), xb = __shfl_up(ib, off);
+			if (lane >= off) { ia += xa; ib += xb; }
+		}
+		if (i < end) out[i] = pair_t{ca + ia - v.x, cb + ib - v.y};
+		ca += __shfl(ia, 63); cb += __shfl(ib, 63);
+	}
+	if (0 == threadIdx.x) { totals[0] = ta; totals[1] = tb; }
 }
 
 // Exclusive prefix of v over the block's threads (v of thread t counts before those of thread t + 1); `total` = block sum.
@@ -147,54 +194,90 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *l
 
 // Offsets of every record's operations / runs in the packed arrays (exclusive scan, tile prefix from k_scan_tile_sums) and,
 // in the same pass, the copy of the operations and runs out of the arenas.  (The status output is the projection kernels'
-// flag array itself: every record ends with its PVC3_ST_* value there.)  Thread t of a tile owns records
-// base + 256 i + t: descriptor loads are coalesced and neighbouring lanes copy neighbouring pieces of the arenas.
-__global__ __launch_bounds__(SCAN_THREADS) void k_offsets_gather(uint64_t n, dev_batch_work const W, dev_batch_packed const P, uint64_t const *__restrict__ tile_sums, uint64_t const *__restrict__ totals)
+// flag array itself: every record ends with its PVC3_ST_* value there.)
+__global__ __launch_bounds__(SCAN_THREADS) void k_offsets_gather(uint64_t n, dev_batch_work const W, dev_batch_packed const P, uint64_t const *__restrict__ tile_sums, uint64_t const *__restrict__ super_sums, uint64_t const *__restrict__ totals)
 {
 	__shared__ uint64_t lds[8];
-	__shared__ uint32_t stage[GATHER_STAGE];		// the operations of 256 records, in output order
-	uint64_t const base = (uint64_t) blockIdx.x * SCAN_TILE;
-	uint64_t carry_a = tile_sums[2 * (uint64_t) blockIdx.x], carry_b = tile_sums[2 * (uint64_t) blockIdx.x + 1];
-	for (uint32_t i = 0; i < SCAN_ITEMS; ++i)
+	__shared__ uint32_t stage[GATHER_STAGE];		// the operations of the tile, in output order
+	uint64_t const first = (uint64_t) blockIdx.x * SCAN_TILE + SCAN_ITEMS * threadIdx.x;
+	uint64_t const carry_a = tile_sums[2 * (uint64_t) blockIdx.x] + super_sums[2 * (uint64_t) (blockIdx.x / SUPER_TILES)];
+	uint64_t const carry_b = tile_sums[2 * (uint64_t) blockIdx.x + 1] + super_sums[2 * (uint64_t) (blockIdx.x / SUPER_TILES) + 1];
+	bool const whole = first + SCAN_ITEMS <= n;
+	u32x4_t const vc = load_counts(W.cig_n, first, n), vr = load_counts(W.run_n, first, n);
+	uint32_t const nc[SCAN_ITEMS] = {vc.x, vc.y, vc.z, vc.w}, nr[SCAN_ITEMS] = {vr.x, vr.y, vr.z, vr.w};
+	uint64_t loc[SCAN_ITEMS] = {0, 0, 0, 0};
+	if (whole)
 	{
-		uint64_t const rec = base + (uint64_t) i * SCAN_THREADS + threadIdx.x;
-		bool const valid = rec < n;
-		uint32_t const nc = valid ? W.cig_n[rec] : 0, nr = valid ? W.run_n[rec] : 0;
-		uint64_t const loc = valid ? W.cig_loc[rec] : 0;
-		uint64_t total_a, total_b;
-		uint64_t const local_a = block_exclusive_scan(nc, lds, total_a);
-		uint64_t const off_a = carry_a + local_a;
-		uint64_t const off_b = carry_b + block_exclusive_scan(nr, lds, total_b);
-		// The operations of these 256 records form one contiguous piece of the output: every thread drops its own few into
-		// LDS, then the block writes the piece with coalesced stores (pieces that do not fit are written directly).
-		bool const staged = total_a <= GATHER_STAGE;
-		if (valid)
-		{
-			P.out_cigar_off[rec] = off_a;
-			P.run_off[rec] = off_b;
-			uint32_t const *src = W.arena + loc;
-			if (staged)
-				for (uint32_t k = 0; k < nc; ++k) stage[local_a + k] = src[k];
-			else
-			{
-				uint32_t *dst = P.out_cigar + off_a;
-				for (uint32_t k = 0; k < nc; ++k) dst[k] = src[k];
-			}
-			if (nr)
-			{
-				pvc3_run const *rs = W.runs_arena + W.run_loc[rec];
-				pvc3_run *rd = P.runs + off_b;
-				for (uint32_t k = 0; k < nr; ++k) rd[k] = rs[k];
-			}
-		}
+		u64x2_t const l0 = *(u64x2_t const *) (W.cig_loc + first), l1 = *(u64x2_t const *) (W.cig_loc + first + 2);
+		loc[0] = l0.x; loc[1] = l0.y; loc[2] = l1.x; loc[3] = l1.y;
+	}
+	else
+		for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+			if (first + k < n) loc[k] = W.cig_loc[first + k];
+	// The first four operations of every record with one 16-byte load (the arena is padded): most records have no more.
+	u32x4_t head[SCAN_ITEMS];
+#pragma unroll
+	for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+	{
+		head[k] = u32x4_t{0, 0, 0, 0};
+		if (nc[k]) __builtin_memcpy(&head[k], W.arena + loc[k], 16);
+	}
+
+	uint64_t total_a, total_b;
+	uint64_t const mine_a = (uint64_t) nc[0] + nc[1] + nc[2] + nc[3], mine_b = (uint64_t) nr[0] + nr[1] + nr[2] + nr[3];
+	uint64_t const local_a = block_exclusive_scan(mine_a, lds, total_a);
+	uint64_t const local_b = block_exclusive_scan(mine_b, lds, total_b);
+	uint64_t off_a[SCAN_ITEMS + 1], off_b[SCAN_ITEMS + 1];
+	off_a[0] = carry_a + local_a; off_b[0] = carry_b + local_b;
+#pragma unroll
+	for (uint32_t k = 0; k < SCAN_ITEMS; ++k) { off_a[k + 1] = off_a[k] + nc[k]; off_b[k + 1] = off_b[k] + nr[k]; }
+	if (whole)
+	{
+		*(u64x2_t *) (P.out_cigar_off + first) = u64x2_t{off_a[0], off_a[1]}; *(u64x2_t *) (P.out_cigar_off + first + 2) = u64x2_t{off_a[2], off_a[3]};
+		*(u64x2_t *) (P.run_off + first) = u64x2_t{off_b[0], off_b[1]}; *(u64x2_t *) (P.run_off + first + 2) = u64x2_t{off_b[2], off_b[3]};
+	}
+	else
+		for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+			if (first + k < n) { P.out_cigar_off[first + k] = off_a[k]; P.run_off[first + k] = off_b[k]; }
+
+	// The operations of the tile's records form one contiguous piece of the output: every thread drops its own into LDS,
+	// then the block writes the piece with coalesced stores (a piece that does not fit is written directly).
+	bool const staged = total_a <= GATHER_STAGE;
+#pragma unroll
+	for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+	{
+		uint32_t const cnt = nc[k];
+		if (0 == cnt) continue;
+		uint32_t const h[4] = {head[k].x, head[k].y, head[k].z, head[k].w};
+		uint32_t const *src = W.arena + loc[k];
 		if (staged)
 		{
-			__syncthreads();
-			for (uint32_t j = threadIdx.x; j < (uint32_t) total_a; j += SCAN_THREADS)
-				P.out_cigar[carry_a + j] = stage[j];
-			__syncthreads();
+			uint32_t *dst = stage + (off_a[k] - carry_a);
+#pragma unroll
+			for (uint32_t x = 0; x < 4; ++x) if (x < cnt) dst[x] = h[x];
+			for (uint32_t x = 4; x < cnt; ++x) dst[x] = src[x];
 		}
-		carry_a += total_a; carry_b += total_b;
+		else
+		{
+			uint32_t *dst = P.out_cigar + off_a[k];
+#pragma unroll
+			for (uint32_t x = 0; x < 4; ++x) if (x < cnt) dst[x] = h[x];
+			for (uint32_t x = 4; x < cnt; ++x) dst[x] = src[x];
+		}
+	}
+	if (mine_b)
+		for (uint32_t k = 0; k < SCAN_ITEMS; ++k)
+			if (nr[k])
+			{
+				pvc3_run const *rs = W.runs_arena + W.run_loc[first + k];
+				pvc3_run *rd = P.runs + off_b[k];
+				for (uint32_t x = 0; x < nr[k]; ++x) rd[x] = rs[x];
+			}
+	if (staged)
+	{
+		__syncthreads();
+		for (uint32_t j = threadIdx.x; j < (uint32_t) total_a; j += SCAN_THREADS)
+			P.out_cigar[carry_a + j] = stage[j];
 	}
 	if (0 == blockIdx.x && 0 == threadIdx.x) { P.out_cigar_off[n] = totals[0]; P.run_off[n] = totals[1]; }
 }
@@ -338,20 +421,22 @@ int launch_window_text4(uint8_t const *text4, uint64_t n_lines, uint8_t *out, vo
 	return (int) hipGetLastError();
 }
 
+// scan_tmp: [2 per tile][2 per super-tile][2 totals]
 uint64_t pack_scan_tmp_words(uint64_t n)
 {
-	return 2 * ((n + SCAN_TILE - 1) / SCAN_TILE) + 2 + 2;
+	uint64_t const n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE, n_super = (n_tiles + SUPER_TILES - 1) / SUPER_TILES;
+	return 2 * n_tiles + 2 * n_super + 2 + 2;
 }
 
 int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &packed, uint64_t *scan_tmp, void *stream)
 {
-	uint64_t const n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-	uint64_t *totals = scan_tmp + 2 * n_tiles + 2;
+	uint64_t const n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE, n_super = (n_tiles + SUPER_TILES - 1) / SUPER_TILES;
+	uint64_t *super_sums = scan_tmp + 2 * n_tiles, *totals = super_sums + 2 * n_super;
 	hipStream_t const s = (hipStream_t) stream;
-	if (n_tiles)
-		hipLaunchKernelGGL(k_scan_tiles, dim3((uint32_t) n_tiles), dim3(SCAN_THREADS), 0, s, n, work.cig_n, work.run_n, scan_tmp);
-	hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, s, n_tiles, scan_tmp, totals);
-	hipLaunchKernelGGL(k_offsets_gather, dim3((uint32_t) (n_tiles ? n_tiles : 1)), dim3(SCAN_THREADS), 0, s, n, work, packed, scan_tmp, totals);
+	if (n_super)
+		hipLaunchKernelGGL(k_scan_tiles, dim3((uint32_t) n_super), dim3(SCAN_THREADS), 0, s, n, n_tiles, work.cig_n, work.run_n, scan_tmp, super_sums);
+	hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, s, n_super, super_sums, totals);
+	hipLaunchKernelGGL(k_offsets_gather, dim3((uint32_t) (n_tiles ? n_tiles : 1)), dim3(SCAN_THREADS), 0, s, n, work, packed, scan_tmp, super_sums, totals);
 	return (int) hipGetLastError();
 }
 

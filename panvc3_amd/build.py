@@ -133,7 +133,7 @@ def build_host(force=False, verbose=False):
 
 
 def build_cpp_tests(force=False, verbose=False):
-	"""tests/cpp/*.cpp: programs that use the C++ mirror header include/pvc3.hpp (they link libpvc3_hip.so)."""
+	"""tests/cpp/*.cpp: programs that use the C++ mirror header include/pvc3.hpp (they link libpvc3_hip.so) or a header of the host pipeline."""
 	build(force=False, verbose=verbose)
 	src_dir = os.path.join(HERE, "..", "tests", "cpp")
 	os.makedirs(BIN, exist_ok=True)
@@ -144,9 +144,10 @@ def build_cpp_tests(force=False, verbose=False):
 		src = os.path.join(src_dir, name)
 		dst = os.path.join(BIN, "test_" + os.path.splitext(name)[0])
 		out.append(dst)
-		cmd = [os.environ.get("CXX", "g++"), "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(HERE, "..", "include"), "-o", dst, src,
+		cmd = [os.environ.get("CXX", "g++"), "-O2", "-g", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(HERE, "..", "include"), "-o", dst, src,
 			   "-L" + HERE, "-lpvc3_hip", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]
-		key = _key([src, os.path.join(HERE, "..", "include", "pvc3.hpp"), os.path.join(HERE, "..", "include", "pvc3.h"), os.path.join(OBJ, "libpvc3_hip.so.key")], cmd[1:])
+		host_headers = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp"))
+		key = _key([src, os.path.join(HERE, "..", "include", "pvc3.hpp"), os.path.join(HERE, "..", "include", "pvc3.h"), os.path.join(OBJ, "libpvc3_hip.so.key")] + host_headers, cmd[1:])
 		if force or _stale(dst, key):
 			if verbose:
 				print(" ".join(cmd), file=sys.stderr)

@@ -10,9 +10,12 @@
 #include <stdexcept>
 #include <algorithm>
 #include <exception>
+#include <future>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include "fast_deflate.hpp"
 
 namespace pvc3host {
 
@@ -58,9 +61,13 @@ class byte_reader
 	unsigned m_threads{1};
 	std::vector <uint8_t> m_cbuf;		// compressed bytes not yet inflated (whole blocks + a partial tail)
 	std::size_t m_clen{};
-	std::vector <uint8_t> m_dbuf;		// inflated bytes
+	// Inflated bytes: the piece being consumed and the next one, which a second thread reads and inflates meanwhile.
+	struct piece { std::vector <uint8_t> data; std::size_t len{}; };
+	piece m_cur, m_next;
 	std::size_t m_dpos{};
 	bool m_eof{};
+	bool m_started{};
+	std::future <bool> m_ahead;
 
 	static constexpr std::size_t CHUNK = 32u << 20;
 
@@ -86,10 +93,11 @@ class byte_reader
 		throw io_error("corrupt BGZF stream (no BC field)");
 	}
 
-	bool refill()
+	// The next piece of the file into `dst` (false at the end); touches only m_raw, m_cbuf, m_clen and m_eof.
+	bool produce(piece &dst)
 	{
-		m_dbuf.clear(); m_dpos = 0;
-		while (m_dbuf.empty())
+		dst.len = 0;
+		while (0 == dst.len)
 		{
 			if (!m_eof)
 			{
@@ -117,23 +125,43 @@ class byte_reader
 				if (m_eof) { if (m_clen) throw io_error("truncated BGZF stream"); return false; }
 				continue;
 			}
-			m_dbuf.resize(out);
+			if (dst.data.size() < out) dst.data.resize(out);		// grows only: no zero-fill per piece
+			dst.len = out;
+			uint8_t *dbuf = dst.data.data();
 			parallel_for(blocks.size(), m_threads, [&](std::size_t i) {
 				block const &b = blocks[i];
 				if (0 == b.out_len) return;
 				z_stream zs{};
 				if (Z_OK != inflateInit2(&zs, -15)) throw io_error("inflateInit2 failed");
 				zs.next_in = m_cbuf.data() + b.in_off; zs.avail_in = (uInt) b.in_len;
-				zs.next_out = m_dbuf.data() + b.out_off; zs.avail_out = (uInt) b.out_len;
+				zs.next_out = dbuf + b.out_off; zs.avail_out = (uInt) b.out_len;
 				int const rc = inflate(&zs, Z_FINISH);
 				inflateEnd(&zs);
 				if (Z_STREAM_END != rc || zs.total_out != b.out_len) throw io_error("corrupt BGZF block");
-				if ((uint32_t) crc32(crc32(0L, Z_NULL, 0), m_dbuf.data() + b.out_off, (uInt) b.out_len) != b.crc) throw io_error("BGZF block checksum mismatch");
+				if ((uint32_t) crc32(crc32(0L, Z_NULL, 0), dbuf + b.out_off, (uInt) b.out_len) != b.crc) throw io_error("BGZF block checksum mismatch");
 			});
 			std::memmove(m_cbuf.data(), m_cbuf.data() + off, m_clen - off);
 			m_clen -= off;
-			if (m_dbuf.empty() && m_eof && 0 == m_clen) return false;		// only the EOF marker was left
+			if (0 == dst.len && m_eof && 0 == m_clen) return false;		// only the EOF marker was left
 		}
+		return true;
+	}
+
+	// Makes the piece read ahead the current one and starts reading the one after it.
+	bool refill()
+	{
+		m_cur.len = 0; m_dpos = 0;
+		if (!m_started)
+		{
+			m_started = true;
+			m_ahead = std::async(std::launch::async, [this]() { return produce(m_next); });
+		}
+		if (!m_ahead.valid())
+			return false;
+		if (!m_ahead.get())		// rethrows what the reading thread threw
+			return false;
+		std::swap(m_cur, m_next);
+		m_ahead = std::async(std::launch::async, [this]() { return produce(m_next); });
 		return true;
 	}
 
@@ -161,7 +189,7 @@ public:
 			if (bgzf)
 			{
 				std::rewind(f);
-				m_raw = f; m_clen = 0; m_eof = false; m_dbuf.clear(); m_dpos = 0;
+				m_raw = f; m_clen = 0; m_eof = false; m_cur.len = 0; m_dpos = 0; m_started = false;
 				return;
 			}
 			std::fclose(f);
@@ -174,6 +202,7 @@ public:
 
 	void close()
 	{
+		if (m_ahead.valid()) { try { (void) m_ahead.get(); } catch (...) {} }
 		if (m_file) { gzclose(m_file); m_file = nullptr; }
 		if (m_raw) { std::fclose(m_raw); m_raw = nullptr; }
 	}
@@ -186,9 +215,9 @@ public:
 		{
 			while (got < n)
 			{
-				if (m_dpos == m_dbuf.size() && !refill()) break;
-				std::size_t const take = std::min(n - got, m_dbuf.size() - m_dpos);
-				std::memcpy((char *) dst + got, m_dbuf.data() + m_dpos, take);
+				if (m_dpos == m_cur.len && !refill()) break;
+				std::size_t const take = std::min(n - got, m_cur.len - m_dpos);
+				std::memcpy((char *) dst + got, m_cur.data.data() + m_dpos, take);
 				m_dpos += take; got += take;
 			}
 			return got;
@@ -213,10 +242,10 @@ public:
 			bool any = false;
 			for (;;)
 			{
-				if (m_dpos == m_dbuf.size() && !refill()) break;
+				if (m_dpos == m_cur.len && !refill()) break;
 				any = true;
-				uint8_t const *b = m_dbuf.data() + m_dpos;
-				std::size_t const left = m_dbuf.size() - m_dpos;
+				uint8_t const *b = m_cur.data.data() + m_dpos;
+				std::size_t const left = m_cur.len - m_dpos;
 				uint8_t const *nl = (uint8_t const *) std::memchr(b, '\n', left);
 				if (nl)
 				{
@@ -250,8 +279,8 @@ public:
 	{
 		if (m_raw)
 		{
-			if (m_dpos == m_dbuf.size() && !refill()) return -1;
-			return m_dbuf[m_dpos];
+			if (m_dpos == m_cur.len && !refill()) return -1;
+			return m_cur.data[m_dpos];
 		}
 		int const c = gzgetc(m_file);
 		if (c >= 0) gzungetc(c, m_file);
@@ -266,7 +295,7 @@ class byte_writer
 	FILE *m_file{};
 	bool m_owns{};
 	bool m_bgzf{};
-	int m_level{6};
+	int m_level{-1};
 	unsigned m_threads{1};
 	std::vector <uint8_t> m_pending;	// uncompressed bytes not yet written
 	std::vector <std::vector <uint8_t>> m_out;
@@ -279,18 +308,30 @@ class byte_writer
 			throw io_error("write error");
 	}
 
-	// BGZF block = gzip member with the BC extra field (SAMv1 §4.1.1).
+	// BGZF block = gzip member with the BC extra field (SAMv1 §4.1.1).  Level < 0: the built-in encoder (fast_deflate.hpp),
+	// otherwise zlib at that level.
 	void deflate_block(uint8_t const *src, std::size_t len, std::vector <uint8_t> &out) const
 	{
-		out.resize(18 + compressBound((uLong) len) + 8);
-		z_stream zs{};
-		if (Z_OK != deflateInit2(&zs, m_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY))
-			throw io_error("deflateInit2 failed");
-		zs.next_in = const_cast <uint8_t *>(src); zs.avail_in = (uInt) len;
-		zs.next_out = out.data() + 18; zs.avail_out = (uInt) (out.size() - 18 - 8);
-		if (Z_STREAM_END != deflate(&zs, Z_FINISH)) { deflateEnd(&zs); throw io_error("deflate failed"); }
-		std::size_t const clen = zs.total_out;
-		deflateEnd(&zs);
+		std::size_t clen = 0;
+		if (m_level < 0)
+		{
+			thread_local fast_deflater enc;
+			out.resize(18 + fast_deflater::bound(len) + 8);
+			clen = enc.compress(src, len, out.data() + 18, out.size() - 18 - 8);
+			if (0 == clen) throw io_error("deflate failed");
+		}
+		else
+		{
+			out.resize(18 + compressBound((uLong) len) + 8);
+			z_stream zs{};
+			if (Z_OK != deflateInit2(&zs, m_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY))
+				throw io_error("deflateInit2 failed");
+			zs.next_in = const_cast <uint8_t *>(src); zs.avail_in = (uInt) len;
+			zs.next_out = out.data() + 18; zs.avail_out = (uInt) (out.size() - 18 - 8);
+			if (Z_STREAM_END != deflate(&zs, Z_FINISH)) { deflateEnd(&zs); throw io_error("deflate failed"); }
+			clen = zs.total_out;
+			deflateEnd(&zs);
+		}
 		std::size_t const bsize = 18 + clen + 8;
 		static uint8_t const head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
 		std::memcpy(out.data(), head, 16);
@@ -332,7 +373,7 @@ public:
 
 	void set_threads(unsigned n) { m_threads = n ? n : 1; }
 
-	void open(char const *path, bool bgzf, int level = 6)		// nullptr or "-" = stdout
+	void open(char const *path, bool bgzf, int level = -1)		// nullptr or "-" = stdout
 	{
 		close();
 		m_bgzf = bgzf; m_level = level;

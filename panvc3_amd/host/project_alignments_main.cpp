@@ -57,7 +57,7 @@ struct options
 	bool bam_input{}, output_bam{}, keep_duplicate_ranges{}, print_invocation{}, print_pid{}, io_only{}, debugging_output{};
 	std::vector <std::string> preserve_tags;
 	std::string rname_tag{"XR"}, pos_tag{"XP"}, rnext_tag{"YR"}, pnext_tag{"YP"}, query_ranges_tag{"XB"}, ref_ranges_tag{"YB"}, rec_idx_tag;
-	int gap_open{0}, gap_ext{-1}, compression_level{6};
+	int gap_open{0}, gap_ext{-1}, compression_level{-1};
 	long status_interval{5};			// --status-output-interval, minutes; 0 disables
 	std::vector <int> devices{0};		// --device / --devices: batches go to the GPUs in turn, output stays in input order
 	uint64_t batch_size{UINT64_C(1) << 18};		// records per GPU batch: small enough for reading, projecting and writing of consecutive batches to overlap
@@ -87,7 +87,7 @@ void usage()
 		"      --device=INT                     GPU to use (default 0)\n"
 		"      --devices=LIST                   GPUs to use, e.g. 0,1,2,3: batches go to them in turn (output order = input order)\n"
 		"      --threads=INT                    host threads for (de)compression, parsing and rewriting\n"
-		"      --compression-level=0..9         BGZF level of BAM output (default 6)\n";
+		"      --compression-level=-1..9        BAM output: -1 (default) the built-in fast deflate encoder, 0..9 zlib at that level\n";
 }
 
 // process_headers (project_alignments.cc:1092-1253)
@@ -244,7 +244,7 @@ int main(int argc, char **argv)
 				if (opt.devices.empty()) die("--devices expects a comma-separated list of GPU numbers");
 				break;
 			}
-			case 1017: opt.compression_level = std::max(0, std::min(9, std::atoi(optarg))); break;
+			case 1017: opt.compression_level = std::max(-1, std::min(9, std::atoi(optarg))); break;
 			case 1013: opt.batch_size = std::strtoull(optarg, nullptr, 10); break;
 			case 1014: opt.io_only = true; break;
 			case 1015: opt.threads = (unsigned) std::max(1, std::atoi(optarg)); break;

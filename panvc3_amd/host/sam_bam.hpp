@@ -623,7 +623,7 @@ class alignment_writer
 public:
 	void set_threads(unsigned n) { m_out.set_threads(n); }
 
-	void open(char const *path, bool bam, sam_header const &hdr, int compression_level = 6)
+	void open(char const *path, bool bam, sam_header const &hdr, int compression_level = -1)
 	{
 		m_is_bam = bam; m_header = &hdr;
 		m_out.open(path, bam, compression_level);

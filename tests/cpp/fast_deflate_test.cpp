@@ -1,0 +1,31 @@
+// Test driver for panvc3_amd/host/fast_deflate.hpp: stdin -> one raw DEFLATE stream per 65 280-byte piece on stdout, each
+// preceded by its length as a 4-byte little-endian integer (tests/test_fast_deflate.py inflates them with zlib).
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#include "../../panvc3_amd/host/fast_deflate.hpp"
+
+int main()
+{
+	std::vector <uint8_t> in;
+	uint8_t buf[1 << 16];
+	for (std::size_t got; (got = std::fread(buf, 1, sizeof(buf), stdin)) > 0; )
+		in.insert(in.end(), buf, buf + got);
+	pvc3host::fast_deflater enc;
+	std::size_t const piece = 0xff00;
+	std::size_t off = 0;
+	do
+	{
+		std::size_t const n = std::min(piece, in.size() - off);
+		std::vector <uint8_t> out(pvc3host::fast_deflater::bound(n));
+		std::size_t const c = enc.compress(in.data() + off, n, out.data(), out.size());
+		if (0 == c) return 1;
+		uint32_t const len = (uint32_t) c;
+		std::fwrite(&len, 4, 1, stdout);
+		std::fwrite(out.data(), 1, c, stdout);
+		off += n;
+	}
+	while (off < in.size());
+	return 0;
+}

@@ -203,81 +203,105 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 			uint32_t const r0 = W.dst_pos[rec];
 			(void) src_pos;
 			uint32_t col = col0, r = r0, q = 0, steps = 0;
+			// The two rows' gap words, from the paired copy (one 128-byte line for both) when the destination is the source's
+			// partner.  The words of the NEXT 64 columns are requested a step ahead: a step ends at a word boundary or inside
+			// the same word, so the walk never waits for a gap word of its own.
+			row_pair const rows = rows_of(S, D, in.dst_entry[rec]);
+			auto gap_words = [&](uint32_t first_col, uint64_t &sw_out, uint64_t &dw_out) {
+				col_pos const pp = locate(rows.src.step, first_col);
+				uint64_t const wi = (uint64_t) pp.blk * rows.src.stride + 1 + pp.w;
+				sw_out = rows.src.blocks[wi]; dw_out = rows.dst.blocks[wi];
+			};
+			uint32_t have_col = col0 & ~63u;			// first column of the words in (sw, dw); those of have_col + 64 are in (sw_next, dw_next)
+			uint64_t sw = 0, dw = 0, sw_next = 0, dw_next = 0;
+			gap_words(have_col, sw, dw);
+			gap_words(have_col + 64, sw_next, dw_next);
 
 			typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 			u32x4 pre;
 			__builtin_memcpy(&pre, ops, 16);			// the CIGAR buffer is padded by the host side
-			for (uint32_t ci = 0; ci < n_cigar && !punt && PVC3_ST_OK == status; ++ci)
+			// One loop over 64-column steps, whatever operation a lane is in: a lane that finishes an operation takes its next
+			// one in the same iteration.  (A loop over the operations with a loop over the steps inside makes the wave run the
+			// inner loop once per operation INDEX: a record with a leading soft clip has its M steps one index later than the
+			// others, and every lane then waits through both rounds.)
+			uint32_t ci = 0, n_rem = 0;
+			bool m_type = false;
+			for (;;)
 			{
-				uint32_t const c = (0 == ci) ? pre.x : (1 == ci) ? pre.y : (2 == ci) ? pre.z : (3 == ci) ? pre.w : ops[ci];
-				uint32_t const op = c & 0xf;
-				uint32_t n_rem = c >> 4;
-				if (OP_I == op || OP_S == op)		// rewrite_cigar.hh:69-73
+				while (0 == n_rem && ci < n_cigar)
 				{
-					out.push(op, n_rem);
-					q += n_rem;
-					continue;
+					uint32_t const c = (0 == ci) ? pre.x : (1 == ci) ? pre.y : (2 == ci) ? pre.z : (3 == ci) ? pre.w : ops[ci];
+					++ci;
+					uint32_t const op = c & 0xf, cnt = c >> 4;
+					if (OP_I == op || OP_S == op) { out.push(op, cnt); q += cnt; }		// rewrite_cigar.hh:69-73
+					else if (OP_H == op || OP_P == op) out.push(op, cnt);				// :75-78
+					else { m_type = !(OP_D == op || OP_N == op); n_rem = cnt; }			// M = X (:80-118) vs D N (:121-147)
 				}
-				if (OP_H == op || OP_P == op)		// :75-78
+				if (0 == n_rem) break;
+				if (++steps > MID_MAX_STEPS) { punt = true; break; }
+				if ((col & ~63u) != have_col)
 				{
-					out.push(op, n_rem);
-					continue;
+					have_col += 64;
+					sw = sw_next; dw = dw_next;
+					gap_words(have_col + 64, sw_next, dw_next);
 				}
-				bool const m_type = !(OP_D == op || OP_N == op);	// M = X (:80-118) vs D N (:121-147)
-				while (n_rem)
+				col_pos p;
+				p.bit = col & 63;
+				uint64_t const ge = ~UINT64_C(0) << p.bit;
+				uint64_t const z = ~sw & ge;				// source non-gap columns at or after col
+				uint32_t const nz = popc64(z);
+				uint64_t act;								// columns handled in this step
+				uint32_t consumed;
+				uint32_t const word_col = col - p.bit;
+				if (nz >= n_rem)
 				{
-					if (++steps > MID_MAX_STEPS) { punt = true; break; }
-					col_pos const p = split_col(col);
-					uint64_t const wi = (uint64_t) p.blk * BLOCK_WORDS + 1 + p.w;
-					uint64_t const sw = S.blocks[wi], dw = D.blocks[wi];
-					uint64_t const ge = ~UINT64_C(0) << p.bit;
-					uint64_t const z = ~sw & ge;				// source non-gap columns at or after col
-					uint32_t const nz = popc64(z);
-					uint64_t act;								// columns handled in this step
-					uint32_t consumed;
-					uint32_t const word_col = col - p.bit;
-					if (nz >= n_rem)
-					{
-						uint32_t const e = thread_select_in_word(z, n_rem - 1);	// last base of this operation
-						act = ge & low_mask(e + 1);
-						consumed = n_rem;
-						col = word_col + e + 1;
-					}
-					else
-					{
-						act = ge;
-						consumed = nz;
-						col = word_col + 64;
-					}
-					uint64_t const dz = ~dw & act;				// destination non-gap columns
-					uint64_t const Z = z & act;					// consumed source bases
-					uint64_t const G = sw & act;				// source gaps in between
-					uint32_t const nd = popc64(dz);
-					uint64_t mE = 0, mX = 0, mI, mD;
-					if (m_type)
-					{
-						mI = Z & ~dz;							// dst gap: match becomes insertion (:93-98)
-						mD = G & dz;							// dst characters between source bases: deletion (:90-91)
-						uint64_t const mC = Z & dz;				// compare query with the dst text (:99-113)
-						if (mC)
-						{
-							uint32_t const hi = 63 - (uint32_t) __builtin_clzll(mC);
-							uint32_t const max_ri = r + popc64(dz & low_mask(hi));
-							if (!D.text4 || max_ri >= D.text_len) { status = PVC3_ST_REF_RANGE; break; }
-							mX = short_runs ? compare_columns_pieces(mC, Z, dz, q, r, seq, D.text4) : compare_columns(mC, Z, dz, q, r, seq, D.text4);
-							mE = mC & ~mX;
-						}
-						q += consumed;
-					}
-					else
-					{
-						mI = 0;
-						mD = dz;								// (:133-137) kept where dst has a character, dropped otherwise
-					}
-					emit_tokens_lane(out, mE, mX, mI, mD);
-					r += nd;
-					n_rem -= consumed;
+					uint32_t const e = thread_select_in_word(z, n_rem - 1);	// last base of this operation
+					act = ge & low_mask(e + 1);
+					consumed = n_rem;
+					col = word_col + e + 1;
 				}
+				else
+				{
+					act = ge;
+					consumed = nz;
+					col = word_col + 64;
+				}
+				uint64_t const dz = ~dw & act;				// destination non-gap columns
+				uint64_t const Z = z & act;					// consumed source bases
+				uint64_t const G = sw & act;				// source gaps in between
+				uint32_t const nd = popc64(dz);
+				uint64_t mE = 0, mX = 0, mI, mD;
+				if (m_type)
+				{
+					mI = Z & ~dz;							// dst gap: match becomes insertion (:93-98)
+					mD = G & dz;							// dst characters between source bases: deletion (:90-91)
+					uint64_t const mC = Z & dz;				// compare query with the dst text (:99-113)
+					if (mC)
+					{
+						uint32_t const hi = 63 - (uint32_t) __builtin_clzll(mC);
+						uint32_t const max_ri = r + popc64(dz & low_mask(hi));
+						if (!D.text4 || max_ri >= D.text_len) { status = PVC3_ST_REF_RANGE; break; }
+#if defined(PVC3_ABL_MID_NO_COMPARE)
+						mX = 0;
+#elif defined(PVC3_ABL_MID_PIECES)
+						mX = compare_columns_pieces(mC, Z, dz, q, r, seq, D.text4);
+#else
+						mX = short_runs ? compare_columns_pieces(mC, Z, dz, q, r, seq, D.text4) : compare_columns(mC, Z, dz, q, r, seq, D.text4);
+#endif
+						mE = mC & ~mX;
+					}
+					q += consumed;
+				}
+				else
+				{
+					mI = 0;
+					mD = dz;								// (:133-137) kept where dst has a character, dropped otherwise
+				}
+#ifndef PVC3_ABL_MID_NO_EMIT
+				emit_tokens_lane(out, mE, mX, mI, mD);
+#endif
+				r += nd;
+				n_rem -= consumed;
 			}
 			out.finish();
 			punt = punt || (out.n_out > MID_TOKENS);

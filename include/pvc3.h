@@ -190,9 +190,12 @@ PVC3_API int pvc3_context_synchronize(pvc3_context *ctx);
  * alignment scratch slots together never exceed it), "trace_initial" (32-bit words of the alignment trace buffer), "arena_initial", "runs_initial",
  * "fast_path" (0: no lane-parallel compare in k_project_fast), "mid_path" (0: skip k_project_mid; with both at 0 every
  * record goes through the cooperative column walk of k_project_general), "packed_dp" (0: every indel run is aligned by the
- * striped one-run-per-wavefront kernel instead of the packed kernels). */
+ * striped one-run-per-wavefront kernel instead of the packed kernels); and two that take effect at the next
+ * pvc3_context_upload_index: "paired_blocks" (1: every entry's bit-vector blocks are also stored side by side with those of
+ * the entry it is projected to, one 128-byte HBM line for both rows), "text_window" (1: the packed reference texts are
+ * also stored as overlapping 128-byte lines, one line per read of up to 150 bases); both default to 1 and cost HBM only. */
 PVC3_API int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value);
-/* Replicates the index (bit-vector blocks, select samples, reference texts) into this context's HBM. */
+/* Replicates the index (bit-vector blocks, select samples, reference texts, and the two copies above) into this context's HBM. */
 PVC3_API int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx);
 PVC3_API int pvc3_context_hbm_bytes(pvc3_context const *ctx, uint64_t *index_bytes, uint64_t *workspace_bytes);
 

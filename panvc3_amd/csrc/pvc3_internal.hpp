@@ -23,8 +23,11 @@ constexpr uint32_t BLOCK_DATA_WORDS = 7;
 constexpr uint32_t BLOCK_COLS = 448;
 constexpr uint32_t PAD_BLOCKS = 2;
 constexpr uint32_t DIR_SHIFT = 32, DIR_BITS = 9;	// directory fields of word 0: zeros before pair p (1, 2, 3) at bit 32 + 9 (p - 1)
-constexpr uint32_t SELECT_SAMPLE = 4096;	// one select sample per 4096 non-gap columns: the table (4 B per 4096 bases) stays cache resident
-constexpr uint32_t SELECT_SAMPLE_SHIFT = 12;
+#ifndef PVC3_SELECT_SHIFT
+#define PVC3_SELECT_SHIFT 12
+#endif
+constexpr uint32_t SELECT_SAMPLE_SHIFT = PVC3_SELECT_SHIFT;
+constexpr uint32_t SELECT_SAMPLE = 1u << SELECT_SAMPLE_SHIFT;	// one select sample per that many non-gap columns
 constexpr uint32_t TEXT_PAD = 512;		// bytes readable past the end of a device text
 constexpr uint32_t TEXT_FRONT_PAD = 16;	// bytes readable before its start
 constexpr uint32_t TEXT4_FRONT = 16;		// packed text: nibbles in front of base 0 (base i = nibble i + TEXT4_FRONT, low nibble first)

@@ -147,6 +147,68 @@ __device__ __forceinline__ uint64_t compare_columns_pieces(uint64_t mC, uint64_t
 	return mX;
 }
 
+// ---- the compare from register windows --------------------------------------------------------------------------------------
+// A 64-column step consumes at most 64 query bases from q on and 64 text bases from r on, whatever its runs of compared
+// columns look like.  So the 80 nibbles of either side from the step's start are fetched ONE STEP AHEAD (the addresses
+// depend only on q and r, known when the previous step ends), and every run takes its 16-nibble pieces out of the two
+// register windows: no load depends on the step's own masks.
+struct win80
+{
+	uint64_t w[5];
+	uint32_t first;		// nibble number (in the byte string) of the window's first nibble: even
+};
+
+template <bool t_query>
+__device__ __forceinline__ win80 load_win(uint8_t const *bytes, uint64_t first)
+{
+	uint8_t const *p = bytes + (first >> 1);
+	u64x2 const a = load_u128_unaligned(p), b = load_u128_unaligned(p + 16);
+	uint64_t c;
+	__builtin_memcpy(&c, p + 32, 8);
+	win80 n;
+	n.w[0] = a.x; n.w[1] = a.y; n.w[2] = b.x; n.w[3] = b.y; n.w[4] = c;
+	if (t_query)		// SEQ stores the first base of a byte in the high nibble
+	{
+#pragma unroll
+		for (uint32_t i = 0; i < 5; ++i) n.w[i] = nibble_linear(n.w[i]);
+	}
+	n.first = (uint32_t) first & ~1u;
+	return n;
+}
+
+// 16 nibbles from nibble offset o (0 .. 79) of the window; what lies past the window reads as 0.
+__device__ __forceinline__ uint64_t win_extract16(win80 const &W, uint32_t o)
+{
+	uint32_t const wi = o >> 4, sh = (o & 15) * 4;
+	uint64_t lo = W.w[0], hi = W.w[1];
+	lo = (1 == wi) ? W.w[1] : lo; hi = (1 == wi) ? W.w[2] : hi;
+	lo = (2 == wi) ? W.w[2] : lo; hi = (2 == wi) ? W.w[3] : hi;
+	lo = (3 == wi) ? W.w[3] : lo; hi = (3 == wi) ? W.w[4] : hi;
+	lo = (4 == wi) ? W.w[4] : lo; hi = (4 <= wi) ? UINT64_C(0) : hi;
+	return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+}
+
+// Mismatch bits of the compared columns mC of one step, 16 columns at a time from the windows.  q_off / r_off: nibble offsets
+// in the windows of the step's first query base / first text base.  (Moving a whole window into place once per run — four
+// conditional dword stages and eight funnel shifts — and comparing 64 bases from it costs 129 VGPRs, three waves per SIMD:
+// slower on every configuration.)
+__device__ __forceinline__ uint64_t compare_columns_windows(uint64_t mC, uint64_t Z, uint64_t dz, uint32_t q_off, uint32_t r_off, win80 const &Q, win80 const &T)
+{
+	uint64_t mX = 0, left = mC;
+	while (left)
+	{
+		uint32_t const c0 = ctz64(left);
+		uint64_t const ones = ~(left >> c0);
+		uint32_t const run = ones ? ctz64(ones) : 64;
+		uint32_t const L = (run < 16) ? run : 16;
+		uint32_t const qo = q_off + popc64(Z & low_mask(c0)), ro = r_off + popc64(dz & low_mask(c0));
+		uint32_t const mm = mismatch16(win_extract16(Q, qo), win_extract16(T, ro)) & (uint32_t) low_mask(L);
+		mX |= (uint64_t) mm << c0;
+		left &= ~(low_mask(L) << c0);
+	}
+	return mX;
+}
+
 __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W)
 {
 	uint32_t const lane = lane_id();
@@ -226,6 +288,15 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 			// others, and every lane then waits through both rounds.)
 			uint32_t ci = 0, n_rem = 0;
 			bool m_type = false;
+			// Gap-dense rows (several short runs of compared columns per step): the compare works from register windows that
+			// are fetched a step ahead.  Otherwise a step has one long run and a load of its own for it is cheaper.
+			bool const windows = short_runs && nullptr != D.text4;
+			win80 qwin{}, twin{};
+			if (windows)
+			{
+				qwin = load_win <true>(seq, 0);
+				twin = load_win <false>(D.text4, (uint64_t) r0 + TEXT4_FRONT);
+			}
 			for (;;)
 			{
 				while (0 == n_rem && ci < n_cigar)
@@ -283,10 +354,15 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 						if (!D.text4 || max_ri >= D.text_len) { status = PVC3_ST_REF_RANGE; break; }
 #if defined(PVC3_ABL_MID_NO_COMPARE)
 						mX = 0;
-#elif defined(PVC3_ABL_MID_PIECES)
-						mX = compare_columns_pieces(mC, Z, dz, q, r, seq, D.text4);
 #else
-						mX = short_runs ? compare_columns_pieces(mC, Z, dz, q, r, seq, D.text4) : compare_columns(mC, Z, dz, q, r, seq, D.text4);
+						if (windows)
+						{
+							// Insertions / soft clips since the window was fetched move q inside it; past 14 bases it is fetched anew.
+							if (q - qwin.first > 14 + 1) qwin = load_win <true>(seq, q);
+							mX = compare_columns_windows(mC, Z, dz, q - qwin.first, r + TEXT4_FRONT - twin.first, qwin, twin);
+						}
+						else
+							mX = short_runs ? compare_columns_pieces(mC, Z, dz, q, r, seq, D.text4) : compare_columns(mC, Z, dz, q, r, seq, D.text4);
 #endif
 						mE = mC & ~mX;
 					}
@@ -302,6 +378,11 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 #endif
 				r += nd;
 				n_rem -= consumed;
+				if (windows)		// the windows of the next step
+				{
+					qwin = load_win <true>(seq, q);
+					twin = load_win <false>(D.text4, (uint64_t) r + TEXT4_FRONT);
+				}
 			}
 			out.finish();
 			punt = punt || (out.n_out > MID_TOKENS);

@@ -191,10 +191,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			// One select sample, then four probes (word 0 + one 16-byte pair of a block, wave.hpp) at the sample's guess for the
 			// start column and for the end column: both rows, all issued together.  A probe is fetched again when the guess
 			// did not hold (a gap column between the sample and the record).
-			uint32_t const guess = select_guess(s_sel, src_pos);
+			select_guess_t const sg = select_guess(s_sel, src_pos, ref_consumed);
+			uint32_t const guess = sg.col;
 			FAST_STAMP(2);		// select sample
 			uint32_t const step = rows.src.step;
-			col_pos const g0 = locate(step, guess), g1 = locate_in(step, guess + ref_consumed, g0.blk);
+			col_pos const g0 = locate(step, guess), g1 = locate_in(step, (sg.end < s_cols) ? sg.end : s_cols, g0.blk);		// (an interpolated guess may pass the last column)
 			dir_probe const ps0 = dir_load(rows.src, g0.blk, pair_of(g0));
 			dir_probe const pd0 = dir_load(rows.dst, g0.blk, pair_of(g0));
 			dir_probe const ps1 = dir_load(rows.src, g1.blk, pair_of(g1));

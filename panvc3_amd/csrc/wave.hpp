@@ -307,12 +307,20 @@ __device__ __forceinline__ uint32_t dir_rank(row_view const &v, dir_probe p, col
 	return r;
 }
 
-// Column of non-gap number pos (0-based, < n_zeros).  `p` is a probe of a block that does not start past the target
-// (rank word <= pos), normally the block and pair of the select sample's guess.
+// Column of non-gap number pos (0-based, < n_zeros).  `p` is a probe of any block, normally the block and pair of the select
+// samples' guess.
 __device__ __forceinline__ uint32_t dir_select0(row_view const &v, uint32_t pos, dir_probe p)
 {
 	for (;;)
 	{
+		if ((uint32_t) p.head > pos)
+		{
+			// The probe lies past the target (an interpolated guess can): head - pos non-gap columns, so at least that many
+			// columns, separate the target from this block's first column.
+			uint32_t const back = (uint32_t) p.head - pos, c = p.blk * v.step;
+			p = dir_load(v, locate(v.step, (c > back) ? (c - back) : 0).blk, 3);
+			continue;
+		}
 		uint32_t const rem = pos - (uint32_t) p.head;
 		uint32_t const hi = (uint32_t) (p.head >> DIR_SHIFT), fm = (1u << DIR_BITS) - 1;
 		uint32_t const c1 = hi & fm, c3 = (hi >> DIR_BITS) & fm, c5 = (hi >> (2 * DIR_BITS)) & fm;
@@ -334,11 +342,26 @@ __device__ __forceinline__ uint32_t dir_select0(row_view const &v, uint32_t pos,
 	}
 }
 
-// The select sample's guess for non-gap number pos: the sample is the column of non-gap number SELECT_SAMPLE * (pos /
-// SELECT_SAMPLE), the target lies at least pos % SELECT_SAMPLE columns further; with no gap in between it is exactly there.
-__device__ __forceinline__ uint32_t select_guess(uint32_t const *__restrict__ sel, uint32_t pos)
+// The select samples' guess for non-gap number pos.  Sample j is the column of non-gap number SELECT_SAMPLE * j; the target
+// lies pos % SELECT_SAMPLE non-gap columns further.  Where the stretch up to the next sample has few gap columns the guess is
+// that many columns further (exact with no gap in between, never past the target); where it has many (more than one column
+// in 16: a gap-dense MSA) the gaps are taken to be spread evenly, which lands within tens of columns instead of hundreds.
+// `span` columns' worth of non-gap columns after the target are guessed to end at `end`.
+struct select_guess_t
 {
-	return sel[pos >> SELECT_SAMPLE_SHIFT] + (pos & (SELECT_SAMPLE - 1));
+	uint32_t col, end;
+};
+
+__device__ __forceinline__ select_guess_t select_guess(uint32_t const *__restrict__ sel, uint32_t pos, uint32_t span)
+{
+	uint32_t const j = pos >> SELECT_SAMPLE_SHIFT, rem = pos & (SELECT_SAMPLE - 1);
+	uint32_t const s0 = sel[j], s1 = sel[j + 1];		// the table ends with a sentinel (the number of columns)
+	uint32_t const width = s1 - s0;
+	bool const dense = width > SELECT_SAMPLE + SELECT_SAMPLE / 16;
+	select_guess_t g;
+	g.col = s0 + (dense ? (uint32_t) (((uint64_t) rem * width) >> SELECT_SAMPLE_SHIFT) : rem);
+	g.end = g.col + (dense ? (uint32_t) (((uint64_t) span * width) >> SELECT_SAMPLE_SHIFT) : span);
+	return g;
 }
 
 // One lane: column of non-gap number pos (0-based); requires pos < n_zeros.  The select sample is the column of non-gap
@@ -395,7 +418,7 @@ __device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, 
 		return PVC3_NO_MATE;
 	row_pair const R = rows_of(S, D, dst_id);
 	// Both probes at the sample's guess: the destination's is right whenever no gap lies between the sample and the target.
-	col_pos const g = locate(R.src.step, select_guess(S.sel, pos));
+	col_pos const g = locate(R.src.step, select_guess(S.sel, pos, 0).col);
 	dir_probe const ps = dir_load(R.src, g.blk, pair_of(g));
 	dir_probe const pd = dir_load(R.dst, g.blk, pair_of(g));
 	return dir_rank(R.dst, pd, locate_in(R.dst.step, dir_select0(R.src, pos, ps), g.blk));

@@ -360,6 +360,74 @@ def test_project_positions(pvc3, oracle_mod, synth):
 	assert np.array_equal(got, want)
 
 
+def test_select_guess_on_uneven_gap_density(pvc3, oracle_mod):
+	"""Rows whose gap density changes abruptly inside a select-sample stretch (4096 non-gap columns): the interpolated guess of
+	the look-up then lies far before or far PAST the target, and the select has to walk forwards or backwards from the probe
+	(wave.hpp dir_select0).  Every position of every row against the oracle, through pvc3_project_positions and through the
+	whole path (reads laid over the same places), with and without the paired / windowed copies of the index."""
+	rng = np.random.default_rng(77)
+	n_cols = 60000
+	def row(kind):
+		g = np.zeros(n_cols, dtype=bool)
+		if "front" == kind: g[1000:21000] = True						# 20 000 gap columns, then none
+		elif "back" == kind: g[30000:52000] = True
+		elif "bursts" == kind:
+			for s in range(0, n_cols - 3000, 9000): g[s + 500:s + 500 + 2500] = True
+		elif "dense" == kind: g[:] = rng.random(n_cols) < 0.6
+		elif "mixed" == kind: g[:30000] = rng.random(30000) < 0.7; g[30000:] = rng.random(30000) < 0.01
+		return g
+	kinds = ["none", "front", "back", "bursts", "dense", "mixed"]
+	rows = [row(k) for k in kinds]
+	texts = ["".join("-" if x else "ACGT"[i & 3] for i, x in enumerate(r)) for r in rows]
+	o = oracle_mod.Oracle()
+	for opts in ({}, {"paired_blocks": 0, "text_window": 0}):
+		index = pvc3.Index()
+		for t in texts:
+			e = index.add_aligned(t)
+			index.set_reference(e, t.replace("-", ""))
+		ctx = pvc3.Context(0)
+		for k, v in opts.items(): ctx.set_option(k, v)
+		ctx.upload_index(index)
+		if not opts:
+			for t in texts:
+				e = o.add_aligned(t)
+				o.set_reference(e, t.replace("-", ""))
+		for s in range(len(rows)):
+			n_zero = int((~rows[s]).sum())
+			pos = np.arange(0, n_zero, 7, dtype=np.uint32)
+			for d in range(len(rows)):
+				got = ctx.project_positions(np.full(pos.size, s, dtype=np.uint32), np.full(pos.size, d, dtype=np.uint32), pos)
+				cols = np.flatnonzero(~rows[s])[pos]
+				want = np.concatenate([[0], np.cumsum(~rows[d])])[cols].astype(np.uint32)		# rank0_dst(select0_src(pos + 1))
+				assert np.array_equal(got, want), (kinds[s], kinds[d], opts)
+		ctx.close()
+	# spot check of the numpy expectation itself against the oracle
+	for s, d, p in ((1, 0, 5), (4, 2, 12345), (5, 3, 20000)):
+		cols = np.flatnonzero(~rows[s])[p]
+		assert o.project_position(s, d, p) == int((~rows[d][:cols]).sum())
+
+
+def test_plain_index_layout_matches_oracle(pvc3, oracle_mod, synth):
+	"""The same workloads without the paired blocks and the windowed text (options at upload): the plain 64-byte blocks and
+	the plain packed text are then what k_project_fast and k_project_mid read."""
+	for name, scale in (("C3", 0.004), ("C3G", 0.002)):
+		gp, rp, _ = synth.config(name, scale=scale)
+		genome = synth.Genome(gp)
+		reads = synth.Reads(genome, rp)
+		ctx = pvc3.Context(0)
+		ctx.set_option("paired_blocks", 0)
+		ctx.set_option("text_window", 0)
+		got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, reads.batch(), ctx=ctx)
+		assert stats["n_failed"] == 0
+		index_bytes, _ = ctx.hbm_bytes()
+		ctx2 = pvc3.Context(0)
+		index = pvc3.Index()
+		genome.fill_index(index)
+		ctx2.upload_index(index)
+		assert ctx2.hbm_bytes()[0] > index_bytes		# the default upload carries the two copies
+		ctx.close(); ctx2.close()
+
+
 @pytest.mark.parametrize("name", ["C3", "C4", "C5"])
 def test_full_size_properties(pvc3, oracle_mod, synth, name):
 	"""BASELINE.json configs[2] and configs[4] at full size (20 M pairs, 8 founders, 1 Gbp; 2x150 and 2x250 bp with long

@@ -176,20 +176,22 @@ __device__ __forceinline__ win80 load_win(uint8_t const *bytes, uint64_t first)
 	return n;
 }
 
-// 16 nibbles from nibble offset o (0 .. 79) of the window; what lies past the window reads as 0.
-__device__ __forceinline__ uint64_t win_extract16(win80 const &W, uint32_t o)
+// 32 nibbles from nibble offset o (0 .. 79) of the window as two words of 16; what lies past the window reads as 0.
+__device__ __forceinline__ void win_extract32(win80 const &W, uint32_t o, uint64_t &first, uint64_t &second)
 {
 	uint32_t const wi = o >> 4, sh = (o & 15) * 4;
-	uint64_t lo = W.w[0], hi = W.w[1];
-	lo = (1 == wi) ? W.w[1] : lo; hi = (1 == wi) ? W.w[2] : hi;
-	lo = (2 == wi) ? W.w[2] : lo; hi = (2 == wi) ? W.w[3] : hi;
-	lo = (3 == wi) ? W.w[3] : lo; hi = (3 == wi) ? W.w[4] : hi;
-	lo = (4 == wi) ? W.w[4] : lo; hi = (4 <= wi) ? UINT64_C(0) : hi;
-	return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+	uint64_t a = W.w[0], b = W.w[1], c = W.w[2];
+	a = (1 == wi) ? W.w[1] : a; b = (1 == wi) ? W.w[2] : b; c = (1 == wi) ? W.w[3] : c;
+	a = (2 == wi) ? W.w[2] : a; b = (2 == wi) ? W.w[3] : b; c = (2 == wi) ? W.w[4] : c;
+	a = (3 == wi) ? W.w[3] : a; b = (3 == wi) ? W.w[4] : b; c = (3 <= wi) ? UINT64_C(0) : c;
+	a = (4 == wi) ? W.w[4] : a; b = (4 <= wi) ? UINT64_C(0) : b;
+	first = sh ? ((a >> sh) | (b << (64 - sh))) : a;
+	second = sh ? ((b >> sh) | (c << (64 - sh))) : b;
 }
 
-// Mismatch bits of the compared columns mC of one step, 16 columns at a time from the windows.  q_off / r_off: nibble offsets
-// in the windows of the step's first query base / first text base.  (Moving a whole window into place once per run — four
+// Mismatch bits of the compared columns mC of one step, up to 32 columns of a run at a time from the windows (the runs of a
+// gap-dense MSA are some twenty columns long: one extraction, two 16-base compares).  q_off / r_off: nibble offsets in the
+// windows of the step's first query base / first text base.  (Moving a whole window into place once per run — four
 // conditional dword stages and eight funnel shifts — and comparing 64 bases from it costs 129 VGPRs, three waves per SIMD:
 // slower on every configuration.)
 __device__ __forceinline__ uint64_t compare_columns_windows(uint64_t mC, uint64_t Z, uint64_t dz, uint32_t q_off, uint32_t r_off, win80 const &Q, win80 const &T)
@@ -200,10 +202,14 @@ __device__ __forceinline__ uint64_t compare_columns_windows(uint64_t mC, uint64_
 		uint32_t const c0 = ctz64(left);
 		uint64_t const ones = ~(left >> c0);
 		uint32_t const run = ones ? ctz64(ones) : 64;
-		uint32_t const L = (run < 16) ? run : 16;
+		uint32_t const L = (run < 32) ? run : 32;
 		uint32_t const qo = q_off + popc64(Z & low_mask(c0)), ro = r_off + popc64(dz & low_mask(c0));
-		uint32_t const mm = mismatch16(win_extract16(Q, qo), win_extract16(T, ro)) & (uint32_t) low_mask(L);
-		mX |= (uint64_t) mm << c0;
+		uint64_t q1, q2, t1, t2;
+		win_extract32(Q, qo, q1, q2);
+		win_extract32(T, ro, t1, t2);
+		uint32_t mm = mismatch16(q1, t1);
+		if (L > 16) mm |= mismatch16(q2, t2) << 16;
+		mX |= ((uint64_t) mm & low_mask(L)) << c0;
 		left &= ~(low_mask(L) << c0);
 	}
 	return mX;

@@ -3,7 +3,8 @@
 // The BAM writer of panvc3_project_alignments spent 10 core-seconds per million records in zlib's deflate at its default
 // level, six times everything else in the pipeline.  BGZF blocks are independent and at most 65 280 bytes long, which
 // makes a much simpler encoder sufficient: one greedy pass with a single-probe hash table over 4-byte sequences (positions
-// fit 16 bits), one dynamic Huffman block per input, canonical codes limited to 15 bits.  The output is an ordinary
+// fit 16 bits) that records the matches, one dynamic Huffman block per input (its exact size is known from the symbol counts
+// before a bit is written, so the bit stream is written without bounds checks), canonical codes limited to 15 bits.  The output is an ordinary
 // DEFLATE stream (any inflate reads it); it is about 10 % larger than zlib's level 6 on BAM records.
 // No reference code corresponds to this file: the reference writes BAM through seqan3 / zlib.
 #pragma once
@@ -22,7 +23,6 @@ class fast_deflater
 	static constexpr unsigned N_LITLEN = 286, N_DIST = 30, N_CLEN = 19;
 
 	std::vector <uint16_t> m_head;		// hash -> position + 1 of the last occurrence (0: none)
-	std::vector <uint32_t> m_syms;		// literal: the byte; match: 0x80000000 | (length - 3) << 16 | (distance - 1)
 
 	struct tables
 	{
@@ -62,34 +62,6 @@ class fast_deflater
 
 	static uint32_t load32(uint8_t const *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 	static uint64_t load64(uint8_t const *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
-
-	struct bit_writer
-	{
-		uint8_t *p, *end;
-		uint64_t acc{};
-		unsigned n{};
-		bool overflow{};
-		void put(uint32_t bits, unsigned count)		// count <= 32
-		{
-			acc |= (uint64_t) bits << n;
-			n += count;
-			if (n >= 32)
-			{
-				if (p + 4 > end) { overflow = true; n -= 32; acc >>= 32; return; }
-				uint32_t const w = (uint32_t) acc;
-				std::memcpy(p, &w, 4);
-				p += 4; acc >>= 32; n -= 32;
-			}
-		}
-		void finish()
-		{
-			while (n > 0)
-			{
-				if (p >= end) { overflow = true; return; }
-				*p++ = (uint8_t) acc; acc >>= 8; n = (n > 8) ? (n - 8) : 0;
-			}
-		}
-	};
 
 	// Code lengths of a complete prefix code for freq[0 .. n), none longer than `limit`; unused symbols get 0.  Huffman's
 	// construction; should a code come out longer than the limit (it takes a Fibonacci-like distribution), the frequencies
@@ -166,6 +138,9 @@ class fast_deflater
 		return n + 5;
 	}
 
+	struct match { uint16_t pos, len, dist; };
+	std::vector <match> m_matches;
+
 public:
 	static std::size_t bound(std::size_t n) { return n + 5 + 64; }		// a stored block is the fallback
 
@@ -177,11 +152,13 @@ public:
 		if (0 == n) { dst[0] = 3; dst[1] = 0; return 2; }		// fixed-code block with the end-of-block symbol only
 		tables const &T = tab();
 		m_head.assign(std::size_t(1) << HASH_BITS, 0);
-		m_syms.clear();
-		m_syms.reserve(n + 1);
-		uint32_t f_ll[N_LITLEN] = {0}, f_d[N_DIST] = {0};
+		m_matches.clear();
+		// Literal counts in two tables (even / odd positions): base qualities repeat one value for long stretches, and a single
+		// counter would make every increment wait for the one before.
+		uint32_t f_lit[2][256] = {{0}}, f_ll[N_LITLEN] = {0}, f_d[N_DIST] = {0};
+		uint64_t extra_bits = 0;
 
-		// ---- greedy parse ------------------------------------------------------------------------------------------------
+		// ---- greedy parse: the matches; everything between them is literals ------------------------------------------------------
 		std::size_t i = 0, misses = 0;
 		std::size_t const last_hashable = (n >= 8) ? (n - 8) : 0;		// matches are extended with 8-byte loads
 		while (i < last_hashable)
@@ -204,9 +181,10 @@ public:
 				while (len < max_len && src[i + len] == src[c + len]) ++len;
 			matched:
 				unsigned const dist = (unsigned) (i - c);
-				m_syms.push_back(0x80000000u | (uint32_t) ((len - 3) << 16) | (dist - 1));
-				++f_ll[257 + T.len_sym[len - 3]];
-				++f_d[(dist - 1 < 256) ? T.dist_sym_lo[dist - 1] : T.dist_sym_hi[(dist - 1) >> 7]];
+				m_matches.push_back(match{(uint16_t) i, (uint16_t) len, (uint16_t) (dist - 1)});
+				unsigned const ls = T.len_sym[len - 3], ds = (dist - 1 < 256) ? T.dist_sym_lo[dist - 1] : T.dist_sym_hi[(dist - 1) >> 7];
+				++f_ll[257 + ls]; ++f_d[ds];
+				extra_bits += T.len_extra[ls] + T.dist_extra[ds];
 				// a position inside the match keeps the table fresh for what follows it
 				if (i + len < last_hashable)
 				{
@@ -218,12 +196,13 @@ public:
 				continue;
 			}
 			// No match here: literals, in larger steps the longer nothing has matched (SEQ and QUAL hardly ever do).
-			std::size_t const step = 1 + (misses >> 5);
+			std::size_t const step = 1 + (misses >> 3);
 			++misses;
 			std::size_t const stop = std::min(i + step, n);
-			for (; i < stop; ++i) { m_syms.push_back(src[i]); ++f_ll[src[i]]; }
+			for (; i < stop; ++i) ++f_lit[i & 1][src[i]];
 		}
-		for (; i < n; ++i) { m_syms.push_back(src[i]); ++f_ll[src[i]]; }
+		for (; i < n; ++i) ++f_lit[i & 1][src[i]];
+		for (unsigned b = 0; b < 256; ++b) f_ll[b] = f_lit[0][b] + f_lit[1][b];
 		f_ll[256] = 1;
 
 		// ---- codes -----------------------------------------------------------------------------------------------------------
@@ -237,6 +216,9 @@ public:
 		if (1 == n_d && 0 == l_d[0]) l_d[0] = 1;		// no match at all: one unused distance code (RFC 1951 3.2.7)
 		assign_codes(l_ll, n_ll, c_ll);
 		assign_codes(l_d, n_d, c_d);
+		uint64_t body_bits = extra_bits;
+		for (unsigned k = 0; k < n_ll; ++k) body_bits += (uint64_t) f_ll[k] * l_ll[k];
+		for (unsigned k = 0; k < n_d; ++k) body_bits += (uint64_t) f_d[k] * l_d[k];
 
 		// The two length sequences, run-length coded with symbols 16 (repeat 3-6), 17 (zeros 3-10) and 18 (zeros 11-138).
 		uint8_t seq[N_LITLEN + N_DIST];
@@ -284,36 +266,66 @@ public:
 		static uint8_t const cl_order[N_CLEN] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 		unsigned n_cl = N_CLEN;
 		while (n_cl > 4 && 0 == l_cl[cl_order[n_cl - 1]]) --n_cl;
+		uint64_t head_bits = 3 + 5 + 5 + 4 + 3 * n_cl;
+		for (unsigned k = 0; k < n_out; ++k)
+			head_bits += l_cl[out[k].sym] + ((16 == out[k].sym) ? 2 : (17 == out[k].sym) ? 3 : (18 == out[k].sym) ? 7 : 0);
+		// The size is known before a bit is written: stored instead when that is not larger, and no bounds checks below
+		// (cap >= n + 5 + 64; the bit writer stores 8 bytes at a time).
+		std::size_t const size = (std::size_t) ((head_bits + body_bits + 7) / 8);
+		if (size >= n + 5)
+			return stored(src, n, dst, cap);
 
 		// ---- bit stream --------------------------------------------------------------------------------------------------
-		bit_writer bw{dst, dst + cap};
-		bw.put(1, 1); bw.put(2, 2);		// BFINAL, BTYPE = 10
-		bw.put(n_ll - 257, 5); bw.put(n_d - 1, 5); bw.put(n_cl - 4, 4);
-		for (unsigned k = 0; k < n_cl; ++k) bw.put(l_cl[cl_order[k]], 3);
+		uint8_t *p = dst;
+		uint64_t acc = 0;
+		unsigned nb = 0;		// bits in acc, < 8 after a flush
+		auto put = [&](uint64_t bits, unsigned count) { acc |= bits << nb; nb += count; };
+		auto flush = [&]() { std::memcpy(p, &acc, 8); p += nb >> 3; acc >>= (nb & ~7u); nb &= 7; };
+		put(1, 1); put(2, 2);		// BFINAL, BTYPE = 10
+		put(n_ll - 257, 5); put(n_d - 1, 5); put(n_cl - 4, 4);
+		flush();
+		for (unsigned k = 0; k < n_cl; ++k) { put(l_cl[cl_order[k]], 3); if (0 == ((k + 1) & 7)) flush(); }
+		flush();
 		for (unsigned k = 0; k < n_out; ++k)
 		{
-			bw.put(c_cl[out[k].sym], l_cl[out[k].sym]);
-			if (16 == out[k].sym) bw.put(out[k].extra, 2);
-			else if (17 == out[k].sym) bw.put(out[k].extra, 3);
-			else if (18 == out[k].sym) bw.put(out[k].extra, 7);
+			put(c_cl[out[k].sym], l_cl[out[k].sym]);
+			if (16 == out[k].sym) put(out[k].extra, 2);
+			else if (17 == out[k].sym) put(out[k].extra, 3);
+			else if (18 == out[k].sym) put(out[k].extra, 7);
+			flush();
 		}
-		for (uint32_t const s : m_syms)
+		uint32_t lit[256];		// code | length << 16
+		for (unsigned b = 0; b < 256; ++b) lit[b] = c_ll[b] | ((uint32_t) l_ll[b] << 16);
+		auto literals = [&](std::size_t from, std::size_t to) {
+			std::size_t k = from;
+			for (; k + 3 <= to; k += 3)		// three codes of at most 15 bits + 7 left over < 64
+			{
+				uint32_t const a = lit[src[k]], b = lit[src[k + 1]], c = lit[src[k + 2]];
+				put(a & 0xffff, a >> 16); put(b & 0xffff, b >> 16); put(c & 0xffff, c >> 16);
+				flush();
+			}
+			for (; k < to; ++k) { uint32_t const a = lit[src[k]]; put(a & 0xffff, a >> 16); }
+			flush();
+		};
+		std::size_t at = 0;
+		for (match const &m : m_matches)
 		{
-			if (!(s & 0x80000000u)) { bw.put(c_ll[s], l_ll[s]); continue; }
-			unsigned const len3 = (s >> 16) & 0xff, d1 = s & 0xffff;
+			literals(at, m.pos);
+			unsigned const len3 = m.len - 3u, d1 = m.dist;
 			unsigned const ls = T.len_sym[len3];
-			bw.put(c_ll[257 + ls], l_ll[257 + ls]);
-			if (T.len_extra[ls]) bw.put(len3 + 3 - T.len_base[ls], T.len_extra[ls]);
+			put(c_ll[257 + ls], l_ll[257 + ls]);
+			put(len3 + 3 - T.len_base[ls], T.len_extra[ls]);
 			unsigned const ds = (d1 < 256) ? T.dist_sym_lo[d1] : T.dist_sym_hi[d1 >> 7];
-			bw.put(c_d[ds], l_d[ds]);
-			if (T.dist_extra[ds]) bw.put(d1 + 1 - T.dist_base[ds], T.dist_extra[ds]);
+			put(c_d[ds], l_d[ds]);
+			put(d1 + 1 - T.dist_base[ds], T.dist_extra[ds]);		// 15 + 5 + 15 + 13 + 7 left over < 64
+			flush();
+			at = (std::size_t) m.pos + m.len;
 		}
-		bw.put(c_ll[256], l_ll[256]);
-		bw.finish();
-		std::size_t const size = (std::size_t) (bw.p - dst);
-		if (bw.overflow || size >= n + 5)
-			return stored(src, n, dst, cap);
-		return size;
+		literals(at, n);
+		put(c_ll[256], l_ll[256]);
+		flush();
+		if (nb) *p++ = (uint8_t) acc;
+		return (std::size_t) (p - dst);
 	}
 };
 

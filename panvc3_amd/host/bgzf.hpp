@@ -233,6 +233,30 @@ public:
 		return got;
 	}
 
+	// Appends exactly n bytes to dst unless the stream ends; returns the number appended.  (No zero-fill before the copy, which
+	// resize() + read() would do: a BAM reader appends every record of a batch to one arena.)
+	std::size_t read_append(std::vector <uint8_t> &dst, std::size_t n)
+	{
+		if (!m_raw)
+		{
+			std::size_t const at = dst.size();
+			dst.resize(at + n);
+			std::size_t const got = read(dst.data() + at, n);
+			dst.resize(at + got);
+			return got;
+		}
+		std::size_t got = 0;
+		while (got < n)
+		{
+			if (m_dpos == m_cur.len && !refill()) break;
+			std::size_t const take = std::min(n - got, m_cur.len - m_dpos);
+			uint8_t const *p = m_cur.data.data() + m_dpos;
+			dst.insert(dst.end(), p, p + take);
+			m_dpos += take; got += take;
+		}
+		return got;
+	}
+
 	// One text line without its terminator; false at the end of the stream.
 	bool getline(std::string &line)
 	{

@@ -599,8 +599,7 @@ public:
 			if (0 == got) return false;
 			if (4 != got || block_size < 32) throw io_error("truncated BAM record");
 			std::size_t const at = arena.size();
-			arena.resize(at + (std::size_t) block_size);
-			if ((std::size_t) block_size != m_in.read(arena.data() + at, (std::size_t) block_size)) throw io_error("truncated BAM record");
+			if ((std::size_t) block_size != m_in.read_append(arena, (std::size_t) block_size)) throw io_error("truncated BAM record");
 			bam_view const v{arena.data() + at, (std::size_t) block_size};
 			if (v.aux_offset() > v.size()) throw io_error("malformed BAM record: its name, CIGAR, SEQ and QUAL exceed block_size");
 			return true;

@@ -2,16 +2,18 @@
 //
 // For 64 records at a time per wavefront (coalesced SoA descriptor loads):
 //   1. validates the CIGAR and the positions (per-record status, same rules as the oracle's batch driver);
-//   2. aligned_position + project_aligned_position (include/panvc3/rewrite_cigar.hh:51-56): one select sample and two
-//      64-byte blocks of the source row give the start column, one block of the destination row the projected position;
+//   2. aligned_position + project_aligned_position (include/panvc3/rewrite_cigar.hh:51-56): one select sample, then four
+//      probes of 24 bytes (wave.hpp: word 0 + one pair of a block) into the paired copy of the two rows give the start
+//      column, the projected position and the ranks of both rows at the end of the span;
 //   3. the mate's project_position (include/panvc3/msa_index.hh:253-258, project_alignments.cc:897-901);
 //   4. FAST PATH.  A record is "simple" when its CIGAR is [S|H] (M|=|X)+ [S|H] with non-zero counts, it consumes at most
 //      256 reference bases and neither row has a gap among the columns it spans (the ranks of both rows advance by exactly
 //      that many bases).  Then rewrite_cigar (rewrite_cigar.hh:80-118) degenerates to a byte compare of the query against the
-//      destination text: the lane builds the mismatch bit-mask with plain loads and emits the = / X runs itself
-//      (cigar_buffer semantics, libpanvc3/cigar.cc:54-95).  Such a record has no indel run, so it is finished.
-//   5. Every other valid record is handed to k_project_general (REC_SLOW; start column, projected position and
-//      reference-consuming length are left in the work arrays).
+//      destination text (4-bit codes; from the windowed copy when the read fits one of its lines): n_words lanes per record
+//      build the mismatch words, then the lane emits the = / X runs itself (cigar_buffer semantics, libpanvc3/cigar.cc:54-95).
+//      Such a record has no indel run, so it is finished.
+//   5. Every other valid record goes to the wave's work list for k_project_mid (REC_SLOW; start column, projected position
+//      and reference-consuming length are left in the work arrays).
 #include <hip/hip_runtime.h>
 
 #include "pvc3_internal.hpp"

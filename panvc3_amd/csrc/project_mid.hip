@@ -127,26 +127,6 @@ __device__ __forceinline__ uint64_t compare_columns(uint64_t mC, uint64_t Z, uin
 	return mX;
 }
 
-// The same result, 16 columns at a time: one 16-byte load and one 16-base compare per piece of a run.  Cheaper when the
-// compared columns of a step fall into several short runs (gap-dense MSAs: a gap run every twenty columns), dearer for one
-// long run; the kernel chooses per wave.
-__device__ __forceinline__ uint64_t compare_columns_pieces(uint64_t mC, uint64_t Z, uint64_t dz, uint32_t q, uint32_t r, uint8_t const *seq, uint8_t const *text4)
-{
-	uint64_t mX = 0, left = mC;
-	while (left)
-	{
-		uint32_t const c0 = ctz64(left);
-		uint64_t const ones = ~(left >> c0);
-		uint32_t const run = ones ? ctz64(ones) : 64;
-		uint32_t const L = (run < 16) ? run : 16;
-		uint32_t const qi = q + popc64(Z & low_mask(c0)), ri = r + popc64(dz & low_mask(c0));
-		uint32_t const mm = mismatch16(load_query16(seq, qi), load_text16(text4, ri)) & (uint32_t) low_mask(L);
-		mX |= (uint64_t) mm << c0;
-		left &= ~(low_mask(L) << c0);
-	}
-	return mX;
-}
-
 // ---- the compare from register windows --------------------------------------------------------------------------------------
 // A 64-column step consumes at most 64 query bases from q on and 64 text bases from r on, whatever its runs of compared
 // columns look like.  So the 80 nibbles of either side from the step's start are fetched ONE STEP AHEAD (the addresses
@@ -368,7 +348,7 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 							mX = compare_columns_windows(mC, Z, dz, q - qwin.first, r + TEXT4_FRONT - twin.first, qwin, twin);
 						}
 						else
-							mX = short_runs ? compare_columns_pieces(mC, Z, dz, q, r, seq, D.text4) : compare_columns(mC, Z, dz, q, r, seq, D.text4);
+							mX = compare_columns(mC, Z, dz, q, r, seq, D.text4);
 #endif
 						mE = mC & ~mX;
 					}

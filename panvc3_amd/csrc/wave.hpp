@@ -171,61 +171,6 @@ __device__ __forceinline__ uint32_t wave_select0(dev_entry const &S, uint64_t co
 	}
 }
 
-// ---- one lane on its own record: whole 64-byte blocks in registers, branch-free inside a block -------------------------
-// (A loop with one dependent load per iteration would serialise HBM round trips; loading the block at once keeps them
-// independent and lets many lanes' misses overlap.)
-struct block_regs
-{
-	uint64_t w[BLOCK_WORDS];	// w[0] = non-gap columns before the block, w[1..7] = gap bits
-};
-
-__device__ __forceinline__ block_regs load_block(uint64_t const *__restrict__ blocks, uint32_t b)
-{
-	typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
-	u64x2 const *p = (u64x2 const *) (blocks + (uint64_t) b * BLOCK_WORDS);
-	u64x2 const a = p[0], c = p[1], d = p[2], e = p[3];
-	block_regs r;
-	r.w[0] = a.x; r.w[1] = a.y; r.w[2] = c.x; r.w[3] = c.y; r.w[4] = d.x; r.w[5] = d.y; r.w[6] = e.x; r.w[7] = e.y;
-	return r;
-}
-
-// rank0 at (data word w, bit) of a block held in registers.
-__device__ __forceinline__ uint32_t block_rank(block_regs const &B, uint32_t w, uint32_t bit)
-{
-	uint32_t r = (uint32_t) B.w[0];
-#pragma unroll
-	for (uint32_t i = 0; i < BLOCK_DATA_WORDS; ++i)
-	{
-		uint64_t const m = (i < w) ? ~UINT64_C(0) : ((i == w) ? low_mask(bit) : UINT64_C(0));
-		r += popc64(~B.w[1 + i] & m);
-	}
-	return r;
-}
-
-// The rem-th (0-based) non-gap column at or after (w_s, bit_s) inside the block.  Returns true and the column offset
-// inside the block, or false with rem reduced by the non-gap columns seen.
-__device__ __forceinline__ bool block_select(block_regs const &B, uint32_t w_s, uint32_t bit_s, uint32_t &rem, uint32_t &off)
-{
-	bool found = false;
-	uint64_t z_hit = 0;
-	uint32_t w_hit = 0, rem_hit = 0;
-#pragma unroll
-	for (uint32_t i = 0; i < BLOCK_DATA_WORDS; ++i)
-	{
-		uint64_t const m = (i < w_s) ? UINT64_C(0) : ((i == w_s) ? (~UINT64_C(0) << bit_s) : ~UINT64_C(0));
-		uint64_t const z = ~B.w[1 + i] & m;
-		uint32_t const c = popc64(z);
-		bool const hit = !found && (rem < c);
-		z_hit = hit ? z : z_hit;
-		w_hit = hit ? i : w_hit;
-		rem_hit = hit ? rem : rem_hit;
-		found = found || hit;
-		rem = found ? rem : (rem - c);
-	}
-	off = 64 * w_hit + thread_select_in_word(z_hit, rem_hit);
-	return found;
-}
-
 // ---- one lane, directory form: word 0 of a block + ONE of its 16-byte pairs ----------------------------------------------
 // Word 0 carries the zeros before the block and before its pairs 1, 2, 3 (pvc3_internal.hpp); pair p holds data words
 // 2 p - 1 and 2 p (pair 0: word 0 itself and data word 0).  A rank or a select inside the block therefore needs 24 bytes in
@@ -364,41 +309,6 @@ __device__ __forceinline__ select_guess_t select_guess(uint32_t const *__restric
 	return g;
 }
 
-// One lane: column of non-gap number pos (0-based); requires pos < n_zeros.  The select sample is the column of non-gap
-// number SELECT_SAMPLE * (pos / SELECT_SAMPLE); the target lies at least rem = pos % SELECT_SAMPLE columns further, so the
-// block of (sample + rem) cannot be past the target's block and, gaps being rare, nearly always IS the target's block: one
-// 64-byte load.  Its rank word tells how many non-gap columns to skip inside it; if the target is further right (gaps in
-// between), the deficit gives the next lower bound.  The block that holds the result is returned in B / blk for reuse.
-__device__ __forceinline__ uint32_t thread_select0(uint64_t const *__restrict__ blocks, uint32_t const *__restrict__ sel, uint32_t pos, block_regs &B, uint32_t &blk)
-{
-	uint32_t const col0 = sel[pos >> SELECT_SAMPLE_SHIFT];
-	blk = (col0 + (pos & (SELECT_SAMPLE - 1))) / BLOCK_COLS;
-	for (;;)
-	{
-		B = load_block(blocks, blk);
-		uint32_t rem = pos - (uint32_t) B.w[0];		// non-gap columns to skip inside this block (rank word <= pos by construction)
-		uint32_t off = 0;
-		if (block_select(B, 0, 0, rem, off))
-			return blk * BLOCK_COLS + off;
-		blk += 1 + rem / BLOCK_COLS;				// rem = non-gap columns still missing: at least that many columns further
-	}
-}
-
-__device__ __forceinline__ uint32_t thread_select0(uint64_t const *__restrict__ blocks, uint32_t const *__restrict__ sel, uint32_t pos)
-{
-	block_regs B;
-	uint32_t blk;
-	return thread_select0(blocks, sel, pos, B, blk);
-}
-
-// One lane: rank0 at column col (number of non-gap columns before col).
-__device__ __forceinline__ uint32_t thread_rank0(uint64_t const *__restrict__ blocks, uint32_t col)
-{
-	col_pos const q = split_col(col);
-	return block_rank(load_block(blocks, q.blk), q.w, q.bit);
-}
-
-// One lane: project_position (msa_index.hh:253-258) = rank0_dst(select0_src(pos + 1)).
 // The rows of a projection from entry S to entry number dst_id (= D): the paired copy when D is S's partner.
 struct row_pair
 {

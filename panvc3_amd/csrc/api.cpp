@@ -628,6 +628,7 @@ int dbatch_alloc(pvc3_context *ctx, batch_caps const &caps, pvc3_dbatch **out)
 	PVC3_TRY(dev_alloc(&w.run_n, n, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.counters, 1, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.slow_list, (n + 63) / 64 * 64 + 64, &b->allocs, &b->bytes));
+	PVC3_TRY(dev_alloc(&w.slow_items, (n + 63) / 64 * 64 + 64, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.slow_count, project_wave_count(n), &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.run_list, (n + 63) / 64 * 64 + 64, &b->allocs, &b->bytes));
 	PVC3_TRY(dev_alloc(&w.run_count, project_wave_count(n), &b->allocs, &b->bytes));

@@ -90,6 +90,8 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	uint32_t acc_failed = 0, acc_fast = 0;		// per lane
 	uint32_t n_slow = 0;						// wave-uniform: entries in this wave's work list for k_project_mid
 	uint32_t *slow_list = W.slow_list + 64 * g_begin;
+	slow_item *slow_items = W.slow_items + 64 * g_begin;
+	bool items_mode = true;					// wave-uniform: decided by the wave's first group (see slow_item)
 
 	// The entry table is read by every lane of every group: keep its head in LDS.
 	__shared__ dev_entry lds_entries[LDS_ENTRIES];
@@ -419,7 +421,21 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		// ---- work list of the records left for k_project_mid --------------------------------------------------------------------------
 		{
 			uint64_t const m = ballot(valid && ok && !fast);
-			if ((m >> lane) & 1) slow_list[n_slow + mbcnt64(m)] = (uint32_t) rec;
+			if (g == g_begin) items_mode = popc64(m) <= 32;
+			if ((m >> lane) & 1)
+			{
+				uint32_t const at = n_slow + mbcnt64(m);
+				slow_list[at] = (uint32_t) rec;
+			}
+			if (items_mode && ((m >> lane) & 1))
+			{
+				uint32_t const at = n_slow + mbcnt64(m);
+				slow_item it;
+				it.rec = (uint32_t) rec; it.col0 = col; it.r0 = r0; it.src_e = src_e;
+				it.dst_e = dst_e; it.n_cigar = n_cigar; it.l_seq = l_seq; it.pad = 0;
+				it.cig_begin = cig_begin; it.seq_begin = seq_begin;
+				slow_items[at] = it;
+			}
 			n_slow += popc64(m);
 		}
 
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	}
 #endif
 
-	W.slow_count[wave] = n_slow;		// wave-uniform stores
+	W.slow_count[wave] = n_slow | (items_mode ? SLOW_ITEMS : 0u);		// wave-uniform stores
 	W.run_count[wave] = 0;				// k_project_mid / k_project_general append the records with indel runs
 	// Per-lane accumulators -> wave totals -> one atomic each.
 	for (int off = 32; off; off >>= 1)

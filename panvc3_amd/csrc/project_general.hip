@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_project_general(dev_entry const *__rest
 	// The records to walk come as this wave's work list: what k_project_mid left of the list k_project_fast wrote (all of it
 	// when k_project_mid is switched off).  Scanning the flags of all records instead cost 0.1 ms per 40 M records.
 	uint32_t const *list = W.slow_list + 64 * g_begin;
-	uint32_t const count = rfl(W.slow_count[wave]);
+	uint32_t const count = rfl(W.slow_count[wave]) & ~SLOW_ITEMS;		// (the flag is there when k_project_mid did not run)
 	for (uint32_t base = 0; base < count; base += 64)
 	{
 		bool const mine = base + lane < count;

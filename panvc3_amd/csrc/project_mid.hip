@@ -195,15 +195,17 @@ __device__ __forceinline__ uint64_t compare_columns_windows(uint64_t mC, uint64_
 	return mX;
 }
 
-__global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W)
+__global__ __launch_bounds__(256, 4) void k_project_mid(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W)
 {
 	uint32_t const lane = lane_id();
 	uint32_t const wave = rfl((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	uint32_t const n_waves = (gridDim.x * blockDim.x) >> 6;
 	// Same partition as k_project_fast (same grid): wave w wrote its list at the start of its own record range.
 	uint64_t const n_groups = (in.n + 63) / 64;
-	uint32_t const *list = W.slow_list + 64 * (n_groups * wave / n_waves);
-	uint32_t const count = W.slow_count[wave];
+	slow_item const *list = W.slow_items + 64 * (n_groups * wave / n_waves);
+	uint32_t const *rec_list = W.slow_list + 64 * (n_groups * wave / n_waves);
+	uint32_t const count = W.slow_count[wave] & ~SLOW_ITEMS;
+	bool const have_items = 0 != (W.slow_count[wave] & SLOW_ITEMS);
 	uint32_t *run_list = W.run_list + 64 * (n_groups * wave / n_waves);
 	uint32_t n_run = 0;		// wave-uniform
 	// The records this kernel leaves to k_project_general are written back to the front of the same list (never ahead of the
@@ -219,7 +221,18 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 	for (uint32_t base = 0; base < count; base += 64)
 	{
 		bool const mine = base + lane < count;
-		uint32_t const rec = mine ? list[base + lane] : 0;
+		slow_item item{};
+		if (mine && have_items) item = list[base + lane];
+		else if (mine)
+		{
+			// a dense list: the record numbers are nearly consecutive and the arrays are read as streams
+			uint32_t const rr = rec_list[base + lane];
+			item.rec = rr; item.col0 = (uint32_t) W.cig_loc[rr]; item.r0 = W.dst_pos[rr];
+			item.src_e = in.src_entry[rr]; item.dst_e = in.dst_entry[rr];
+			item.cig_begin = in.cigar_off[rr]; item.n_cigar = (uint32_t) (in.cigar_off[rr + 1] - item.cig_begin);
+			item.seq_begin = in.seq_off[rr]; item.l_seq = in.l_seq[rr];
+		}
+		uint32_t const rec = item.rec;
 		uint32_t status = PVC3_ST_OK;
 		bool punt = false;
 		lane_sink out;
@@ -231,30 +244,25 @@ __global__ __launch_bounds__(256) void k_project_mid(dev_entry const *__restrict
 		bool dense = false;
 		if (mine)
 		{
-			dev_entry const *sp = entries + in.src_entry[rec], *dp = entries + in.dst_entry[rec];
+			dev_entry const *sp = entries + item.src_e, *dp = entries + item.dst_e;
 			dense = (16 * (sp->n_cols - sp->n_zeros) > sp->n_cols) || (16 * (dp->n_cols - dp->n_zeros) > dp->n_cols);
 		}
 		bool const short_runs = 2 * popc64(ballot(dense)) > popc64(ballot(mine));
 
 		if (mine)
 		{
-			uint32_t const src_pos = in.src_pos[rec];
-			dev_entry const S = entries[in.src_entry[rec]];
-			dev_entry const D = entries[in.dst_entry[rec]];
-			uint64_t const cig_begin = in.cigar_off[rec];
-			uint32_t const n_cigar = (uint32_t) (in.cigar_off[rec + 1] - cig_begin);
-			uint32_t const *ops = in.cigar + cig_begin;
-			uint8_t const *seq = in.seq4 + in.seq_off[rec];
-			l_seq = in.l_seq[rec];
-			uint64_t const stash = W.cig_loc[rec];		// left by k_project_fast: start column | reference-consuming length << 32
-			uint32_t const col0 = (uint32_t) stash;
-			uint32_t const r0 = W.dst_pos[rec];
-			(void) src_pos;
+			dev_entry const S = entries[item.src_e];
+			dev_entry const D = entries[item.dst_e];
+			uint32_t const n_cigar = item.n_cigar;
+			uint32_t const *ops = in.cigar + item.cig_begin;
+			uint8_t const *seq = in.seq4 + item.seq_begin;
+			l_seq = item.l_seq;
+			uint32_t const col0 = item.col0, r0 = item.r0;		// start column and projected position, from k_project_fast
 			uint32_t col = col0, r = r0, q = 0, steps = 0;
 			// The two rows' gap words, from the paired copy (one 128-byte line for both) when the destination is the source's
 			// partner.  The words of the NEXT 64 columns are requested a step ahead: a step ends at a word boundary or inside
 			// the same word, so the walk never waits for a gap word of its own.
-			row_pair const rows = rows_of(S, D, in.dst_entry[rec]);
+			row_pair const rows = rows_of(S, D, item.dst_e);
 			auto gap_words = [&](uint32_t first_col, uint64_t &sw_out, uint64_t &dw_out) {
 				col_pos const pp = locate(rows.src.step, first_col);
 				uint64_t const wi = (uint64_t) pp.blk * rows.src.stride + 1 + pp.w;

@@ -159,6 +159,20 @@ struct dev_counters
 	unsigned long long qual_head;		// next free byte of that buffer
 };
 
+// What k_project_mid needs of a record that k_project_fast could not finish, written by the lane that had it all in
+// registers, one item behind the other in the wave's part of the list: k_project_mid then reads 48 contiguous bytes per
+// record instead of nine fields from nine arrays at a scattered record number (a 128-byte line each: half of the lines the
+// kernel moved on config C3, where one record in 26 comes here).  A wave whose first group of 64 leaves more than half of its
+// records (a gap-dense MSA) does not write items: its list is then nearly every record in turn, the nine arrays are read
+// as streams, and the items would be 48 more bytes to write for each.
+struct slow_item
+{
+	uint32_t rec, col0, r0, src_e;
+	uint32_t dst_e, n_cigar, l_seq, pad;
+	uint64_t cig_begin, seq_begin;
+};
+static_assert(48 == sizeof(slow_item), "slow_item layout");
+
 // Per-record results before packing.  rec_flags: bits 0-7 status; REC_SLOW while a record waits for k_project_mid /
 // k_project_general, which leave the plain status (the array then doubles as the status output).
 struct dev_batch_work
@@ -179,7 +193,8 @@ struct dev_batch_work
 	uint8_t *scratch;					// DP scratch, scratch_per_wave bytes per realign wave
 	uint64_t scratch_per_wave;
 	uint32_t *slow_list;				// records left by the fast path: wave w of k_project_fast fills [64 * first group of w ...)
-	uint32_t *slow_count;				// [waves of k_project_fast]
+	slow_item *slow_items;				// the same records, same places, with what k_project_mid needs of them
+	uint32_t *slow_count;				// [waves of k_project_fast]; k_project_fast sets SLOW_ITEMS when it wrote slow_items as well
 	uint32_t *run_list;					// records with an indel run, same partition: k_project_mid appends, then k_project_general
 	uint32_t *run_count;				// [waves of k_project_fast]
 	uint32_t *run_prefix;				// [waves of k_project_fast + 1] exclusive prefix sums of run_count (k_run_prefix)
@@ -214,6 +229,7 @@ struct dev_batch_packed
 constexpr uint32_t WAVE_STATS = 8;
 constexpr uint32_t WS_BITVEC = 0, WS_REF = 1, WS_FAILED = 2, WS_DONE = 3, WS_BYTES = 4, WS_WITH_RUNS = 5;
 
+constexpr uint32_t SLOW_ITEMS = 0x80000000u;
 constexpr uint32_t REC_STATUS_MASK = 0xffu;
 constexpr uint32_t REC_HAS_RUN = 0x100u;
 constexpr uint32_t REC_SLOW = 0x200u;		// left by k_project_fast for k_project_general

@@ -405,6 +405,35 @@ def test_select_guess_on_uneven_gap_density(pvc3, oracle_mod):
 	for s, d, p in ((1, 0, 5), (4, 2, 12345), (5, 3, 20000)):
 		cols = np.flatnonzero(~rows[s])[p]
 		assert o.project_position(s, d, p) == int((~rows[d][:cols]).sum())
+	# The whole path over the same rows: reads of 40 - 150 bases copied from every source row (a few substitutions), plain
+	# CIGARs and some with a clip, an insertion or a deletion, every pair of rows, positions spread over the changes of density.
+	bb = BatchBuilder()
+	for s in range(len(rows)):
+		seq = texts[s].replace("-", "")
+		for d in range(len(rows)):
+			for p0 in list(range(0, len(seq) - 200, 997)) + [len(seq) - 151]:
+				L = int(rng.integers(40, 151))
+				q = list(seq[p0:p0 + L])
+				for x in rng.integers(0, L, size=2): q[x] = "ACGT"[int(rng.integers(0, 4))]
+				kind = int(rng.integers(0, 4))
+				if 0 == kind: cig, query = "%dM" % L, q
+				elif 1 == kind: cig, query = "5S%dM" % L, list("ACGTA") + q
+				elif 2 == kind: cig, query = "%dM3I%dM" % (L // 2, L - L // 2), q[:L // 2] + list("TTT") + q[L // 2:]
+				else: cig, query = "%dM4D%dM" % (L // 2, L - L // 2 - 4), q[:L // 2] + q[L // 2 + 4:]
+				bb.add(p0, s, d, cig, "".join(query))
+	batch = bb.build()
+	want = o.batch_project(batch, 0, -1, 0, n_threads=8)
+	for opts in ({}, {"paired_blocks": 0, "text_window": 0}):
+		index = pvc3.Index()
+		for t in texts:
+			e = index.add_aligned(t)
+			index.set_reference(e, t.replace("-", ""))
+		ctx = pvc3.Context(0)
+		for k, v in opts.items(): ctx.set_option(k, v)
+		ctx.upload_index(index)
+		got, stats = pvc3.project_batch(ctx, batch, 0, -1, 0)
+		assert_results_equal(batch, got, want)
+		ctx.close()
 
 
 def test_plain_index_layout_matches_oracle(pvc3, oracle_mod, synth):

@@ -50,6 +50,50 @@ char const *const PRESERVED_TAGS[] = {	// project_alignments.cc:53-87
 
 inline uint16_t tag_key(char const t[2]) { return (uint16_t) ((uint8_t) t[0] * 256 + (uint8_t) t[1]); }	// include/panvc3/sam_tag.hh:34-44
 
+// The tags of one output record: what std::map <uint16_t, std::vector <uint8_t>> would hold, without its node per tag and
+// record (the byte vectors keep their capacity from record to record).
+class tag_set
+{
+	struct entry { uint16_t key; std::vector <uint8_t> data; };
+	std::vector <entry> m_entries;
+	std::size_t m_used{};
+	std::vector <uint16_t> m_order;
+
+public:
+	void clear() { m_used = 0; }
+
+	std::vector <uint8_t> &operator[](uint16_t key)
+	{
+		for (std::size_t i = 0; i < m_used; ++i)
+			if (m_entries[i].key == key) return m_entries[i].data;
+		if (m_used == m_entries.size()) m_entries.emplace_back();
+		entry &e = m_entries[m_used++];
+		e.key = key; e.data.clear();
+		return e.data;
+	}
+
+	template <typename t_fn>
+	void for_each_sorted(t_fn &&fn)
+	{
+		m_order.resize(m_used);
+		for (std::size_t i = 0; i < m_used; ++i) m_order[i] = (uint16_t) i;
+		std::sort(m_order.begin(), m_order.end(), [&](uint16_t a, uint16_t b) { return m_entries[a].key < m_entries[b].key; });
+		for (uint16_t const i : m_order) fn(m_entries[i].data);
+	}
+};
+
+// A byte of BAM SEQ read through seqan3::dna5: a code that is not A, C, G or T (1, 2, 4, 8) becomes N (15).
+struct dna5_byte_table
+{
+	uint8_t v[256];
+	dna5_byte_table()
+	{
+		auto canon = [](unsigned c) -> unsigned { return (1 == c || 2 == c || 4 == c || 8 == c) ? c : 15u; };
+		for (unsigned b = 0; b < 256; ++b) v[b] = (uint8_t) ((canon(b >> 4) << 4) | canon(b & 0xf));
+	}
+};
+static dna5_byte_table const dna5_bytes;
+
 struct options
 {
 	char const *alignments{}, *msa_index{}, *reference{}, *reference_msa_id{}, *ref_order{}, *output_path{}, *realigned_ranges{};
@@ -427,7 +471,8 @@ int main(int argc, char **argv)
 		struct slice_state		// per-thread scratch and results of one slice of a batch
 		{
 			std::string bytes, oa;
-			std::map <uint16_t, std::vector <uint8_t>> tags;		// ordered by tag key, as seqan3's sam_tag_dictionary
+			tag_set tags;											// written in the order of the tag keys, as seqan3's sam_tag_dictionary
+			std::vector <aux_field> aux;
 			std::vector <std::pair <uint32_t, uint32_t>> ranges;
 			std::map <uint16_t, uint64_t> removed;
 			bam_record w;
@@ -488,16 +533,26 @@ int main(int argc, char **argv)
 			b_src_pos.resize(n); b_src_entry.resize(n); b_dst_entry.resize(n); b_flags.resize(n); b_l_seq.resize(n);
 			b_mate_se.resize(n); b_mate_de.resize(n); b_mate_pos.resize(n);
 			b_cigar_off.resize(n + 1); b_seq_off.resize(n + 1); b_qual_off.resize(n + 1);
+			// The sizes are read out of the records by all threads (a record header is a cache miss of its own), the prefix sums
+			// are one pass over three dense arrays.
+			std::size_t const n_fill = std::min <std::size_t>(n, 4 * (std::size_t) opt.threads);
 			b_cigar_off[0] = b_seq_off[0] = b_qual_off[0] = 0;
+			parallel_for(n_fill, opt.threads, [&](std::size_t si) {
+				for (uint64_t i = n * si / n_fill; i < n * (si + 1) / n_fill; ++i)
+				{
+					bam_view const r = batch[i];
+					b_cigar_off[i + 1] = r.n_cigar();
+					b_seq_off[i + 1] = (r.l_seq() + 1) / 2;
+					b_qual_off[i + 1] = r.has_qual() ? r.l_seq() : 0;
+				}
+			});
 			for (uint64_t i = 0; i < n; ++i)
 			{
-				bam_view const r = batch[i];
-				b_cigar_off[i + 1] = b_cigar_off[i] + r.n_cigar();
-				b_seq_off[i + 1] = b_seq_off[i] + (r.l_seq() + 1) / 2;
-				b_qual_off[i + 1] = b_qual_off[i] + (r.has_qual() ? r.l_seq() : 0);
+				b_cigar_off[i + 1] += b_cigar_off[i];
+				b_seq_off[i + 1] += b_seq_off[i];
+				b_qual_off[i + 1] += b_qual_off[i];
 			}
 			b_cigar.resize(b_cigar_off[n]); b_seq4.resize(b_seq_off[n]); b_qual.resize(b_qual_off[n]);
-			std::size_t const n_fill = std::min <std::size_t>(n, 4 * (std::size_t) opt.threads);
 			parallel_for(n_fill, opt.threads, [&](std::size_t si) {
 				for (uint64_t i = n * si / n_fill; i < n * (si + 1) / n_fill; ++i)
 				{
@@ -552,7 +607,8 @@ int main(int argc, char **argv)
 			parallel_for(n_slices, opt.threads, [&](std::size_t si) {
 			slice_state &S = slices[si];
 			S.bytes.clear(); S.ranges.clear(); S.removed.clear(); S.n_ranges = 0;
-			std::map <uint16_t, std::vector <uint8_t>> &tags = S.tags;
+			tag_set &tags = S.tags;
+			std::vector <aux_field> &aux = S.aux;
 			std::string &oa = S.oa;
 			for (uint64_t i = n * si / n_slices; i < n * (si + 1) / n_slices; ++i)
 			{
@@ -574,7 +630,8 @@ int main(int argc, char **argv)
 				tags.clear();
 				bool have_nm = false; int64_t nm = 0;
 				std::string old_oa;
-				for (auto const &f : parse_aux(r.bytes() + r.aux_offset(), r.bytes() + r.size()))
+				parse_aux(r.bytes() + r.aux_offset(), r.bytes() + r.size(), aux);
+				for (auto const &f : aux)
 				{
 					uint16_t const key = tag_key(f.tag);
 					if ('N' == f.tag[0] && 'M' == f.tag[1] && aux_scalar_size(f.type) && 'A' != f.type && 'f' != f.type)
@@ -613,15 +670,15 @@ int main(int argc, char **argv)
 				};
 				// -- OA (:805-844): RNAME,POS (0-based as the reference prints it),strand,CIGAR,MAPQ,NM;
 				oa = old_oa;
-				oa += in_header.refs[(std::size_t) ref_id].name; oa += ','; oa += std::to_string(r.pos()); oa += ',';
+				oa += in_header.refs[(std::size_t) ref_id].name; oa += ','; append_decimal(oa, r.pos()); oa += ',';
 				oa += (r.flag() & 0x10) ? '-' : '+'; oa += ',';
 				for (uint16_t k = 0; k < r.n_cigar(); ++k)
 				{
 					uint32_t const cc = r.get <uint32_t>(r.cigar_offset() + 4u * k);
-					oa += std::to_string(cc >> 4); oa += CIGAR_CHARS[(cc & 0xf) < 9 ? (cc & 0xf) : 0];
+					append_decimal(oa, cc >> 4); oa += CIGAR_CHARS[(cc & 0xf) < 9 ? (cc & 0xf) : 0];
 				}
-				oa += ','; oa += std::to_string((unsigned) r.mapq()); oa += ',';
-				if (have_nm) oa += std::to_string(nm);
+				oa += ','; append_decimal(oa, r.mapq()); oa += ',';
+				if (have_nm) append_decimal(oa, nm);
 				oa += ';';
 				{
 					std::vector <uint8_t> &d = tags[tag_key("OA")];
@@ -668,18 +725,22 @@ int main(int argc, char **argv)
 				w.data.insert(w.data.end(), (uint8_t const *) cig, (uint8_t const *) (cig + n_cig));
 				// SEQ through seqan3::dna5 (non-ACGT becomes N), QUAL through phred42 (saturates at 41)
 				std::size_t const seq_at = w.data.size();
-				w.data.insert(w.data.end(), r.seq4(), r.seq4() + (r.l_seq() + 1) / 2);
-				for (uint32_t k = 0; k < r.l_seq(); ++k)
 				{
-					uint8_t &byte = w.data[seq_at + (k >> 1)];
-					unsigned const shift = (~k & 1u) << 2;
-					unsigned const code = (byte >> shift) & 0xf;
-					if (1 != code && 2 != code && 4 != code && 8 != code) byte = (uint8_t) ((byte & ~(0xf << shift)) | (15u << shift));
+					std::size_t const n_bytes = (r.l_seq() + 1) / 2;
+					w.data.resize(seq_at + n_bytes);
+					uint8_t const *src = r.seq4();
+					uint8_t *dst = w.data.data() + seq_at;
+					for (std::size_t k = 0; k < n_bytes; ++k) dst[k] = dna5_bytes.v[src[k]];
+					if (r.l_seq() & 1) dst[n_bytes - 1] = (uint8_t) ((dst[n_bytes - 1] & 0xf0) | (src[n_bytes - 1] & 0x0f));	// the unused low nibble stays as it was
 				}
 				std::size_t const qual_at = w.data.size();
 				w.data.insert(w.data.end(), r.qual(), r.qual() + r.l_seq());
-				if (r.has_qual()) for (uint32_t k = 0; k < r.l_seq(); ++k) if (w.data[qual_at + k] > 41) w.data[qual_at + k] = 41;
-				for (auto const &kv : tags) w.data.insert(w.data.end(), kv.second.begin(), kv.second.end());
+				if (r.has_qual())
+				{
+					uint8_t *q = w.data.data() + qual_at;
+					for (uint32_t k = 0; k < r.l_seq(); ++k) q[k] = (q[k] > 41) ? 41 : q[k];
+				}
+				tags.for_each_sorted([&](std::vector <uint8_t> const &v) { w.data.insert(w.data.end(), v.begin(), v.end()); });
 				writer.format(w, S.bytes);
 			}
 			});

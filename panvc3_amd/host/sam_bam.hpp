@@ -257,10 +257,10 @@ inline std::size_t aux_scalar_size(char t)
 	switch (t) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; }
 }
 
-// Splits the aux block; throws on malformed data.
-inline std::vector <aux_field> parse_aux(uint8_t const *p, uint8_t const *end)
+// Splits the aux block into `out` (cleared first; reuse it across records); throws on malformed data.
+inline void parse_aux(uint8_t const *p, uint8_t const *end, std::vector <aux_field> &out)
 {
-	std::vector <aux_field> out;
+	out.clear();
 	while (p < end)
 	{
 		if (end - p < 3) throw io_error("truncated BAM tag");
@@ -286,7 +286,24 @@ inline std::vector <aux_field> parse_aux(uint8_t const *p, uint8_t const *end)
 		p += f.size;
 		out.push_back(f);
 	}
+}
+
+inline std::vector <aux_field> parse_aux(uint8_t const *p, uint8_t const *end)
+{
+	std::vector <aux_field> out;
+	parse_aux(p, end, out);
 	return out;
+}
+
+// Decimal digits of v appended to s (std::to_string allocates a string per call).
+inline void append_decimal(std::string &s, int64_t v)
+{
+	char buf[24];
+	char *e = buf + sizeof(buf), *b = e;
+	uint64_t u = (v < 0) ? (uint64_t) 0 - (uint64_t) v : (uint64_t) v;
+	do { *--b = (char) ('0' + u % 10); u /= 10; } while (u);
+	if (v < 0) *--b = '-';
+	s.append(b, (std::size_t) (e - b));
 }
 
 inline void append_int_aux(std::vector <uint8_t> &aux, char const tag[2], int64_t v)

@@ -233,6 +233,19 @@ public:
 		return got;
 	}
 
+	// The unread bytes of the current inflated piece (BGZF input only; false for other inputs and at the end of the stream), for
+	// callers that frame records in place, and consume() to step over what they used.
+	bool span(uint8_t const *&p, std::size_t &n)
+	{
+		if (!m_raw) return false;
+		if (m_dpos == m_cur.len && !refill()) return false;
+		p = m_cur.data.data() + m_dpos;
+		n = m_cur.len - m_dpos;
+		return true;
+	}
+
+	void consume(std::size_t n) { m_dpos += n; }
+
 	// Appends exactly n bytes to dst unless the stream ends; returns the number appended.  (No zero-fill before the copy, which
 	// resize() + read() would do: a BAM reader appends every record of a batch to one arena.)
 	std::size_t read_append(std::vector <uint8_t> &dst, std::size_t n)
@@ -322,7 +335,8 @@ class byte_writer
 	int m_level{-1};
 	unsigned m_threads{1};
 	std::vector <uint8_t> m_pending;	// uncompressed bytes not yet written
-	std::vector <std::vector <uint8_t>> m_out;
+	std::vector <std::vector <uint8_t>> m_out, m_out_writing;		// deflated blocks: being made / on their way to the file
+	std::future <void> m_writing;
 
 	static constexpr std::size_t BLOCK_DATA = 0xff00;	// uncompressed bytes per block (as htslib)
 
@@ -379,8 +393,13 @@ class byte_writer
 			std::size_t const len = (i < n_full) ? BLOCK_DATA : tail;
 			deflate_block(m_pending.data() + i * BLOCK_DATA, len, m_out[i]);
 		});
-		for (std::size_t i = 0; i < n; ++i)
-			write_raw(m_out[i].data(), m_out[i].size());
+		// The blocks go to the file on a thread of their own while the next group is deflated.
+		if (m_writing.valid()) m_writing.get();		// rethrows a write error
+		m_out.swap(m_out_writing);
+		m_writing = std::async(std::launch::async, [this, n]() {
+			for (std::size_t i = 0; i < n; ++i)
+				write_raw(m_out_writing[i].data(), m_out_writing[i].size());
+		});
 		if (n == n_full && tail)
 		{
 			std::memmove(m_pending.data(), m_pending.data() + n_full * BLOCK_DATA, tail);
@@ -428,6 +447,7 @@ public:
 		if (m_bgzf)
 		{
 			flush_blocks(true);
+			if (m_writing.valid()) m_writing.get();
 			// The empty EOF marker block.
 			static uint8_t const eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 			write_raw(eof, sizeof(eof));

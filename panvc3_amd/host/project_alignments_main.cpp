@@ -212,14 +212,15 @@ void append_program_info(sam_header const &in, sam_header &out, int argc, char *
 // The records of one batch: their bytes back to back in one arena (no allocation per record).
 struct batch_store
 {
-	std::vector <uint8_t> raw;
-	std::vector <uint64_t> off{0};			// [n + 1]
+	std::vector <uint8_t> raw;				// the records' bytes (with whatever lay between them in the input: length fields, filtered records)
+	std::vector <uint64_t> begin;			// [n] where record i starts in raw
+	std::vector <uint32_t> len;				// [n]
 	std::vector <uint64_t> input_index;		// index among all input records, filtered ones included
 	std::size_t size() const { return input_index.size(); }
 	bool empty() const { return input_index.empty(); }
-	bam_view operator[](std::size_t i) const { return bam_view{raw.data() + off[i], (std::size_t) (off[i + 1] - off[i])}; }
-	void clear() { raw.clear(); off.assign(1, 0); input_index.clear(); }
-	void swap(batch_store &o) { raw.swap(o.raw); off.swap(o.off); input_index.swap(o.input_index); }
+	bam_view operator[](std::size_t i) const { return bam_view{raw.data() + begin[i], (std::size_t) len[i]}; }
+	void clear() { raw.clear(); begin.clear(); len.clear(); input_index.clear(); }
+	void swap(batch_store &o) { raw.swap(o.raw); begin.swap(o.begin); len.swap(o.len); input_index.swap(o.input_index); }
 };
 
 // Finished batches on their way to the output file: the formatted bytes of the slices, in order.
@@ -350,6 +351,18 @@ int main(int argc, char **argv)
 		append_program_info(in_header, out_header, argc, argv);
 
 		// ---- index, reference, GPU ---------------------------------------------------------------------------------------------
+		// The GPU contexts come up on a thread of their own (the HIP runtime takes a few tenths of a second to start) while the
+		// index file and the reference are read.
+		std::future <std::vector <pvc3_context *>> contexts_coming = std::async(std::launch::async, [&]() {
+			std::vector <pvc3_context *> made;
+			for (int const dev : opt.devices)
+			{
+				pvc3_context *ctx{};
+				if (pvc3_context_create(dev, &ctx)) throw std::runtime_error(std::string("pvc3_context_create: ") + pvc3_last_error());
+				made.push_back(ctx);
+			}
+			return made;
+		});
 		msa_index_file msa;
 		msa.load(opt.msa_index);
 		pvc3_index *index{};
@@ -399,14 +412,9 @@ int main(int argc, char **argv)
 			}
 		}
 		double t_startup = 0.0;
-		std::vector <pvc3_context *> contexts;
-		for (int const dev : opt.devices)
-		{
-			pvc3_context *ctx{};
-			check(pvc3_context_create(dev, &ctx), "pvc3_context_create");
+		std::vector <pvc3_context *> contexts = contexts_coming.get();
+		for (pvc3_context *ctx : contexts)
 			check(pvc3_context_upload_index(ctx, index), "pvc3_context_upload_index");		// the index is replicated on every GPU
-			contexts.push_back(ctx);
-		}
 
 		alignment_writer writer;
 		writer.set_threads(opt.threads);
@@ -486,23 +494,58 @@ int main(int argc, char **argv)
 			auto const t_read = now();
 			struct add_time { double &acc; std::chrono::steady_clock::time_point t0; ~add_time() { acc += std::chrono::duration <double>(std::chrono::steady_clock::now() - t0).count(); } } timer{tm.read, t_read};
 			dst.clear();
-			while (!eof && (dst.size() < opt.batch_size || (dst.size() & 3)))
+			// Whether a record passes the filters (project_alignments.cc:528-570); counts it either way.
+			auto keeps = [&](bam_view const &rec) -> bool {
+				uint16_t const fl = rec.flag();
+				if (fl & (0x4 | 0x200 | 0x400)) { ++st.flags_not_matched; return false; }		// unmapped, QC fail, duplicate (:528-537)
+				if (rec.ref_id() < 0) { ++st.ref_id_missing; return false; }						// :546-551
+				if (rec.pos() < 0) { ++st.flags_not_matched; return false; }						// :553-564
+				if (0 == rec.l_seq()) { ++st.seq_missing; return false; }							// :566-570
+				if ((std::size_t) rec.ref_id() >= src_entries.size()) throw std::runtime_error("record with a reference id outside the header");
+				++st.matched_reads;
+				return true;
+			};
+			auto wanted = [&]() { return dst.size() < opt.batch_size || (dst.size() & 3); };
+			while (!eof && wanted())
 			{
+				// BAM from a BGZF file: the whole records that lie in the inflated piece at hand are framed in place and copied
+				// to the arena in one go (length fields and filtered records included; they are just not listed).
+				uint8_t const *p{};
+				std::size_t avail = 0;
+				if (reader.bam_span(p, avail))
+				{
+					std::size_t used = 0;
+					std::size_t const base = dst.raw.size();
+					while (wanted() && avail - used >= 4)
+					{
+						int32_t block_size;
+						std::memcpy(&block_size, p + used, 4);
+						if (block_size < 32) throw io_error("truncated BAM record");
+						if (avail - used < 4 + (std::size_t) block_size) break;
+						bam_view const rec{p + used + 4, (std::size_t) block_size};
+						if (rec.aux_offset() > rec.size()) throw io_error("malformed BAM record: its name, CIGAR, SEQ and QUAL exceed block_size");
+						uint64_t const idx = input_index++;
+						if (keeps(rec))
+						{
+							dst.begin.push_back(base + used + 4); dst.len.push_back((uint32_t) block_size);
+							dst.input_index.push_back(idx);
+						}
+						used += 4 + (std::size_t) block_size;
+					}
+					if (used)
+					{
+						dst.raw.insert(dst.raw.end(), p, p + used);
+						reader.consume(used);
+						continue;
+					}
+				}
+				// one record the slow way: text input, or a record that straddles two pieces
 				std::size_t const at = dst.raw.size();
 				if (!reader.next_append(dst.raw, scratch)) { eof = true; break; }
 				bam_view const rec{dst.raw.data() + at, dst.raw.size() - at};
 				uint64_t const idx = input_index++;
-				uint16_t const fl = rec.flag();
-				bool keep = false;
-				if (fl & (0x4 | 0x200 | 0x400)) ++st.flags_not_matched;		// unmapped, QC fail, duplicate (:528-537)
-				else if (rec.ref_id() < 0) ++st.ref_id_missing;				// :546-551
-				else if (rec.pos() < 0) ++st.flags_not_matched;				// :553-564
-				else if (0 == rec.l_seq()) ++st.seq_missing;				// :566-570
-				else if ((std::size_t) rec.ref_id() >= src_entries.size()) throw std::runtime_error("record with a reference id outside the header");
-				else keep = true;
-				if (!keep) { dst.raw.resize(at); continue; }
-				++st.matched_reads;
-				dst.off.push_back(dst.raw.size());
+				if (!keeps(rec)) { dst.raw.resize(at); continue; }
+				dst.begin.push_back(at); dst.len.push_back((uint32_t) (dst.raw.size() - at));
 				dst.input_index.push_back(idx);
 			}
 		};

@@ -606,6 +606,10 @@ public:
 		return false;
 	}
 
+	// BAM from a BGZF file: the inflated bytes not yet read, for framing whole records in place (see byte_reader::span).
+	bool bam_span(uint8_t const *&p, std::size_t &n) { return m_is_bam && m_in.span(p, n); }
+	void consume(std::size_t n) { m_in.consume(n); }
+
 	// The next record's bytes appended to `arena` (no allocation per record); returns false at the end of the input.
 	bool next_append(std::vector <uint8_t> &arena, bam_record &scratch)
 	{

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <algorithm>
@@ -69,7 +70,12 @@ class byte_reader
 	bool m_started{};
 	std::future <bool> m_ahead;
 
-	static constexpr std::size_t CHUNK = 32u << 20;
+	// Compressed bytes read (and inflated) per piece; PVC3_BGZF_CHUNK overrides it so that a test can make records straddle pieces.
+	std::size_t const CHUNK = []() -> std::size_t {
+		char const *e = std::getenv("PVC3_BGZF_CHUNK");
+		std::size_t const v = e ? (std::size_t) std::strtoull(e, nullptr, 10) : 0;
+		return v ? v : (std::size_t) (32u << 20);
+	}();
 
 	struct block { std::size_t in_off, in_len, out_off, out_len; uint32_t crc; };
 

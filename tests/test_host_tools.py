@@ -26,8 +26,8 @@ def tools():
 	return {n: os.path.join(BIN, n) for n in ("panvc3_index_msa", "panvc3_project_alignments", "panvc3_convert_bed_positions", "panvc3_rewrite_cigar")}
 
 
-def _run(cmd, cwd=None, check=True):
-	p = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+def _run(cmd, cwd=None, check=True, env=None):
+	p = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=None if env is None else dict(os.environ, **env))
 	if check and p.returncode != 0:
 		raise AssertionError("%s failed (%d): %s" % (cmd[0], p.returncode, p.stderr.decode()[-2000:]))
 	return p
@@ -198,6 +198,10 @@ def test_io_round_trip_sam_bam(tools, tmp_path):
 	# the BGZF layer cuts blocks at fixed offsets: the file does not depend on the number of deflate threads
 	_run([tools["panvc3_project_alignments"], "--io-only", "--threads=1", "-a", "in.sam", "-b", "-o", "t1.bam"], cwd=tmp_path)
 	_run([tools["panvc3_project_alignments"], "--io-only", "--threads=7", "-a", "t1.bam", "-b", "-o", "t7.bam"], cwd=tmp_path)
+	# the BGZF reader in pieces far smaller than its 32 MB (even than a block): the records and the header straddle them
+	for chunk in ("700", "5000"):
+		_run([tools["panvc3_project_alignments"], "--io-only", "-a", "t1.bam", "-o", "chunk%s.sam" % chunk], cwd=tmp_path, env={"PVC3_BGZF_CHUNK": chunk})
+		assert open(tmp_path / ("chunk%s.sam" % chunk)).read() == open(tmp_path / "back.sam").read()
 	assert open(tmp_path / "t1.bam", "rb").read() == open(tmp_path / "t7.bam", "rb").read() == open(tmp_path / "x.bam", "rb").read()
 	# a truncated BGZF file is an error, not a short read
 	raw = open(tmp_path / "x.bam", "rb").read()
@@ -359,6 +363,13 @@ def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_m
 	_run([tools["panvc3_project_alignments"], "-a", "alignments.sam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-u", "order.txt", "--record-index-tag=XI", "-t", "XS", "-t", "YS", "-b", "-o", "out.bam"], cwd=tmp_path)
 	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "out.bam", "-o", "out.sam"], cwd=tmp_path)
 	assert [l for l in open(tmp_path / "out.sam").read().split("\n") if l and not l.startswith("@")] == expect
+	# BAM in (the records are framed in place inside the inflated pieces of the file; pieces of 3 000 compressed bytes make
+	# them straddle), small batches, SAM out: the same records again
+	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "alignments.sam", "-b", "-o", "alignments.bam"], cwd=tmp_path)
+	for env in (None, {"PVC3_BGZF_CHUNK": "3000"}):
+		p3 = _run([tools["panvc3_project_alignments"], "-a", "alignments.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-u", "order.txt",
+				   "--record-index-tag=XI", "-t", "XS", "-t", "YS", "--batch-size=64"], cwd=tmp_path, env=env)
+		assert [l for l in p3.stdout.decode().split("\n") if l and not l.startswith("@")] == expect
 	text, refs, got = bamio.read_bam(tmp_path / "out.bam")
 	assert refs == [("test", 10000)]
 	for g in got[:50]:

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpvc3_hip.so")
-SOURCES = ["api.cpp", "index.cpp", "kernels.hip", "project_fast.hip", "project_mid.hip", "project_general.hip", "realign.hip", "mapq.hip"]
+SOURCES = ["api.cpp", "index.cpp", "kernels.hip", "project_fast.hip", "project_probes.hip", "project_mid.hip", "project_general.hip", "realign.hip", "mapq.hip"]
 ARCH = "gfx950"
 
 

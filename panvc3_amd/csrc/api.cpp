@@ -64,7 +64,11 @@ struct pvc3_context
 	uint32_t mid_path{1};
 	uint32_t packed_dp{1};
 	uint32_t paired_blocks{1};			// upload_index: paired copies of the gap bit-vector blocks (dev_entry::paired)
-	uint32_t text_window{1};			// upload_index: windowed copies of the packed texts (dev_entry::text4w)
+	uint32_t text_window{1};			// upload_index: windowed copies of the packed texts (dev_entry::text4w; only without position windows)
+	uint32_t position_windows{1};		// upload_index: position windows (dev_entry::pwin) when they fit the device
+	uint32_t window_read_length{150};	// longest read whose compare is to be served from one window: up to 158 bases -> 128-byte windows, else 256
+	uint64_t window_reserve{UINT64_C(24) << 30};	// HBM that must stay free after the windows (batches, arenas, trace)
+	bool have_windows{};				// the uploaded index has them: k_project_fast runs, otherwise k_project_fast_probes
 	uint8_t *scratch{};
 	uint64_t scratch_alloc{};
 	uint32_t *trace{};					// trace words of the packed alignment kernels
@@ -258,7 +262,8 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	HIP_TRY(hipMemsetAsync(b->work.counters, 0, sizeof(dev_counters), s));
 	HIP_TRY(hipMemsetAsync(b->work.wave_stats, 0, 3 * (uint64_t) project_wave_count(b->n) * WAVE_STATS * sizeof(unsigned long long), s));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
-	if (int const e = launch_project_fast(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s)) return set_error(PVC3_E_HIP, "k_project_fast launch: %s", hipGetErrorString((hipError_t) e));
+	if (int const e = (ctx->have_windows ? launch_project_fast : launch_project_probes)(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s))
+		return set_error(PVC3_E_HIP, "k_project_fast launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
 	if (ctx->mid_path)
 		if (int const e = launch_project_mid(ctx->d_entries, ctx->n_entries, b->in, b->work, s)) return set_error(PVC3_E_HIP, "k_project_mid launch: %s", hipGetErrorString((hipError_t) e));
@@ -442,6 +447,9 @@ int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value)
 	else if ("packed_dp" == k) ctx->packed_dp = (0 != value);
 	else if ("paired_blocks" == k) ctx->paired_blocks = (0 != value);		// takes effect at the next pvc3_context_upload_index
 	else if ("text_window" == k) ctx->text_window = (0 != value);			// likewise
+	else if ("position_windows" == k) ctx->position_windows = (0 != value);	// likewise
+	else if ("window_read_length" == k) ctx->window_read_length = (uint32_t) ((value > 4096) ? 4096 : value);	// likewise
+	else if ("window_reserve" == k) ctx->window_reserve = (uint64_t) value;	// likewise
 	else return set_error(PVC3_E_INVALID, "pvc3_context_set_option: unknown option %s", key);
 	return PVC3_OK;
 }
@@ -461,10 +469,44 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	free_index_replica(ctx);
 	std::vector <dev_entry> table(idx->entries.size());
+	// Position windows: two bytes per source position of every entry that has a destination.  Built when they leave
+	// `window_reserve` bytes of the device free (288 GB of HBM: a human-scale index with twenty founders fits); otherwise the
+	// index is served by the select samples and the paired blocks alone (k_project_fast_probes).
+	uint32_t const pwin_shift = (ctx->window_read_length <= 158) ? 6 : 7;
+	auto partner_of = [&](size_t i) -> size_t {
+		host_entry const &e = idx->entries[i];
+		if (!e.text.empty()) return i;			// an entry with a text is its own destination (reads aligned to the reference row)
+		size_t best = idx->entries.size();
+		for (size_t j = 0; j < idx->entries.size(); ++j)
+		{
+			host_entry const &o = idx->entries[j];
+			if (j == i || o.text.empty() || o.n_cols != e.n_cols) continue;
+			size_t const dist = (j > i) ? (j - i) : (i - j);
+			if (best == idx->entries.size() || dist < ((best > i) ? (best - i) : (i - best))) best = j;
+		}
+		return best;
+	};
+	bool windows = 0 != ctx->position_windows;
+	if (windows)
+	{
+		uint64_t need = 0, plain = 0;
+		for (size_t i = 0; i < idx->entries.size(); ++i)
+		{
+			host_entry const &e = idx->entries[i];
+			plain += 3 * e.blocks.size() * sizeof(uint64_t) + 2 * e.text.size();
+			if (e.n_zeros && partner_of(i) < idx->entries.size())
+				need += (((e.n_zeros - 1) >> pwin_shift) + 1) * (UINT64_C(2) << pwin_shift);
+		}
+		size_t free_b = 0, total_b = 0;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		windows = need && (need + plain + ctx->window_reserve <= free_b);
+	}
+	ctx->have_windows = false;
 	for (size_t i = 0; i < idx->entries.size(); ++i)
 	{
 		host_entry const &e = idx->entries[i];
 		dev_entry &d = table[i];
+		d.pwin = nullptr; d.pwin_partner = NO_PARTNER; d.pwin_shift = pwin_shift;
 		PVC3_TRY(dev_upload(&d.blocks, e.blocks.data(), e.blocks.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
 		PVC3_TRY(dev_upload(&d.sel, e.sel.data(), e.sel.size(), 64, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
 		d.text = nullptr;
@@ -486,7 +528,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 			HIP_TRY(hipMemsetAsync(p4, 0, bytes4, ctx->stream));
 			HIP_TRY((hipError_t) launch_pack_text4(d.text, e.text.size(), p4, ctx->stream));
 			d.text4 = p4;
-			if (ctx->text_window)
+			if (ctx->text_window && !windows)
 			{
 				// Every line the kernel can address: line k for a run that starts at nibble n has k = n / STEP <= nibbles / STEP.
 				uint64_t const n_lines = (TEXT4_FRONT + e.text.size()) / TEXT_WINDOW_STEP + 1;
@@ -525,6 +567,23 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 				HIP_TRY(hipStreamSynchronize(ctx->stream));		// `both` is pageable and leaves scope
 				d.partner = (uint32_t) best;
 			}
+		}
+	}
+	if (windows)
+	{
+		for (size_t i = 0; i < idx->entries.size(); ++i)
+		{
+			host_entry const &e = idx->entries[i];
+			size_t const partner = partner_of(i);
+			if (0 == e.n_zeros || partner >= idx->entries.size()) continue;
+			uint64_t const n_windows = ((e.n_zeros - 1) >> pwin_shift) + 1;
+			uint8_t *pw{};
+			PVC3_TRY(dev_alloc(&pw, n_windows * (UINT64_C(2) << pwin_shift) + 16, &ctx->index_allocs, &ctx->index_bytes));
+			if (int const rc = launch_build_pwin(table[i], table[partner], pwin_shift, n_windows, pw, ctx->stream))
+				return set_error(PVC3_E_HIP, "k_pwin launch: %s", hipGetErrorString((hipError_t) rc));
+			table[i].pwin = pw;
+			table[i].pwin_partner = (uint32_t) partner;
+			ctx->have_windows = true;
 		}
 	}
 	dev_entry const *d_table{};

@@ -353,6 +353,64 @@ __global__ __launch_bounds__(256) void k_window_text4(uint8_t const *__restrict_
 	}
 }
 
+// ---- position windows (dev_entry::pwin) ---------------------------------------------------------------------------------------
+// Headers: one thread per window.  c0 = select0(P + 1) of the source row from the select samples, r0 = rank0 of the
+// destination row there, clean = the columns from c0 on without a gap in either row (the padding past the last column is
+// all gaps, so the count stops there by itself).
+__global__ __launch_bounds__(256) void k_pwin_headers(dev_entry const S, dev_entry const D, uint32_t shift, uint64_t n_windows, uint8_t *__restrict__ out)
+{
+	uint64_t const stride = (uint64_t) gridDim.x * blockDim.x;
+	uint64_t const wbytes = UINT64_C(2) << shift;
+	row_view const sv{S.blocks, BLOCK_WORDS, BLOCK_COLS}, dv{D.blocks, BLOCK_WORDS, BLOCK_COLS};
+	for (uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; k < n_windows; k += stride)
+	{
+		uint32_t const P = (uint32_t) (k << shift);		// < n_zeros by the number of windows
+		col_pos const g = locate(BLOCK_COLS, select_guess(S.sel, P, 0).col);
+		uint32_t const c0 = dir_select0(sv, P, dir_load(sv, g.blk, pair_of(g)));
+		col_pos const p0 = locate(BLOCK_COLS, c0);
+		uint32_t const r0 = dir_rank(dv, dir_load(dv, p0.blk, pair_of(p0)), p0);
+		uint32_t clean = 0, col = c0;
+		while (clean < PWIN_CLEAN_CAP)
+		{
+			col_pos const p = locate(BLOCK_COLS, col);
+			uint64_t const wi = (uint64_t) p.blk * BLOCK_WORDS + 1 + p.w;
+			uint64_t const bad = (S.blocks[wi] | D.blocks[wi]) >> p.bit;
+			uint32_t const avail = 64 - p.bit;
+			uint32_t t = bad ? ctz64(bad) : 64;
+			t = (t < avail) ? t : avail;
+			clean += t; col += t;
+			if (t < avail) break;
+		}
+		typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+		*(u32x4 *) (out + wbytes * k) = u32x4{c0, r0, (clean < PWIN_CLEAN_CAP) ? clean : PWIN_CLEAN_CAP, 0};
+	}
+}
+
+// Text: 16 bytes per thread, 32 nibbles of the destination's packed text from base r0 - PWIN_TEXT_BACK + 32 j on.
+__global__ __launch_bounds__(256) void k_pwin_text(uint8_t const *__restrict__ text4, uint32_t shift, uint64_t n_windows, uint8_t *__restrict__ out)
+{
+	uint64_t const stride = (uint64_t) gridDim.x * blockDim.x;
+	uint32_t const wbytes = 2u << shift, pieces = wbytes / 16 - 1, lg = shift - 3;		// 8 or 16 sixteen-byte pieces per window, the first is the header
+	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < (n_windows << lg); i += stride)
+	{
+		uint64_t const k = i >> lg;
+		uint32_t const j = (uint32_t) (i & ((1u << lg) - 1));
+		if (j >= pieces) continue;
+		uint32_t const r0 = *(uint32_t const *) (out + (uint64_t) wbytes * k + 4);
+		uint64_t const n0 = (uint64_t) r0 + TEXT4_FRONT - PWIN_TEXT_BACK + 32 * j;
+		uint8_t const *p = text4 + (n0 >> 1);
+		uint64_t v[2];
+		__builtin_memcpy(v, p, 16);
+		if (n0 & 1)
+		{
+			uint64_t const next = p[16];
+			v[0] = (v[0] >> 4) | (v[1] << 60);
+			v[1] = (v[1] >> 4) | (next << 60);
+		}
+		__builtin_memcpy(out + (uint64_t) wbytes * k + PWIN_HEADER + 16 * j, v, 16);
+	}
+}
+
 // Folds the per-wave statistics of k_project_fast / k_project_mid / k_project_general (blockIdx.y) into the counters:
 // one thread per wave row, one atomic per block and counter.
 __global__ __launch_bounds__(256) void k_reduce_stats(uint32_t n_waves, dev_batch_work const W)
@@ -418,6 +476,14 @@ int launch_window_text4(uint8_t const *text4, uint64_t n_lines, uint8_t *out, vo
 {
 	if (n_lines)
 		hipLaunchKernelGGL(k_window_text4, dim3(grid_for(8 * n_lines, 256, 256 * 32)), dim3(256), 0, (hipStream_t) stream, text4, n_lines, out);
+	return (int) hipGetLastError();
+}
+
+int launch_build_pwin(dev_entry const &src, dev_entry const &dst, uint32_t shift, uint64_t n_windows, uint8_t *out, void *stream)
+{
+	if (0 == n_windows) return 0;
+	hipLaunchKernelGGL(k_pwin_headers, dim3(grid_for(n_windows, 256, 256 * 32)), dim3(256), 0, (hipStream_t) stream, src, dst, shift, n_windows, out);
+	hipLaunchKernelGGL(k_pwin_text, dim3(grid_for(n_windows << (shift - 3), 256, 256 * 64)), dim3(256), 0, (hipStream_t) stream, dst.text4, shift, n_windows, out);
 	return (int) hipGetLastError();
 }
 

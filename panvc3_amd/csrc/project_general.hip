@@ -52,6 +52,13 @@ __global__ __launch_bounds__(256) void k_project_general(dev_entry const *__rest
 			A.col = (uint32_t) stash;
 			A.ref_consumed = (uint32_t) (stash >> 32);
 			A.r0 = W.dst_pos[rec];
+			// What k_project_fast's position window left open of the start (all of it when the pair of entries has no windows).
+			uint32_t const skip = W.cig_n[rec];
+			if (skip && A.src_e < n_entries && A.dst_e < n_entries)
+			{
+				if (resolve_start(entries[A.src_e], entries[A.dst_e], A.dst_e, A.src_pos, A.col, A.r0, skip))
+					W.dst_pos[rec] = A.r0;
+			}
 		}
 
 		G.flags = 0; G.cig_n = 0; G.loc_lo = 0; G.loc_hi = 0;

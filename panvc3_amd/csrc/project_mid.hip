@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 4) void k_project_mid(dev_entry const *__restr
 		{
 			// a dense list: the record numbers are nearly consecutive and the arrays are read as streams
 			uint32_t const rr = rec_list[base + lane];
-			item.rec = rr; item.col0 = (uint32_t) W.cig_loc[rr]; item.r0 = W.dst_pos[rr];
+			item.rec = rr; item.col0 = (uint32_t) W.cig_loc[rr]; item.r0 = W.dst_pos[rr]; item.skip = W.cig_n[rr];
 			item.src_e = in.src_entry[rr]; item.dst_e = in.dst_entry[rr];
 			item.cig_begin = in.cigar_off[rr]; item.n_cigar = (uint32_t) (in.cigar_off[rr + 1] - item.cig_begin);
 			item.seq_begin = in.seq_off[rr]; item.l_seq = in.l_seq[rr];
@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256, 4) void k_project_mid(dev_entry const *__restr
 		bool punt = false;
 		lane_sink out;
 		out.init(my_tok);
-		uint32_t cols = 0, ref_span = 0, l_seq = 0;
+		uint32_t cols = 0, ref_span = 0, l_seq = 0, col_start = 0;
+		bool start_moved = false;
 
 		// Which form of the compare: by the gap density of the rows these records lie on (more than one gap column in 16 in
 		// either row means runs of compared columns of some twenty bases), decided for the wave.
@@ -257,7 +258,13 @@ __global__ __launch_bounds__(256, 4) void k_project_mid(dev_entry const *__restr
 			uint32_t const *ops = in.cigar + item.cig_begin;
 			uint8_t const *seq = in.seq4 + item.seq_begin;
 			l_seq = item.l_seq;
-			uint32_t const col0 = item.col0, r0 = item.r0;		// start column and projected position, from k_project_fast
+			// Start column and projected position: from k_project_fast, or finished here from what its position window knew.
+			uint32_t col0 = item.col0, r0 = item.r0;
+			if (resolve_start(S, D, item.dst_e, item.skip ? in.src_pos[rec] : 0, col0, r0, item.skip))
+			{
+				W.dst_pos[rec] = r0;
+				start_moved = true;
+			}
 			uint32_t col = col0, r = r0, q = 0, steps = 0;
 			// The two rows' gap words, from the paired copy (one 128-byte line for both) when the destination is the source's
 			// partner.  The words of the NEXT 64 columns are requested a step ahead: a step ends at a word boundary or inside
@@ -382,6 +389,7 @@ __global__ __launch_bounds__(256, 4) void k_project_mid(dev_entry const *__restr
 			punt = punt || (out.n_out > MID_TOKENS);
 			cols = col - col0;
 			ref_span = r - r0;
+			col_start = col0;
 		}
 
 		// ---- wave level: arena space for the finished records, copy, per-record outputs ------------------------------------------
@@ -401,6 +409,12 @@ __global__ __launch_bounds__(256, 4) void k_project_mid(dev_entry const *__restr
 			uint64_t const m = ballot(mine && punt);
 			if ((m >> lane) & 1) punt_list[n_punt + mbcnt64(m)] = rec;
 			n_punt += popc64(m);
+			// k_project_general reads the start of a record from the work arrays: leave what was found here.
+			if (mine && punt && start_moved)
+			{
+				*(uint32_t *) &W.cig_loc[rec] = col_start;		// low half: the column (the high half keeps the reference-consuming length)
+				W.cig_n[rec] = 0;
+			}
 		}
 		{
 			// Work list for k_realign.

@@ -1,25 +1,21 @@
-// project_fast.hip — k_project_fast: lane = record.  First kernel of the hot path, over an index with position windows.
+// project_probes.hip — k_project_fast_probes: lane = record.  First kernel of the hot path for an index WITHOUT position
+// windows (dev_entry::pwin; pvc3_context_upload_index leaves them out when they do not fit the device or are switched off);
+// with them k_project_fast (project_fast.hip) runs instead.  Same results, same work lists.
 //
-// A position window (dev_entry::pwin, pvc3_internal.hpp) holds, in the ONE 128- or 256-byte line that a record's source
-// position addresses by itself, everything rewrite_cigar needs of the index for an alignment without gap columns: the
-// start column and the projected position (aligned_position + project_aligned_position, include/panvc3/rewrite_cigar.hh:
-// 51-56), the number of columns from there on that have no gap in either row, and the destination text of those columns.
-// So for 64 records at a time per wavefront (coalesced SoA descriptor loads):
+// For 64 records at a time per wavefront (coalesced SoA descriptor loads):
 //   1. validates the CIGAR and the positions (per-record status, same rules as the oracle's batch driver);
-//   2. requests the window's 16-byte header — and, at once, the compare's loads: SEQ and the window's text, whose addresses
-//      depend on the descriptors only.  One memory round trip after the descriptors instead of the three of
-//      k_project_fast_probes (select sample -> gap blocks -> text), one random line per record instead of three;
-//   3. FAST PATH.  A record is "simple" when its CIGAR is [S|H] (M|=|X)+ [S|H] with non-zero counts and it consumes fewer
-//      than 256 reference bases; it is finished here when the window is clean from its first column to the record's last
-//      (no gap column in either row) and its text lies in the window's line.  rewrite_cigar (rewrite_cigar.hh:80-118) is
-//      then a compare of the query against the destination text (4-bit codes): n_words lanes per record build the mismatch
-//      words, the lane emits the = / X runs itself (cigar_buffer semantics, libpanvc3/cigar.cc:54-95).  Such a record has no
-//      indel run, so it is finished;
-//   4. the mate's project_position (include/panvc3/msa_index.hh:253-258, project_alignments.cc:897-901): the neighbouring
-//      lane's result when the mate is the neighbouring record, a window of its own otherwise;
-//   5. every other valid record goes to the wave's work list for k_project_mid with what the window told about its start:
-//      the start column and projected position themselves, or the window's last clean column and the number of source
-//      positions still to go (resolve_start, wave.hpp).
+//   2. aligned_position + project_aligned_position (include/panvc3/rewrite_cigar.hh:51-56): one select sample, then four
+//      probes of 24 bytes (wave.hpp: word 0 + one pair of a block) into the paired copy of the two rows give the start
+//      column, the projected position and the ranks of both rows at the end of the span;
+//   3. the mate's project_position (include/panvc3/msa_index.hh:253-258, project_alignments.cc:897-901);
+//   4. FAST PATH.  A record is "simple" when its CIGAR is [S|H] (M|=|X)+ [S|H] with non-zero counts, it consumes at most
+//      256 reference bases and neither row has a gap among the columns it spans (the ranks of both rows advance by exactly
+//      that many bases).  Then rewrite_cigar (rewrite_cigar.hh:80-118) degenerates to a byte compare of the query against the
+//      destination text (4-bit codes; from the windowed copy when the read fits one of its lines): n_words lanes per record
+//      build the mismatch words, then the lane emits the = / X runs itself (cigar_buffer semantics, libpanvc3/cigar.cc:54-95).
+//      Such a record has no indel run, so it is finished.
+//   5. Every other valid record goes to the wave's work list for k_project_mid (REC_SLOW; start column, projected position
+//      and reference-consuming length are left in the work arrays).
 #include <hip/hip_runtime.h>
 
 #include "pvc3_internal.hpp"
@@ -33,7 +29,7 @@ namespace {
 
 constexpr uint32_t FAST_MAX_BASES = 256;
 constexpr uint32_t FAST_WORDS = FAST_MAX_BASES / 32;
-constexpr uint32_t LDS_ENTRIES = 128;
+constexpr uint32_t LDS_ENTRIES = 256;
 constexpr uint32_t STAGE_TOKENS = 64 * FAST_WORDS;		// uint32 in a wave's LDS area (mismatch words, then output operations)
 #ifndef PVC3_FAST_PASSES
 #define PVC3_FAST_PASSES 4
@@ -42,29 +38,6 @@ constexpr uint32_t FAST_PASSES = PVC3_FAST_PASSES;	// passes of the cooperative 
 #ifndef PVC3_FAST_MIN_WAVES
 #define PVC3_FAST_MIN_WAVES 4
 #endif
-
-typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
-
-// What this kernel needs of an entry, 32 bytes: the head of the table lives in LDS in this form.
-struct fast_entry
-{
-	uint8_t const *pwin;
-	uint32_t n_zeros, n_cols;
-	uint32_t partner;			// destination the windows were made for
-	uint32_t text_len;			// of that destination
-	uint32_t shift;
-	uint32_t pad;
-};
-static_assert(32 == sizeof(fast_entry), "fast_entry layout");
-
-__device__ __forceinline__ fast_entry make_fast_entry(dev_entry const *__restrict__ entries, uint32_t id)
-{
-	dev_entry const &e = entries[id];
-	fast_entry f;
-	f.pwin = e.pwin; f.n_zeros = e.n_zeros; f.n_cols = e.n_cols; f.partner = e.pwin_partner; f.shift = e.pwin_shift; f.pad = 0;
-	f.text_len = e.pwin ? entries[e.pwin_partner].text_len : 0;
-	return f;
-}
 
 // Mismatch bits of 32 consecutive query nibbles (16 bytes of SEQ) against 32 text nibbles (t, nibble-linear).
 __device__ __forceinline__ uint32_t mismatch32(u64x2 const &qq, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3)
@@ -106,7 +79,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 #define FAST_STAMP(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W, uint32_t use_fast_path)
+__global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast_probes(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W, uint32_t use_fast_path)
 {
 	uint32_t const lane = lane_id();
 	uint32_t const wave = rfl((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -122,10 +95,10 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	slow_item *slow_items = W.slow_items + 64 * g_begin;
 	bool items_mode = true;					// wave-uniform: decided by the wave's first group (see slow_item)
 
-	// The entry table is read by every lane of every group: keep its head in LDS, in the form this kernel needs.
-	__shared__ fast_entry lds_entries[LDS_ENTRIES];
+	// The entry table is read by every lane of every group: keep its head in LDS.
+	__shared__ dev_entry lds_entries[LDS_ENTRIES];
 	for (uint32_t i = threadIdx.x; i < LDS_ENTRIES && i < n_entries; i += blockDim.x)
-		lds_entries[i] = make_fast_entry(entries, i);
+		lds_entries[i] = entries[i];
 	__syncthreads();
 	// Per-wave staging for the cooperative compare: record descriptors out, mismatch words back.
 	__shared__ u64x2 lds_desc[4][64];
@@ -133,7 +106,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	uint32_t const wave_in_block = rfl(threadIdx.x >> 6);
 	u64x2 *my_desc = lds_desc[wave_in_block];
 	uint32_t *my_mask = lds_mask[wave_in_block];
-	auto get_entry = [&](uint32_t id) -> fast_entry { return (id < LDS_ENTRIES) ? lds_entries[id] : make_fast_entry(entries, id); };
+	auto get_entry = [&](uint32_t id) -> dev_entry { return (id < LDS_ENTRIES) ? lds_entries[id] : entries[id]; };
 	// A batch whose offsets are malformed (k_validate_batch; a pipelined batch is checked while its kernels are already
 	// queued) is not read at all: every record is rejected and the host reports PVC3_E_INVALID.
 	bool const batch_bad = 0xFFFFFFFFu != rfl(*W.first_bad);
@@ -166,11 +139,17 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 
 		FAST_STAMP(0);		// descriptors
 		bool const e_ok = (src_e < n_entries) && (dst_e < n_entries);
-		fast_entry const S = get_entry(e_ok ? src_e : 0);
-		uint32_t const d_cols = get_entry(e_ok ? dst_e : 0).n_cols;
+		dev_entry const S = get_entry(e_ok ? src_e : 0);
+		dev_entry const D = get_entry(e_ok ? dst_e : 0);
+		row_pair const rows = rows_of(S, D, dst_e);
+		uint32_t const *s_sel = S.sel;
+		uint32_t const s_zeros = S.n_zeros, s_cols = S.n_cols;
+		uint8_t const *d_text4 = D.text4, *d_text4w = D.text4w;
+		uint32_t const d_text_len = D.text_len, d_cols = D.n_cols;
 
 		// ---- CIGAR: validation + shape automaton of the fast path (first four operations from one 16-byte load) ----------------
 		uint32_t const *ops = in.cigar + cig_begin;
+		typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 		u32x4 pre4;
 		__builtin_memcpy(&pre4, ops, 16);					// the CIGAR buffer is padded by the host side
 		uint32_t const pre[4] = {pre4.x, pre4.y, pre4.z, pre4.w};
@@ -204,68 +183,76 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		if (batch_bad) status = PVC3_ST_QUERY_RANGE;
 		else if (!e_ok) status = PVC3_ST_SRC_RANGE;
 		else if (bad_op) status = PVC3_ST_CIGAR_OP;
-		else if (S.n_cols != d_cols || (uint64_t) src_pos + (ref_consumed ? ref_consumed : 1u) > S.n_zeros) status = PVC3_ST_SRC_RANGE;
+		else if (s_cols != d_cols || (uint64_t) src_pos + (ref_consumed ? ref_consumed : 1u) > s_zeros) status = PVC3_ST_SRC_RANGE;
 		else if (query_consumed > l_seq) status = PVC3_ST_QUERY_RANGE;
 		bool const ok = valid && (PVC3_ST_OK == status);
 
-		// ---- the record's window: header requested now, read after the compare ---------------------------------------------------------
-		bool const has_win = ok && S.pwin && S.partner == dst_e;
-		uint32_t const sh = S.shift;
-		uint32_t const o = src_pos & ((1u << sh) - 1);		// the record starts o source positions into its window
-		uint8_t const *line = S.pwin + ((uint64_t) (src_pos >> sh) << (sh + 1));
-		u32x4 hdr{0, 0, 0, 0};
-		if (has_win) hdr = *(u32x4 const *) line;
-
-		// The mate's window as well, unless the neighbouring lane is about to look the same position up (pairs stored back
-		// to back): project_position is a pure function of (entries, position).
-		bool const m_in = has_mate && mate_se < n_entries && mate_de < n_entries;
-		bool nb_cand;
-		{
-			uint32_t const n_se = (uint32_t) __shfl_xor((int) src_e, 1), n_de = (uint32_t) __shfl_xor((int) dst_e, 1);
-			uint32_t const n_pos = (uint32_t) __shfl_xor((int) src_pos, 1);
-			nb_cand = has_mate && (mate_se == n_se) && (mate_de == n_de) && (mate_pos == n_pos);
-		}
-		bool m_win = false, m_valid = false;
-		uint32_t m_sh = 0;
-		uint8_t const *m_line = nullptr;
-		u32x4 mh{0, 0, 0, 0};
-		if (m_in)
-		{
-			fast_entry const M = get_entry(mate_se);
-			m_valid = (mate_pos < M.n_zeros) && (M.n_cols == get_entry(mate_de).n_cols);		// msa_index.hh:253-258 needs the position to exist
-			m_win = m_valid && M.pwin && M.partner == mate_de;
-			m_sh = M.shift;
-			m_line = M.pwin + ((uint64_t) (mate_pos >> m_sh) << (m_sh + 1));
-			if (m_win && !nb_cand) mh = *(u32x4 const *) m_line;
-		}
-
-		// ---- fast path: the compare, on every record that can still turn out to be one --------------------------------------------------
+		// ---- start column and projected position (rewrite_cigar.hh:51-56) --------------------------------------------------------
+		uint32_t col = 0, r0 = 0;
+		bool fast = false;
 		uint32_t const lead_q = (OP_S == (lead & 0xf)) ? (lead >> 4) : 0;	// query bases before the M-type span
 		uint32_t const phase = lead_q & 1;
-		// Work in query-nibble positions u = t + phase counted from a byte boundary of SEQ, so that 32 positions are exactly
-		// 16 bytes of SEQ and 32 bytes of text; the mask is shifted back by `phase` afterwards.
-		uint32_t const nib = o + PWIN_TEXT_BACK - phase;		// nibble of the window's text that lines up with query position u = 0
-		bool cand;
+		if (ok)
 		{
+			// One select sample, then four probes (word 0 + one 16-byte pair of a block, wave.hpp) at the sample's guess for the
+			// start column and for the end column: both rows, all issued together.  A probe is fetched again when the guess
+			// did not hold (a gap column between the sample and the record).
+			select_guess_t const sg = select_guess(s_sel, src_pos, ref_consumed);
+			uint32_t const guess = sg.col;
+			FAST_STAMP(2);		// select sample
+			uint32_t const step = rows.src.step;
+			col_pos const g0 = locate(step, guess), g1 = locate_in(step, (sg.end < s_cols) ? sg.end : s_cols, g0.blk);		// (an interpolated guess may pass the last column)
+			dir_probe const ps0 = dir_load(rows.src, g0.blk, pair_of(g0));
+			dir_probe const pd0 = dir_load(rows.dst, g0.blk, pair_of(g0));
+			dir_probe const ps1 = dir_load(rows.src, g1.blk, pair_of(g1));
+			dir_probe const pd1 = dir_load(rows.dst, g1.blk, pair_of(g1));
+			col = dir_select0(rows.src, src_pos, ps0);
+			// (If the paired copy's blocks overlap, PAIRED_STEP < 448, the end of the span is looked up in the block of its start.)
+			col_pos const p0 = locate_in(step, col, g0.blk);
+			col_pos const p1 = locate_in(step, col + ref_consumed, p0.blk);
+			r0 = dir_rank(rows.dst, pd0, p0);
+			// No gap column in either row over the span <=> both ranks advance by exactly ref_consumed.
+			bool const gapless = (dir_rank(rows.src, ps1, p1) == src_pos + ref_consumed) && (dir_rank(rows.dst, pd1, p1) == r0 + ref_consumed);
 			bool const simple = (2 == shape || 3 == shape);
-			uint32_t const U = ref_consumed + phase;
-			// The compare reads the text in 16-byte pieces from the byte of its first nibble: pieces 0 .. U / 32.
-			bool const fits = PWIN_HEADER + (nib >> 1) + 16 * (U / 32 + 1) <= (2u << sh);
-			cand = use_fast_path && has_win && simple && (U < FAST_MAX_BASES) && fits;
+			fast = use_fast_path && simple && gapless && (ref_consumed + phase < FAST_MAX_BASES) && d_text4 && ((uint64_t) r0 + ref_consumed <= d_text_len);
 		}
-		bool fast = false;
-		uint32_t col = 0, r0 = 0, skip = PWIN_NO_ANCHOR;
+
+		FAST_STAMP(3);		// probes, select, ranks
+		// ---- mate (project_alignments.cc:897-901) -----------------------------------------------------------------------------------
+		// project_position is a pure function of (entries, position).  When the mate is the neighbouring record of the batch
+		// (pairs stored back to back) its projected position has just been computed by the neighbouring lane.
+		uint32_t mate = PVC3_NO_MATE;
+		{
+			uint32_t const n_se = (uint32_t) __shfl_xor((int) src_e, 1), n_de = (uint32_t) __shfl_xor((int) dst_e, 1);
+			uint32_t const n_pos = (uint32_t) __shfl_xor((int) src_pos, 1), n_r0 = (uint32_t) __shfl_xor((int) r0, 1);
+			bool const n_ok = 0 != __shfl_xor((int) ok, 1);
+			bool const from_neighbour = has_mate && n_ok && (mate_se == n_se) && (mate_de == n_de) && (mate_pos == n_pos);
+			if (from_neighbour)
+				mate = n_r0;
+			else if (has_mate && mate_se < n_entries && mate_de < n_entries)
+			{
+				mate = thread_project_position(get_entry(mate_se), get_entry(mate_de), mate_de, mate_pos);
+				acc_bytes += 4 + 64 + 64;		// select sample, one source block, one destination block
+			}
+		}
+
+		FAST_STAMP(4);		// mate
+		// ---- fast path ------------------------------------------------------------------------------------------------------------------
 		uint32_t f_n_out = 0;
 		uint64_t f_loc = 0;
 #ifdef PVC3_ABL_NO_COMPARE
 		if (false)
 #else
-		if (ballot(cand))
+		if (ballot(fast))
 #endif
 		{
-			uint32_t const Rc = cand ? ref_consumed : 0;
-			uint32_t const U = cand ? (Rc + phase) : 0;
+			uint32_t const R = fast ? ref_consumed : 0;
+			// Work in query-nibble positions u = t + phase counted from a byte boundary of SEQ, so that 32 positions are exactly
+			// 16 bytes of SEQ and 32 bytes of text; the mask is shifted back by `phase` afterwards.
+			uint32_t const U = fast ? (R + phase) : 0;
 			uint8_t const *qp = in.seq4 + seq_begin + (lead_q >> 1);
+			// Text nibble that lines up with query position u = 0 (base r0 - phase; the packed text has TEXT4_FRONT nibbles in front).
+			uint64_t const tn = (uint64_t) r0 + TEXT4_FRONT - phase;
 			// One more position than needed, so that the lane after a record's last full word exists (see below).
 			uint32_t const n_words = (wave_max(U) + 32) / 32;		// 1 .. FAST_WORDS
 			// The compare is done by n_words lanes per record, one 32-position word each: a wave instruction then touches the
@@ -274,7 +261,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			{
 				u64x2 d;
 				d.x = (uint64_t) qp | ((uint64_t) U << 48);
-				d.y = (uint64_t) (line + PWIN_HEADER + (nib >> 1)) | ((uint64_t) (nib & 1) << 63);
+				// From the windowed copy when the run fits a line of it (reads of up to 150 bases): one 128-byte line of text.
+				uint32_t const tn32 = (uint32_t) tn;				// text_len + TEXT4_FRONT < 2^32 (pvc3_index_set_reference)
+				uint32_t const line = tn32 / TEXT_WINDOW_STEP, in_line = tn32 - line * TEXT_WINDOW_STEP;
+				uint8_t const *tp = (d_text4w && U <= TEXT_WINDOW_MAX) ? (d_text4w + 128 * (uint64_t) line + (in_line >> 1)) : (d_text4 + (tn >> 1));
+				d.y = (uint64_t) tp | ((tn & 1) << 63);
 				my_desc[lane] = d;
 			}
 			wave_lds_sync();
@@ -283,6 +274,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				uint32_t const per = (64 * inv) >> 16;			// records per pass
 				uint32_t const sr = (lane * inv) >> 16;				// lane / n_words
 				uint32_t const w = lane - sr * n_words;
+				typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 				auto fetch = [&](uint32_t rr, bool act, u64x2 &qq, u32x4 &tt, uint32_t &left, uint32_t &odd4) {
 					u64x2 const dd = my_desc[act ? rr : lane];
 					uint32_t const Ur = (uint32_t) (dd.x >> 48);
@@ -334,65 +326,9 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			}
 			wave_lds_sync();
 			FAST_STAMP(5);		// compare
-		}
-
-		// ---- what the window says (rewrite_cigar.hh:51-56) ---------------------------------------------------------------------------------
-		if (has_win)
-		{
-			uint32_t const clean = hdr.z;
-			// Clean columns hold one source position and one destination position each: inside the clean stretch the start
-			// column and the projected position are sums.  Past it they are left to resolve_start (wave.hpp), from the
-			// stretch's end.
-			uint32_t const adv = (o < clean) ? o : clean;
-			col = hdr.x + adv;
-			r0 = hdr.y + adv;
-			skip = (o < clean) ? 0 : (o - clean + 1);
-			// No gap column in either row from the window's first column to the record's last.
-			fast = cand && (o + ref_consumed <= clean) && ((uint64_t) r0 + ref_consumed <= S.text_len);
-		}
-		bool const exact = has_win && (0 == skip);
-		FAST_STAMP(3);		// window header
-
-		// ---- mate (project_alignments.cc:897-901) -----------------------------------------------------------------------------------
-		uint32_t mate = PVC3_NO_MATE;
-		{
-			uint32_t const n_r0 = (uint32_t) __shfl_xor((int) r0, 1);
-			bool const n_exact = 0 != __shfl_xor((int) exact, 1);
-			if (nb_cand && n_exact)
-				mate = n_r0;
-			else if (m_valid)
-			{
-				if (m_win)
-				{
-					if (nb_cand) mh = *(u32x4 const *) m_line;		// the neighbour's own look-up is left to k_project_mid
-					uint32_t const mo = mate_pos & ((1u << m_sh) - 1);
-					if (mo < mh.z)
-						mate = mh.y + mo;
-					else
-					{
-						uint32_t c = mh.x + mh.z, r = mh.y + mh.z;
-						resolve_start(entries[mate_se], entries[mate_de], mate_de, mate_pos, c, r, mo - mh.z + 1);
-						mate = r;
-					}
-				}
-				else
-					mate = thread_project_position(entries[mate_se], entries[mate_de], mate_de, mate_pos);
-			}
-			if (m_in && !nb_cand)
-				acc_bytes += 4 + 64 + 64;		// select sample, one source block, one destination block
-		}
-		FAST_STAMP(4);		// mate
-
-		// ---- fast path: run counts, arena space, emission ----------------------------------------------------------------------------------
-#ifdef PVC3_ABL_NO_COMPARE
-		fast = false;
-#endif
-		if (ballot(fast))
-		{
-			uint32_t const R = fast ? ref_consumed : 0;
-			uint32_t const n_words = (wave_max(cand ? (ref_consumed + phase) : 0) + 32) / 32;		// as in the compare
 			uint32_t mu[FAST_WORDS + 1];
 			{
+				typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 				u32x4 const *mp = (u32x4 const *) (my_mask + lane * FAST_WORDS);
 				u32x4 const a = mp[0], b = mp[1];
 				uint32_t const all[FAST_WORDS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -498,7 +434,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				uint32_t const at = n_slow + mbcnt64(m);
 				slow_item it;
 				it.rec = (uint32_t) rec; it.col0 = col; it.r0 = r0; it.src_e = src_e;
-				it.dst_e = dst_e; it.n_cigar = n_cigar; it.l_seq = l_seq; it.skip = skip;
+				it.dst_e = dst_e; it.n_cigar = n_cigar; it.l_seq = l_seq; it.skip = 0;
 				it.cig_begin = cig_begin; it.seq_begin = seq_begin;
 				slow_items[at] = it;
 			}
@@ -510,9 +446,9 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		{
 			bool const slow = ok && !fast;
 			W.mate_dst_pos[rec] = mate;
-			W.dst_pos[rec] = ok ? r0 : 0;		// a rejected record has empty outputs; a record with skip != 0 gets its position from the walk kernels
+			W.dst_pos[rec] = ok ? r0 : 0;		// a rejected record has empty outputs
 			W.rec_flags[rec] = slow ? REC_SLOW : status;
-			W.cig_n[rec] = slow ? skip : f_n_out;	// (slow: see resolve_start; the walk kernels store the number of operations)
+			W.cig_n[rec] = f_n_out;
 			W.cig_loc[rec] = slow ? ((uint64_t) col | ((uint64_t) ref_consumed << 32)) : f_loc;
 			W.run_n[rec] = 0;
 			acc_failed += (PVC3_ST_OK != status);
@@ -552,22 +488,13 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	}
 }
 
-uint32_t grid_blocks(uint64_t n)
-{
-	// Persistent waves: 4 waves per block, at most 8 blocks per CU; at least one group of 64 records per wave.
-	uint64_t const groups = (n + 63) / 64;
-	uint64_t const blocks = (groups + 3) / 4;
-	return (uint32_t) (blocks < 1 ? 1 : (blocks > 256 * 8 ? 256 * 8 : blocks));
-}
-
 }	// anonymous namespace
 
-uint32_t project_wave_count(uint64_t n) { return 4 * grid_blocks(n); }
-
-int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream)
+int launch_project_probes(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream)
 {
 	if (0 == in.n) return 0;
-	hipLaunchKernelGGL(k_project_fast, dim3(grid_blocks(in.n)), dim3(256), 0, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
+	// The grid is that of k_project_fast: the work lists are per wave.
+	hipLaunchKernelGGL(k_project_fast_probes, dim3(project_wave_count(in.n) / 4), dim3(256), 0, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
 	return (int) hipGetLastError();
 }
 

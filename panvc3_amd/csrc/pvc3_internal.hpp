@@ -68,8 +68,26 @@ struct dev_entry
 	// TEXT_WINDOW_STEP * k on (the lines overlap).  Any run of up to TEXT_WINDOW_MAX nibbles lies inside ONE line, so the
 	// compare of a read of up to 150 bases fetches one 128-byte line of text instead of 1.6 on average.
 	uint8_t const *text4w;
+	// Position windows (null without one): what a projection from this entry to entry `pwin_partner` needs of a record that
+	// starts at source position p, in ONE line addressed by p alone — no select sample, no rank block, no separate text line.
+	// Window k covers the source positions from P = k << pwin_shift on and is 2 << pwin_shift bytes long (128 or 256):
+	//   u32 c0      column of source position P (select0(P + 1))
+	//   u32 r0      rank0 of the partner at c0 (the projected position of P)
+	//   u32 clean   number of consecutive columns from c0 on that are non-gap in BOTH rows (capped at PWIN_CLEAN_CAP)
+	//   u32 0
+	//   bytes 16..  the partner's packed text (4-bit codes, low nibble first) from base r0 - PWIN_TEXT_BACK on
+	// For p = P + o with o < clean the column is c0 + o and the projected position r0 + o; an alignment of R
+	// reference-consuming bases has no gap column in either row iff o + R <= clean, and its text is then nibbles
+	// o + PWIN_TEXT_BACK .. of the same line.  HBM is sized for this: two bytes per source position of every row.
+	uint8_t const *pwin;
+	uint32_t pwin_partner;
+	uint32_t pwin_shift;
 };
-static_assert(72 == sizeof(dev_entry), "dev_entry layout");
+static_assert(88 == sizeof(dev_entry), "dev_entry layout");
+constexpr uint32_t PWIN_HEADER = 16;			// bytes
+constexpr uint32_t PWIN_TEXT_BACK = 2;			// nibbles of text before base r0 in a window (the compare may start one nibble early)
+constexpr uint32_t PWIN_CLEAN_CAP = 1024;		// columns
+constexpr uint32_t PWIN_NO_ANCHOR = 0xFFFFFFFFu;	// `skip` of a record whose start column has to be looked up from the select samples
 // The compare reads the run in 16-byte pieces from the byte of its first nibble: piece floor(U / 32) is the last one, so a
 // run of U <= 159 nibbles that starts in the first 96 nibbles of a line ends at byte 47 + 80 = 127 of it.
 constexpr uint32_t TEXT_WINDOW_STEP = 96;		// nibbles
@@ -168,7 +186,7 @@ struct dev_counters
 struct slow_item
 {
 	uint32_t rec, col0, r0, src_e;
-	uint32_t dst_e, n_cigar, l_seq, pad;
+	uint32_t dst_e, n_cigar, l_seq, skip;		// skip: see resolve_start (wave.hpp); 0 = (col0, r0) are the record's own
 	uint64_t cig_begin, seq_begin;
 };
 static_assert(48 == sizeof(slow_item), "slow_item layout");
@@ -254,6 +272,8 @@ int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &
 int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);
 int launch_pack_text4(uint8_t const *text, uint64_t len, uint8_t *out, void *stream);
 int launch_window_text4(uint8_t const *text4, uint64_t n_lines, uint8_t *out, void *stream);	// out[128 k + j] = text4[TEXT_WINDOW_STEP / 2 * k + j]
+int launch_build_pwin(dev_entry const &src, dev_entry const &dst, uint32_t shift, uint64_t n_windows, uint8_t *out, void *stream);	// dev_entry::pwin of `src` towards `dst`
+int launch_project_probes(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream);	// k_project_fast's predecessor, for an index without position windows
 int launch_project_positions(dev_entry const *entries, uint32_t n_entries, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out, void *stream);
 // Layout check of a freshly loaded batch; *first_bad = smallest malformed record (left at 0xFFFFFFFF if there is none).
 int launch_validate(dev_batch_in const &in, uint64_t n_cigar, uint64_t n_seq, uint64_t n_qual, uint64_t const *qual_off, uint32_t *first_bad, void *stream);

@@ -322,6 +322,69 @@ __device__ __forceinline__ row_pair rows_of(dev_entry const &S, dev_entry const 
 	return row_pair{row_view{paired ? S.paired : S.blocks, stride, step}, row_view{paired ? S.paired + BLOCK_WORDS : D.blocks, stride, step}};
 }
 
+// Start column of source position pos and the destination's rank there, from the select samples (the look-up of
+// thread_project_position, both results).  pos < S.n_zeros.
+__device__ __forceinline__ void thread_locate(dev_entry const &S, dev_entry const &D, uint32_t dst_id, uint32_t pos, uint32_t &col, uint32_t &r)
+{
+	row_pair const R = rows_of(S, D, dst_id);
+	col_pos const g = locate(R.src.step, select_guess(S.sel, pos, 0).col);
+	dir_probe const ps = dir_load(R.src, g.blk, pair_of(g));
+	dir_probe const pd = dir_load(R.dst, g.blk, pair_of(g));
+	col = dir_select0(R.src, pos, ps);
+	r = dir_rank(R.dst, pd, locate_in(R.dst.step, col, g.blk));
+}
+
+// From an anchor — a column `col` and the destination's rank `r` there — to the source's non-gap column number `skip`
+// counted from col on (0: the first one at or after col): its column and the destination's rank there.  One pair of gap
+// words per 64 columns; false when the target lies more than ADVANCE_WORDS words ahead (a long gap run: the caller looks
+// it up from the select samples instead).  This is how a position window serves a record whose window is not clean up to
+// its start (k_project_fast): the walk kernels finish the look-up from the window's last clean column.
+constexpr uint32_t ADVANCE_WORDS = 6;
+__device__ __forceinline__ bool advance_anchor(row_pair const &R, uint32_t &col, uint32_t &r, uint32_t skip)
+{
+	for (uint32_t it = 0; it < ADVANCE_WORDS; ++it)
+	{
+		col_pos const p = locate(R.src.step, col);
+		uint64_t const wi = (uint64_t) p.blk * R.src.stride + 1 + p.w;
+		uint64_t const sw = R.src.blocks[wi], dw = R.dst.blocks[wi];
+		uint64_t const ge = ~UINT64_C(0) << p.bit;
+		uint64_t const z = ~sw & ge;
+		uint32_t const nz = popc64(z);
+		if (skip < nz)
+		{
+			uint32_t const e = thread_select_in_word(z, skip);
+			r += popc64(~dw & ge & low_mask(e));
+			col = col - p.bit + e;
+			return true;
+		}
+		skip -= nz;
+		r += popc64(~dw & ge);
+		col = col - p.bit + 64;
+	}
+	return false;
+}
+
+// What k_project_fast leaves of a record it does not finish: (col, r, skip).  skip == 0: col is the record's start column
+// and r its projected position.  skip == PWIN_NO_ANCHOR: nothing is known (no position window for this pair of entries).
+// Otherwise (col, r) is an anchor — the first column after the clean stretch of the record's window — and the start
+// column is the source's non-gap column number skip - 1 from there on.  Returns true when (col, r) changed.
+__device__ __forceinline__ bool resolve_start(dev_entry const &S, dev_entry const &D, uint32_t dst_id, uint32_t src_pos, uint32_t &col, uint32_t &r, uint32_t skip)
+{
+	if (0 == skip)
+		return false;
+	if (PWIN_NO_ANCHOR != skip)
+	{
+		uint32_t c = col, rr = r;
+		if (advance_anchor(rows_of(S, D, dst_id), c, rr, skip - 1))
+		{
+			col = c; r = rr;
+			return true;
+		}
+	}
+	thread_locate(S, D, dst_id, src_pos, col, r);
+	return true;
+}
+
 __device__ __forceinline__ uint32_t thread_project_position(dev_entry const &S, dev_entry const &D, uint32_t dst_id, uint32_t pos)
 {
 	if (pos >= S.n_zeros || S.n_cols != D.n_cols)

@@ -24,8 +24,13 @@ def oracle_mod():
 # Which projection kernels the GPU tests send the records through.  "default" is the product configuration (lane-parallel
 # fast path, then the lane-per-record walk, then the cooperative column walk for what is left); the other two force every
 # record through one of the slower kernels so that each of them is compared with the oracle on every test input
-# ("walk_only" also sends every indel run through the striped alignment kernel instead of the packed ones).
-PATH_MODES = {"default": {}, "mid_only": {"fast_path": 0}, "walk_only": {"fast_path": 0, "mid_path": 0, "packed_dp": 0}}
+# ("walk_only" also sends every indel run through the striped alignment kernel instead of the packed ones).  "probes" is the
+# product configuration of an index without position windows (one that does not fit the device): k_project_fast_probes
+# looks the records up through the select samples and the paired blocks.
+PATH_MODES = {
+	"default": {}, "probes": {"position_windows": 0}, "mid_only": {"fast_path": 0},
+	"walk_only": {"fast_path": 0, "mid_path": 0, "packed_dp": 0},
+}
 
 
 @pytest.fixture(scope="module", params=list(PATH_MODES))

@@ -380,7 +380,7 @@ def test_select_guess_on_uneven_gap_density(pvc3, oracle_mod):
 	rows = [row(k) for k in kinds]
 	texts = ["".join("-" if x else "ACGT"[i & 3] for i, x in enumerate(r)) for r in rows]
 	o = oracle_mod.Oracle()
-	for opts in ({}, {"paired_blocks": 0, "text_window": 0}):
+	for opts in ({}, {"position_windows": 0}, {"paired_blocks": 0}, {"window_read_length": 250}, {"paired_blocks": 0, "text_window": 0, "position_windows": 0}):
 		index = pvc3.Index()
 		for t in texts:
 			e = index.add_aligned(t)
@@ -423,7 +423,7 @@ def test_select_guess_on_uneven_gap_density(pvc3, oracle_mod):
 				bb.add(p0, s, d, cig, "".join(query))
 	batch = bb.build()
 	want = o.batch_project(batch, 0, -1, 0, n_threads=8)
-	for opts in ({}, {"paired_blocks": 0, "text_window": 0}):
+	for opts in ({}, {"position_windows": 0}, {"paired_blocks": 0}, {"window_read_length": 250}, {"paired_blocks": 0, "text_window": 0, "position_windows": 0}):
 		index = pvc3.Index()
 		for t in texts:
 			e = index.add_aligned(t)
@@ -437,8 +437,8 @@ def test_select_guess_on_uneven_gap_density(pvc3, oracle_mod):
 
 
 def test_plain_index_layout_matches_oracle(pvc3, oracle_mod, synth):
-	"""The same workloads without the paired blocks and the windowed text (options at upload): the plain 64-byte blocks and
-	the plain packed text are then what k_project_fast and k_project_mid read."""
+	"""The same workloads without the position windows, the paired blocks and the windowed text (options at upload): the plain
+	64-byte blocks and the plain packed text are then what k_project_fast_probes and k_project_mid read."""
 	for name, scale in (("C3", 0.004), ("C3G", 0.002)):
 		gp, rp, _ = synth.config(name, scale=scale)
 		genome = synth.Genome(gp)
@@ -446,6 +446,7 @@ def test_plain_index_layout_matches_oracle(pvc3, oracle_mod, synth):
 		ctx = pvc3.Context(0)
 		ctx.set_option("paired_blocks", 0)
 		ctx.set_option("text_window", 0)
+		ctx.set_option("position_windows", 0)
 		got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, reads.batch(), ctx=ctx)
 		assert stats["n_failed"] == 0
 		index_bytes, _ = ctx.hbm_bytes()

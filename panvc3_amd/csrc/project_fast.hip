@@ -45,6 +45,17 @@ constexpr uint32_t FAST_PASSES = PVC3_FAST_PASSES;	// passes of the cooperative 
 
 typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 
+// 16 bytes from a dword-aligned address in global memory.  Pointers that went through LDS or an integer have lost their
+// address space; a flat load would also count against the LDS counter (lgkmcnt) and wait with the LDS traffic around it.
+__device__ __forceinline__ u32x4 global_load16(void const *p)
+{
+	typedef uint32_t __attribute__((address_space(1))) const *gptr;
+	gptr const g = (gptr) (uintptr_t) p;
+	u32x4 v;
+	v.x = g[0]; v.y = g[1]; v.z = g[2]; v.w = g[3];
+	return v;
+}
+
 // What this kernel needs of an entry, 32 bytes: the head of the table lives in LDS in this form.
 struct fast_entry
 {
@@ -130,9 +141,13 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	// Per-wave staging for the cooperative compare: record descriptors out, mismatch words back.
 	__shared__ u64x2 lds_desc[4][64];
 	__shared__ uint32_t lds_mask[4][STAGE_TOKENS];
+	// What only the few records that go on to k_project_mid need again (their work-list items): parked in LDS instead of
+	// eight registers that would be live across the compare.
+	__shared__ u32x4 lds_park[4][2][64];
 	uint32_t const wave_in_block = rfl(threadIdx.x >> 6);
 	u64x2 *my_desc = lds_desc[wave_in_block];
 	uint32_t *my_mask = lds_mask[wave_in_block];
+	u32x4 (*my_park)[64] = lds_park[wave_in_block];
 	auto get_entry = [&](uint32_t id) -> fast_entry { return (id < LDS_ENTRIES) ? lds_entries[id] : make_fast_entry(entries, id); };
 	// A batch whose offsets are malformed (k_validate_batch; a pipelined batch is checked while its kernels are already
 	// queued) is not read at all: every record is rejected and the host reports PVC3_E_INVALID.
@@ -207,6 +222,16 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		else if (S.n_cols != d_cols || (uint64_t) src_pos + (ref_consumed ? ref_consumed : 1u) > S.n_zeros) status = PVC3_ST_SRC_RANGE;
 		else if (query_consumed > l_seq) status = PVC3_ST_QUERY_RANGE;
 		bool const ok = valid && (PVC3_ST_OK == status);
+		my_park[0][lane] = u32x4{src_e, dst_e, n_cigar, l_seq};
+		my_park[1][lane] = u32x4{(uint32_t) cig_begin, (uint32_t) (cig_begin >> 32), (uint32_t) seq_begin, (uint32_t) (seq_begin >> 32)};
+		if (valid)
+		{
+			acc_failed += (PVC3_ST_OK != status);
+			// every record: 7 descriptor fields (28 + 4 flags), input CIGAR, select sample, destination rank word; 24 bytes of results
+			acc_bytes += 32 + 4 * n_cigar + (ok ? 12 : 0) + 24 + (has_mate ? 12 : 0);
+		}
+		// what the fast path itself must read and write for a record it finishes: SEQ, gap-bit windows, text (+ CIGAR out)
+		uint32_t const fast_bytes = (l_seq + 1) / 2 + 2 * ((ref_consumed + 8) / 8) + (ref_consumed + 1) / 2;
 
 		// ---- the record's window: header requested now, read after the compare ---------------------------------------------------------
 		bool const has_win = ok && S.pwin && S.partner == dst_e;
@@ -214,7 +239,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		uint32_t const o = src_pos & ((1u << sh) - 1);		// the record starts o source positions into its window
 		uint8_t const *line = S.pwin + ((uint64_t) (src_pos >> sh) << (sh + 1));
 		u32x4 hdr{0, 0, 0, 0};
-		if (has_win) hdr = *(u32x4 const *) line;
+		if (has_win) hdr = global_load16(line);
 
 		// The mate's window as well, unless the neighbouring lane is about to look the same position up (pairs stored back
 		// to back): project_position is a pure function of (entries, position).
@@ -226,55 +251,61 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			nb_cand = has_mate && (mate_se == n_se) && (mate_de == n_de) && (mate_pos == n_pos);
 		}
 		bool m_win = false, m_valid = false;
-		uint32_t m_sh = 0;
-		uint8_t const *m_line = nullptr;
+		uint32_t mo = 0;
 		u32x4 mh{0, 0, 0, 0};
 		if (m_in)
 		{
 			fast_entry const M = get_entry(mate_se);
 			m_valid = (mate_pos < M.n_zeros) && (M.n_cols == get_entry(mate_de).n_cols);		// msa_index.hh:253-258 needs the position to exist
 			m_win = m_valid && M.pwin && M.partner == mate_de;
-			m_sh = M.shift;
-			m_line = M.pwin + ((uint64_t) (mate_pos >> m_sh) << (m_sh + 1));
-			if (m_win && !nb_cand) mh = *(u32x4 const *) m_line;
+			mo = mate_pos & ((1u << M.shift) - 1);
+			if (m_win && !nb_cand) mh = global_load16(M.pwin + ((uint64_t) (mate_pos >> M.shift) << (M.shift + 1)));
 		}
+		bool const count_mate = m_in && !nb_cand;
 
 		// ---- fast path: the compare, on every record that can still turn out to be one --------------------------------------------------
 		uint32_t const lead_q = (OP_S == (lead & 0xf)) ? (lead >> 4) : 0;	// query bases before the M-type span
 		uint32_t const phase = lead_q & 1;
 		// Work in query-nibble positions u = t + phase counted from a byte boundary of SEQ, so that 32 positions are exactly
-		// 16 bytes of SEQ and 32 bytes of text; the mask is shifted back by `phase` afterwards.
-		uint32_t const nib = o + PWIN_TEXT_BACK - phase;		// nibble of the window's text that lines up with query position u = 0
+		// 16 bytes of SEQ and 32 nibbles of text; the mask is shifted back by `phase` afterwards.
+		// Both sides are loaded in 16-byte pieces from DWORD-aligned addresses and shifted into place in registers (SEQ by
+		// whole bytes, the text by nibbles; the dword a shift pulls in comes from the lane of the next piece): a 16-byte load
+		// from an address that is not a multiple of four costs the texture addresser three times as much
+		// (tools/calib/ta_cost.hip: 65 against 22 cycles for this lane pattern), and these loads were 60 % of its time.
+		uint8_t const *qb = in.seq4 + seq_begin + (lead_q >> 1);		// SEQ byte of query position u = 0
+		uint32_t const nib = o + PWIN_TEXT_BACK - phase;			// nibble of the window's text that lines up with u = 0
+		uint32_t const sb = (uint32_t) (uintptr_t) qb & 3, st = nib & 7;	// SEQ shift in bytes, text shift in nibbles
+		uint32_t pieces;											// 16-byte pieces of either side the compare has to load
 		bool cand;
 		{
 			bool const simple = (2 == shape || 3 == shape);
 			uint32_t const U = ref_consumed + phase;
-			// The compare reads the text in 16-byte pieces from the byte of its first nibble: pieces 0 .. U / 32.
-			bool const fits = PWIN_HEADER + (nib >> 1) + 16 * (U / 32 + 1) <= (2u << sh);
+			uint32_t const pq = (2 * sb + U + 31) / 32, pt = (st + U + 31) / 32;
+			pieces = (pq > pt) ? pq : pt;
+			bool const fits = (pieces <= FAST_WORDS) && (PWIN_HEADER + 4 * (nib >> 3) + 16 * pieces <= (2u << sh));
 			cand = use_fast_path && has_win && simple && (U < FAST_MAX_BASES) && fits;
 		}
 		bool fast = false;
 		uint32_t col = 0, r0 = 0, skip = PWIN_NO_ANCHOR;
 		uint32_t f_n_out = 0;
 		uint64_t f_loc = 0;
+		uint32_t n_words = 0;		// wave-uniform: lanes per record in the compare, mask words per record afterwards
 #ifdef PVC3_ABL_NO_COMPARE
 		if (false)
 #else
 		if (ballot(cand))
 #endif
 		{
-			uint32_t const Rc = cand ? ref_consumed : 0;
-			uint32_t const U = cand ? (Rc + phase) : 0;
-			uint8_t const *qp = in.seq4 + seq_begin + (lead_q >> 1);
-			// One more position than needed, so that the lane after a record's last full word exists (see below).
-			uint32_t const n_words = (wave_max(U) + 32) / 32;		// 1 .. FAST_WORDS
+			uint32_t const U = cand ? (ref_consumed + phase) : 0;
+			n_words = wave_max(cand ? pieces : 0);		// 1 .. FAST_WORDS
 			// The compare is done by n_words lanes per record, one 32-position word each: a wave instruction then touches the
 			// lines of 64 / n_words records instead of one line per lane, which the memory pipeline serves 2-3x faster
 			// (tools/calib/random_access.hip).  Descriptors go to the lanes through LDS, the masks come back the same way.
 			{
 				u64x2 d;
-				d.x = (uint64_t) qp | ((uint64_t) U << 48);
-				d.y = (uint64_t) (line + PWIN_HEADER + (nib >> 1)) | ((uint64_t) (nib & 1) << 63);
+				d.x = ((uint64_t) (qb - sb) & UINT64_C(0xFFFFFFFFFFFF)) | ((uint64_t) U << 48);
+				// (pieces = 0 for a record that is no candidate: nothing is loaded for it, its addresses may be anything)
+				d.y = ((uint64_t) (line + PWIN_HEADER + 4 * (nib >> 3)) & UINT64_C(0xFFFFFFFFFFFF)) | ((uint64_t) (sb | (st << 2) | ((cand ? pieces : 0) << 5)) << 48);
 				my_desc[lane] = d;
 			}
 			wave_lds_sync();
@@ -283,52 +314,53 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				uint32_t const per = (64 * inv) >> 16;			// records per pass
 				uint32_t const sr = (lane * inv) >> 16;				// lane / n_words
 				uint32_t const w = lane - sr * n_words;
-				auto fetch = [&](uint32_t rr, bool act, u64x2 &qq, u32x4 &tt, uint32_t &left, uint32_t &odd4) {
+				auto fetch = [&](uint32_t rr, bool act, u32x4 &qq, u32x4 &tt, uint32_t &left, uint32_t &shifts) {
 					u64x2 const dd = my_desc[act ? rr : lane];
-					uint32_t const Ur = (uint32_t) (dd.x >> 48);
+					uint32_t const Ur = (uint32_t) (dd.x >> 48), meta = (uint32_t) (dd.y >> 48);
 					left = (act && Ur > 32 * w) ? (Ur - 32 * w) : 0;
-					odd4 = (uint32_t) (dd.y >> 63) * 4;
-					// When the text starts at an odd nibble a word needs the first nibble of the next 16 bytes: the lane at
-					// position 32 w == Ur loads them although it has nothing to compare.
-					if (act && Ur && 32 * w <= Ur)		// SEQ loads stay inside the record (+ at most 31 positions of padding)
+					shifts = meta & 31;
+					if (act && w < (meta >> 5))		// both loads stay inside the record's SEQ (+ padding) and the window's line
 					{
-						uint8_t const *q = (uint8_t const *) (dd.x & UINT64_C(0xFFFFFFFFFFFF)) + 16 * w;
-						uint8_t const *t = (uint8_t const *) (dd.y & UINT64_C(0xFFFFFFFFFFFF)) + 16 * w;
-						if (left) qq = load_u128_unaligned(q);
-						__builtin_memcpy(&tt, t, 16);
+						qq = global_load16((uint32_t const *) (dd.x & UINT64_C(0xFFFFFFFFFFFF)) + 4 * w);
+						tt = global_load16((uint32_t const *) (dd.y & UINT64_C(0xFFFFFFFFFFFF)) + 4 * w);
 					}
 				};
-				auto finish = [&](uint32_t rr, bool act, u64x2 const &qq, u32x4 const &tt, uint32_t left, uint32_t odd4) {
-					// Shift the 128-bit text window right by one nibble if needed; the top nibble comes from the next lane.
-					uint32_t const next = (uint32_t) __shfl_down((int) tt.x, 1);
+				auto finish = [&](uint32_t rr, bool act, u32x4 const &qq, u32x4 const &tt, uint32_t left, uint32_t shifts) {
+					// The dword after a lane's 16 bytes is the first dword of the next lane's piece (a record's last piece
+					// never needs one: `pieces` counts what the shifts pull in).
+					uint32_t const nq = (uint32_t) __shfl_down((int) qq.x, 1), nt = (uint32_t) __shfl_down((int) tt.x, 1);
 					uint32_t m = 0;
 					if (left)
 					{
-						uint32_t const t0 = __builtin_amdgcn_alignbit(tt.y, tt.x, odd4), t1 = __builtin_amdgcn_alignbit(tt.z, tt.y, odd4);
-						uint32_t const t2 = __builtin_amdgcn_alignbit(tt.w, tt.z, odd4), t3 = __builtin_amdgcn_alignbit(next, tt.w, odd4);
-						m = mismatch32(qq, t0, t1, t2, t3) & (uint32_t) low_mask(left < 32 ? left : 32);
+						uint32_t const bq = 8 * (shifts & 3), bt = 4 * (shifts >> 2);
+						uint32_t const q0 = __builtin_amdgcn_alignbit(qq.y, qq.x, bq), q1 = __builtin_amdgcn_alignbit(qq.z, qq.y, bq);
+						uint32_t const q2 = __builtin_amdgcn_alignbit(qq.w, qq.z, bq), q3 = __builtin_amdgcn_alignbit(nq, qq.w, bq);
+						uint32_t const t0 = __builtin_amdgcn_alignbit(tt.y, tt.x, bt), t1 = __builtin_amdgcn_alignbit(tt.z, tt.y, bt);
+						uint32_t const t2 = __builtin_amdgcn_alignbit(tt.w, tt.z, bt), t3 = __builtin_amdgcn_alignbit(nt, tt.w, bt);
+						u64x2 q64;
+						q64.x = (uint64_t) q0 | ((uint64_t) q1 << 32); q64.y = (uint64_t) q2 | ((uint64_t) q3 << 32);
+						m = mismatch32(q64, t0, t1, t2, t3) & (uint32_t) low_mask(left < 32 ? left : 32);
 					}
-					if (act) my_mask[rr * FAST_WORDS + w] = m;
+					if (act && w < FAST_WORDS) my_mask[rr * FAST_WORDS + w] = m;
 				};
 				// FAST_PASSES passes at a time: all their loads are in flight before the first word is compared (a pass per round
 				// trip made the compare three dependent round trips for 150-base reads, a quarter of the kernel's time).
 				for (uint32_t base = 0; base < 64; base += FAST_PASSES * per)
 				{
-					u64x2 qv[FAST_PASSES];
-					u32x4 tv[FAST_PASSES];
-					uint32_t left_v[FAST_PASSES], odd_v[FAST_PASSES];
+					u32x4 qv[FAST_PASSES], tv[FAST_PASSES];
+					uint32_t left_v[FAST_PASSES], shift_v[FAST_PASSES];
 #pragma unroll
 					for (uint32_t k = 0; k < FAST_PASSES; ++k)
 					{
 						uint32_t const rr = base + k * per + sr;
-						qv[k] = u64x2{0, 0}; tv[k] = u32x4{0, 0, 0, 0};
-						fetch(rr, (sr < per) & (rr < 64), qv[k], tv[k], left_v[k], odd_v[k]);
+						qv[k] = u32x4{0, 0, 0, 0}; tv[k] = u32x4{0, 0, 0, 0};
+						fetch(rr, (sr < per) & (rr < 64), qv[k], tv[k], left_v[k], shift_v[k]);
 					}
 #pragma unroll
 					for (uint32_t k = 0; k < FAST_PASSES; ++k)
 					{
 						uint32_t const rr = base + k * per + sr;
-						finish(rr, (sr < per) & (rr < 64), qv[k], tv[k], left_v[k], odd_v[k]);
+						finish(rr, (sr < per) & (rr < 64), qv[k], tv[k], left_v[k], shift_v[k]);
 					}
 				}
 			}
@@ -360,25 +392,31 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			bool const n_exact = 0 != __shfl_xor((int) exact, 1);
 			if (nb_cand && n_exact)
 				mate = n_r0;
+			else if (m_win && !nb_cand && mo < mh.z)
+				mate = mh.y + mo;
 			else if (m_valid)
 			{
+				// The rare cases: the mate's window is not clean up to the mate, the neighbour's own look-up is left to
+				// k_project_mid, or the pair of entries has no windows.  (The mate's descriptor is read again here rather than
+				// kept in registers across the compare.)
+				uint32_t const se = in.mate_src_entry[rl], de = in.mate_dst_entry[rl], pos = in.mate_pos[rl];
 				if (m_win)
 				{
-					if (nb_cand) mh = *(u32x4 const *) m_line;		// the neighbour's own look-up is left to k_project_mid
-					uint32_t const mo = mate_pos & ((1u << m_sh) - 1);
+					dev_entry const &MS = entries[se];
+					if (nb_cand) mh = global_load16(MS.pwin + ((uint64_t) (pos >> MS.pwin_shift) << (MS.pwin_shift + 1)));
 					if (mo < mh.z)
 						mate = mh.y + mo;
 					else
 					{
 						uint32_t c = mh.x + mh.z, r = mh.y + mh.z;
-						resolve_start(entries[mate_se], entries[mate_de], mate_de, mate_pos, c, r, mo - mh.z + 1);
+						resolve_start(MS, entries[de], de, pos, c, r, mo - mh.z + 1);
 						mate = r;
 					}
 				}
 				else
-					mate = thread_project_position(entries[mate_se], entries[mate_de], mate_de, mate_pos);
+					mate = thread_project_position(entries[se], entries[de], de, pos);
 			}
-			if (m_in && !nb_cand)
+			if (count_mate)
 				acc_bytes += 4 + 64 + 64;		// select sample, one source block, one destination block
 		}
 		FAST_STAMP(4);		// mate
@@ -390,7 +428,6 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		if (ballot(fast))
 		{
 			uint32_t const R = fast ? ref_consumed : 0;
-			uint32_t const n_words = (wave_max(cand ? (ref_consumed + phase) : 0) + 32) / 32;		// as in the compare
 			uint32_t mu[FAST_WORDS + 1];
 			{
 				u32x4 const *mp = (u32x4 const *) (my_mask + lane * FAST_WORDS);
@@ -479,8 +516,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				acc_bitvec += 2 * ((R + 8) / 8);
 				acc_ref += (R + 1) / 2;
 				acc_fast += 1;
-				// what the fast path itself must read and write for this record: SEQ, gap-bit windows, text, CIGAR out
-				acc_bytes += (l_seq + 1) / 2 + 2 * ((R + 8) / 8) + (R + 1) / 2 + 4 * f_n_out;
+				acc_bytes += fast_bytes + 4 * f_n_out;
 			}
 		}
 
@@ -496,10 +532,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			if (items_mode && ((m >> lane) & 1))
 			{
 				uint32_t const at = n_slow + mbcnt64(m);
+				u32x4 const a = my_park[0][lane], b = my_park[1][lane];
 				slow_item it;
-				it.rec = (uint32_t) rec; it.col0 = col; it.r0 = r0; it.src_e = src_e;
-				it.dst_e = dst_e; it.n_cigar = n_cigar; it.l_seq = l_seq; it.skip = skip;
-				it.cig_begin = cig_begin; it.seq_begin = seq_begin;
+				it.rec = (uint32_t) rec; it.col0 = col; it.r0 = r0; it.src_e = a.x;
+				it.dst_e = a.y; it.n_cigar = a.z; it.l_seq = a.w; it.skip = skip;
+				it.cig_begin = (uint64_t) b.x | ((uint64_t) b.y << 32); it.seq_begin = (uint64_t) b.z | ((uint64_t) b.w << 32);
 				slow_items[at] = it;
 			}
 			n_slow += popc64(m);
@@ -515,9 +552,6 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			W.cig_n[rec] = slow ? skip : f_n_out;	// (slow: see resolve_start; the walk kernels store the number of operations)
 			W.cig_loc[rec] = slow ? ((uint64_t) col | ((uint64_t) ref_consumed << 32)) : f_loc;
 			W.run_n[rec] = 0;
-			acc_failed += (PVC3_ST_OK != status);
-			// every record: 7 descriptor fields (28 + 4 flags), input CIGAR, select sample, destination rank word; 24 bytes of results
-			acc_bytes += 32 + 4 * n_cigar + (ok ? 12 : 0) + 24 + (has_mate ? 12 : 0);
 		}
 		FAST_STAMP(8);		// work list, outputs
 	}

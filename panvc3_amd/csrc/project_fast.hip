@@ -22,6 +22,8 @@
 //      positions still to go (resolve_start, wave.hpp).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pvc3_internal.hpp"
 #include "wave.hpp"
 #include "device_common.hpp"
@@ -33,10 +35,10 @@ namespace {
 
 constexpr uint32_t FAST_MAX_BASES = 256;
 constexpr uint32_t FAST_WORDS = FAST_MAX_BASES / 32;
-constexpr uint32_t LDS_ENTRIES = 128;
+constexpr uint32_t LDS_ENTRIES = 256;
 constexpr uint32_t STAGE_TOKENS = 64 * FAST_WORDS;		// uint32 in a wave's LDS area (mismatch words, then output operations)
 #ifndef PVC3_FAST_PASSES
-#define PVC3_FAST_PASSES 4
+#define PVC3_FAST_PASSES 3
 #endif
 constexpr uint32_t FAST_PASSES = PVC3_FAST_PASSES;	// passes of the cooperative compare whose loads are issued together
 #ifndef PVC3_FAST_MIN_WAVES
@@ -148,7 +150,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	u64x2 *my_desc = lds_desc[wave_in_block];
 	uint32_t *my_mask = lds_mask[wave_in_block];
 	u32x4 (*my_park)[64] = lds_park[wave_in_block];
-	auto get_entry = [&](uint32_t id) -> fast_entry { return (id < LDS_ENTRIES) ? lds_entries[id] : make_fast_entry(entries, id); };
+	// Entries beyond the table ("far") are handled in branches of their own that leave their results in LDS: a value that
+	// is loaded from global memory on a rare path and merged with the common path's LDS read in one register makes the
+	// compiler wait for ALL outstanding vector memory operations (s_waitcnt vmcnt(0)) before that LDS read on the common
+	// path too — which serialised the loads requested ahead with the group's own.
+	auto near_entry = [&](uint32_t id) -> fast_entry { return lds_entries[(id < LDS_ENTRIES) ? id : (LDS_ENTRIES - 1)]; };
 	// A batch whose offsets are malformed (k_validate_batch; a pipelined batch is checked while its kernels are already
 	// queued) is not read at all: every record is rejected and the host reports PVC3_E_INVALID.
 	bool const batch_bad = 0xFFFFFFFFu != rfl(*W.first_bad);
@@ -159,38 +165,123 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	uint64_t stamp_prev = __builtin_amdgcn_s_memtime();
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
+	// ---- the descriptors of a group, requested one group ahead ---------------------------------------------------------------------
+	// Nothing a group loads may wait for another load of the same group if it can be helped: at four waves per SIMD every
+	// dependent memory round trip of a group is time nobody fills (occupancy experiment).  The descriptors of
+	// group g + 1 and the 256 CIGAR operations that follow the last operation of group g — where group g + 1's begin, which
+	// is known without its descriptors — are requested at the top of group g; group g + 1 then starts with everything in
+	// registers and what it loads itself (window header, SEQ, window text) is one round trip.
+	struct group_desc
+	{
+		uint32_t src_pos, src_e, dst_e, fl, l_seq, mate_se, mate_de, mate_pos;
+		uint64_t cig_begin, cig_end, seq_begin;
+	};
+	bool const mates = nullptr != in.mate_pos;		// wave-uniform
+	auto load_desc = [&](uint64_t g) -> group_desc {
+		uint64_t const rec = g * 64 + lane;
+		uint64_t const rl = (rec < in.n) ? rec : (in.n - 1);		// clamped index: every lane issues the same loads
+		group_desc d;
+		d.src_pos = in.src_pos[rl]; d.src_e = in.src_entry[rl]; d.dst_e = in.dst_entry[rl]; d.fl = in.flags[rl];
+		d.cig_begin = in.cigar_off[rl]; d.cig_end = in.cigar_off[rl + 1];
+		d.seq_begin = in.seq_off[rl]; d.l_seq = in.l_seq[rl];
+		// (The mate fields are loaded whether or not the flags announce a mate: a load that waits for the flags is a memory
+		// round trip of its own.)
+		d.mate_se = mates ? in.mate_src_entry[rl] : 0; d.mate_de = mates ? in.mate_dst_entry[rl] : 0; d.mate_pos = mates ? in.mate_pos[rl] : 0;
+		return d;
+	};
+	// The CIGAR operations [base + 4 lane, base + 4 lane + 4): 1 KB per wave, coalesced.  The buffer is padded by 64 operations.
+	uint64_t const cigar_total = batch_bad ? 0 : rfl64(in.cigar_off[in.n]);
+	auto load_chunk = [&](uint64_t base) -> u32x4 {
+		u32x4 v{0, 0, 0, 0};
+		if (base + 4 * lane + 4 <= cigar_total + 64)
+			__builtin_memcpy(&v, in.cigar + base + 4 * lane, 16);
+		return v;
+	};
+	group_desc next_desc = load_desc(g_begin);
+	uint64_t next_chunk_base = (g_begin < g_end && !batch_bad) ? rfl64(in.cigar_off[64 * g_begin]) : 0;
+	u32x4 next_chunk = load_chunk(next_chunk_base);
+
 	for (uint64_t g = g_begin; g < g_end; ++g)
 	{
 		uint64_t const rec = g * 64 + lane;
 		bool const valid = rec < in.n;
-		uint64_t const rl = valid ? rec : (in.n - 1);		// clamped index: every lane issues the same loads
+		uint64_t const rl = valid ? rec : (in.n - 1);
 
-		// ---- descriptors (coalesced) -------------------------------------------------------------------------------------------
-		uint32_t const src_pos = in.src_pos[rl];
-		uint32_t const src_e = in.src_entry[rl];
-		uint32_t const dst_e = in.dst_entry[rl];
-		uint32_t const fl = in.flags[rl];
-		uint64_t const cig_begin = batch_bad ? 0 : in.cigar_off[rl];
-		uint32_t const n_cigar = batch_bad ? 0 : (uint32_t) (in.cigar_off[rl + 1] - cig_begin);
-		uint64_t const seq_begin = in.seq_off[rl];
-		uint32_t const l_seq = in.l_seq[rl];
-		bool const has_mate = valid && in.mate_pos && (fl & PVC3_FLAG_HAS_MATE);
-		uint32_t const mate_se = has_mate ? in.mate_src_entry[rl] : 0;
-		uint32_t const mate_de = has_mate ? in.mate_dst_entry[rl] : 0;
-		uint32_t const mate_pos = has_mate ? in.mate_pos[rl] : 0;
+		// ---- descriptors: those requested a group ago; the next group's are requested now -----------------------------------------
+		group_desc const D = next_desc;
+		u32x4 const chunk = next_chunk;
+		uint64_t const chunk_base = next_chunk_base;
+		uint32_t const src_pos = D.src_pos, src_e = D.src_e, dst_e = D.dst_e, fl = D.fl, l_seq = D.l_seq;
+		uint32_t const mate_se = D.mate_se, mate_de = D.mate_de, mate_pos = D.mate_pos;
+		uint64_t const cig_begin = batch_bad ? 0 : D.cig_begin;
+		uint32_t const n_cigar = batch_bad ? 0 : (uint32_t) (D.cig_end - D.cig_begin);
+		uint64_t const seq_begin = D.seq_begin;
+		bool const has_mate = valid && mates && (fl & PVC3_FLAG_HAS_MATE);
+		// The group's operations go through LDS to the lanes that own them (the area is free here: the parked fields of the
+		// previous group have been read).
+		uint32_t *stage = (uint32_t *) &my_park[0][0];
+		*(u32x4 *) (stage + 4 * lane) = chunk;
+		if (g + 1 < g_end)
+		{
+			next_desc = load_desc(g + 1);
+			// The last record's end is the next group's begin.
+			next_chunk_base = batch_bad ? 0 : (((uint64_t) readlane((uint32_t) (D.cig_end >> 32), 63) << 32) | readlane((uint32_t) D.cig_end, 63));
+			next_chunk = load_chunk(next_chunk_base);
+		}
+		wave_lds_sync();
 
 		FAST_STAMP(0);		// descriptors
 		bool const e_ok = (src_e < n_entries) && (dst_e < n_entries);
-		fast_entry const S = get_entry(e_ok ? src_e : 0);
-		uint32_t const d_cols = get_entry(e_ok ? dst_e : 0).n_cols;
+		fast_entry S = near_entry(e_ok ? src_e : 0);
+		uint32_t d_cols = near_entry(e_ok ? dst_e : 0).n_cols;
+		{
+			// A far entry: what the status needs of it, through LDS; the record is then left to k_project_mid.
+			bool const far = e_ok && (src_e >= LDS_ENTRIES || dst_e >= LDS_ENTRIES);
+			if (ballot(far))
+			{
+				uint32_t *slot = (uint32_t *) &my_desc[lane];
+				if (far)
+				{
+					slot[0] = entries[src_e].n_zeros; slot[1] = entries[src_e].n_cols; slot[2] = entries[dst_e].n_cols;
+				}
+				wave_lds_sync();
+				if (far)
+				{
+					S.n_zeros = slot[0]; S.n_cols = slot[1]; d_cols = slot[2];
+					S.pwin = nullptr;
+				}
+				wave_lds_sync();
+			}
+		}
 
 		// ---- CIGAR: validation + shape automaton of the fast path (first four operations from one 16-byte load) ----------------
 		uint32_t const *ops = in.cigar + cig_begin;
 		u32x4 pre4;
-		__builtin_memcpy(&pre4, ops, 16);					// the CIGAR buffer is padded by the host side
+		{
+			uint64_t const at = cig_begin - chunk_base;		// (wraps to a large number if the offsets are not what the chunk assumed)
+			bool const staged_ops = at + 4 <= 256;
+			uint32_t const *sp = staged_ops ? (stage + (uint32_t) at) : (uint32_t const *) &my_desc[lane];
+			if (ballot(!staged_ops))
+			{
+				// A group with more than 252 operations before this record's: fetched here, handed over through LDS like the
+				// others (see the note on far entries).
+				if (!staged_ops)
+				{
+					u32x4 v{0, 0, 0, 0};
+					if (n_cigar) __builtin_memcpy(&v, ops, 16);			// the CIGAR buffer is padded by the host side
+					*(u32x4 *) &my_desc[lane] = v;
+				}
+				wave_lds_sync();
+			}
+			pre4 = u32x4{sp[0], sp[1], sp[2], sp[3]};
+		}
+		wave_lds_sync();		// the parked fields go to the same area
 		uint32_t const pre[4] = {pre4.x, pre4.y, pre4.z, pre4.w};
 		uint32_t ref_consumed = 0, query_consumed = 0, shape = 0, lead = 0, trail = 0;
 		bool bad_op = false;
+		// (Plain selects: an `if` that assigns `lead` in one arm and `trail` in another is turned into one store through a
+		// selected address, which puts both variables into scratch memory — and every scratch access is a vector memory
+		// operation that the wave then waits for together with everything else in flight.)
 		auto step = [&](uint32_t c) {
 			uint32_t const op = c & 0xf, n = c >> 4;
 			bool const m_type = (OP_M == op || OP_EQ == op || OP_X == op);
@@ -199,14 +290,12 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			ref_consumed += (m_type || OP_D == op || OP_N == op) ? n : 0;
 			query_consumed += (m_type || OP_I == op || OP_S == op) ? n : 0;
 			// 0 start, 1 after the leading clip, 2 inside the M-type span, 3 after the trailing clip, 4 not simple
-			uint32_t next = 4;
-			if (0 != n)
-			{
-				if (m_type && shape <= 2) next = 2;
-				else if (clip && 0 == shape) { next = 1; lead = c; }
-				else if (clip && 2 == shape) { next = 3; trail = c; }
-			}
-			shape = next;
+			bool const is_m = (0 != n) && m_type && shape <= 2;
+			bool const is_lead = (0 != n) && !is_m && clip && 0 == shape;
+			bool const is_trail = (0 != n) && !is_m && clip && 2 == shape;
+			lead = is_lead ? c : lead;
+			trail = is_trail ? c : trail;
+			shape = is_m ? 2u : is_lead ? 1u : is_trail ? 3u : 4u;
 		};
 #pragma unroll
 		for (uint32_t i = 0; i < 4; ++i)
@@ -255,13 +344,15 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		u32x4 mh{0, 0, 0, 0};
 		if (m_in)
 		{
-			fast_entry const M = get_entry(mate_se);
-			m_valid = (mate_pos < M.n_zeros) && (M.n_cols == get_entry(mate_de).n_cols);		// msa_index.hh:253-258 needs the position to exist
-			m_win = m_valid && M.pwin && M.partner == mate_de;
+			fast_entry const M = near_entry(mate_se);
+			bool const m_far = mate_se >= LDS_ENTRIES || mate_de >= LDS_ENTRIES;		// left to thread_project_position below
+			m_valid = m_far || ((mate_pos < M.n_zeros) && (M.n_cols == near_entry(mate_de).n_cols));		// msa_index.hh:253-258 needs the position to exist
+			m_win = m_valid && !m_far && M.pwin && M.partner == mate_de;
 			mo = mate_pos & ((1u << M.shift) - 1);
 			if (m_win && !nb_cand) mh = global_load16(M.pwin + ((uint64_t) (mate_pos >> M.shift) << (M.shift + 1)));
 		}
 		bool const count_mate = m_in && !nb_cand;
+		FAST_STAMP(2);		// window headers (the diagnostic build waits for them here; the kernel reads them after the compare)
 
 		// ---- fast path: the compare, on every record that can still turn out to be one --------------------------------------------------
 		uint32_t const lead_q = (OP_S == (lead & 0xf)) ? (lead >> 4) : 0;	// query bases before the M-type span
@@ -339,7 +430,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 						uint32_t const t2 = __builtin_amdgcn_alignbit(tt.w, tt.z, bt), t3 = __builtin_amdgcn_alignbit(nt, tt.w, bt);
 						u64x2 q64;
 						q64.x = (uint64_t) q0 | ((uint64_t) q1 << 32); q64.y = (uint64_t) q2 | ((uint64_t) q3 << 32);
+#ifdef PVC3_ABL_NO_MISMATCH
+						m = ((uint32_t) q64.x ^ (uint32_t) q64.y ^ (uint32_t) (q64.x >> 32) ^ (uint32_t) (q64.y >> 32) ^ t0 ^ t1 ^ t2 ^ t3) & (uint32_t) low_mask(left < 32 ? left : 32) & 0x10101u;
+#else
 						m = mismatch32(q64, t0, t1, t2, t3) & (uint32_t) low_mask(left < 32 ? left : 32);
+#endif
 					}
 					if (act && w < FAST_WORDS) my_mask[rr * FAST_WORDS + w] = m;
 				};
@@ -591,7 +686,8 @@ uint32_t grid_blocks(uint64_t n)
 	// Persistent waves: 4 waves per block, at most 8 blocks per CU; at least one group of 64 records per wave.
 	uint64_t const groups = (n + 63) / 64;
 	uint64_t const blocks = (groups + 3) / 4;
-	return (uint32_t) (blocks < 1 ? 1 : (blocks > 256 * 8 ? 256 * 8 : blocks));
+	static uint32_t const max_blocks = [] { char const *e = getenv("PVC3_GRID_BLOCKS"); return e ? (uint32_t) atoi(e) : 256u * 8; }();	// (experiments)
+	return (uint32_t) (blocks < 1 ? 1 : (blocks > max_blocks ? max_blocks : blocks));
 }
 
 }	// anonymous namespace
@@ -601,7 +697,9 @@ uint32_t project_wave_count(uint64_t n) { return 4 * grid_blocks(n); }
 int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream)
 {
 	if (0 == in.n) return 0;
-	hipLaunchKernelGGL(k_project_fast, dim3(grid_blocks(in.n)), dim3(256), 0, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
+	// PVC3_FAST_DYN_LDS: bytes of unused dynamic LDS per block — an occupancy experiment (fewer blocks per CU), not an option.
+	static uint32_t const dyn_lds = [] { char const *e = getenv("PVC3_FAST_DYN_LDS"); return e ? (uint32_t) atoi(e) : 0u; }();
+	hipLaunchKernelGGL(k_project_fast, dim3(grid_blocks(in.n)), dim3(256), dyn_lds, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
 	return (int) hipGetLastError();
 }
 

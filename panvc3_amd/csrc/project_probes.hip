@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast_probe
 		uint32_t const pre[4] = {pre4.x, pre4.y, pre4.z, pre4.w};
 		uint32_t ref_consumed = 0, query_consumed = 0, shape = 0, lead = 0, trail = 0;
 		bool bad_op = false;
+		// (Plain selects: see k_project_fast — an `if` that assigns `lead` in one arm and `trail` in another puts both into scratch.)
 		auto step = [&](uint32_t c) {
 			uint32_t const op = c & 0xf, n = c >> 4;
 			bool const m_type = (OP_M == op || OP_EQ == op || OP_X == op);
@@ -163,14 +164,12 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast_probe
 			ref_consumed += (m_type || OP_D == op || OP_N == op) ? n : 0;
 			query_consumed += (m_type || OP_I == op || OP_S == op) ? n : 0;
 			// 0 start, 1 after the leading clip, 2 inside the M-type span, 3 after the trailing clip, 4 not simple
-			uint32_t next = 4;
-			if (0 != n)
-			{
-				if (m_type && shape <= 2) next = 2;
-				else if (clip && 0 == shape) { next = 1; lead = c; }
-				else if (clip && 2 == shape) { next = 3; trail = c; }
-			}
-			shape = next;
+			bool const is_m = (0 != n) && m_type && shape <= 2;
+			bool const is_lead = (0 != n) && !is_m && clip && 0 == shape;
+			bool const is_trail = (0 != n) && !is_m && clip && 2 == shape;
+			lead = is_lead ? c : lead;
+			trail = is_trail ? c : trail;
+			shape = is_m ? 2u : is_lead ? 1u : is_trail ? 3u : 4u;
 		};
 #pragma unroll
 		for (uint32_t i = 0; i < 4; ++i)

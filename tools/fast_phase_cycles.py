@@ -42,10 +42,10 @@ out = (C.c_ulonglong * (16 * n_waves))()
 L.pvc3_debug_fast_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
 assert 0 == L.pvc3_debug_fast_stamps(db._h, out, n_waves)
 v = np.array(out[:], dtype=np.float64).reshape(n_waves, 16)
-names = ["descriptors", "entries + CIGAR", "select sample", "probes, select, ranks", "mate", "compare", "run count, scan, arena", "emission", "work list, outputs"]
+names = ["descriptors (+ next group's requested)", "entries + CIGAR", "window headers", "header arithmetic", "mate", "compare", "run count, scan, arena", "emission", "work list, outputs"]
 g = v[:, 12].sum()
 print("%s%s: k_project_fast %.3f ms with stamps; %d waves, %d groups" % (desc, " (sorted)" if len(sys.argv) > 3 else "", st["ms_project"], n_waves, g))
 tot = v[:, :9].sum()
 for k, name in enumerate(names):
-	print("%-26s %9.0f cycles (100 MHz ticks x clock ratio) per group  %5.1f %%" % (name, v[:, k].sum() / g, 100 * v[:, k].sum() / tot))
-print("%-26s %9.0f" % ("sum", tot / g))
+	print("%-40s %9.0f cycles (100 MHz ticks x clock ratio) per group  %5.1f %%" % (name, v[:, k].sum() / g, 100 * v[:, k].sum() / tot))
+print("%-40s %9.0f" % ("sum", tot / g))

@@ -186,15 +186,18 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		d.seq_begin = in.seq_off[rl]; d.l_seq = in.l_seq[rl];
 		// (The mate fields are loaded whether or not the flags announce a mate: a load that waits for the flags is a memory
 		// round trip of its own.)
-		d.mate_se = mates ? in.mate_src_entry[rl] : 0; d.mate_de = mates ? in.mate_dst_entry[rl] : 0; d.mate_pos = mates ? in.mate_pos[rl] : 0;
+		// (Without mate arrays the loads go to another array and are ignored: no branch, so that the compiler can count the
+		// operations in flight instead of waiting for all of them.)
+		d.mate_se = (mates ? in.mate_src_entry : in.src_pos)[rl]; d.mate_de = (mates ? in.mate_dst_entry : in.src_pos)[rl]; d.mate_pos = (mates ? in.mate_pos : in.src_pos)[rl];
 		return d;
 	};
 	// The CIGAR operations [base + 4 lane, base + 4 lane + 4): 1 KB per wave, coalesced.  The buffer is padded by 64 operations.
 	uint64_t const cigar_total = batch_bad ? 0 : rfl64(in.cigar_off[in.n]);
 	auto load_chunk = [&](uint64_t base) -> u32x4 {
-		u32x4 v{0, 0, 0, 0};
-		if (base + 4 * lane + 4 <= cigar_total + 64)
-			__builtin_memcpy(&v, in.cigar + base + 4 * lane, 16);
+		// Lanes past the end of the (padded) buffer read its last 16 bytes: what they get is never used.
+		uint64_t const at = base + 4 * lane, last = cigar_total + 60;
+		u32x4 v;
+		__builtin_memcpy(&v, in.cigar + ((at < last) ? at : last), 16);
 		return v;
 	};
 	group_desc next_desc = load_desc(g_begin);
@@ -221,9 +224,9 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		// previous group have been read).
 		uint32_t *stage = (uint32_t *) &my_park[0][0];
 		*(u32x4 *) (stage + 4 * lane) = chunk;
-		if (g + 1 < g_end)
 		{
-			next_desc = load_desc(g + 1);
+			// (After the wave's last group this requests that group's descriptors once more: harmless, and no branch.)
+			next_desc = load_desc((g + 1 < g_end) ? (g + 1) : g);
 			// The last record's end is the next group's begin.
 			next_chunk_base = batch_bad ? 0 : (((uint64_t) readlane((uint32_t) (D.cig_end >> 32), 63) << 32) | readlane((uint32_t) D.cig_end, 63));
 			next_chunk = load_chunk(next_chunk_base);
@@ -484,9 +487,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		uint32_t mate = PVC3_NO_MATE;
 		{
 			uint32_t const n_r0 = (uint32_t) __shfl_xor((int) r0, 1);
-			bool const n_exact = 0 != __shfl_xor((int) exact, 1);
+			bool const n_exact = 0 != __shfl_xor((int) exact, 1), n_has_win = 0 != __shfl_xor((int) has_win, 1);
 			if (nb_cand && n_exact)
 				mate = n_r0;
+			else if (nb_cand && n_has_win)
+				mate = MATE_FROM_NEIGHBOUR;		// the neighbour goes to k_project_mid, which resolves its start: it fills this in
 			else if (m_win && !nb_cand && mo < mh.z)
 				mate = mh.y + mo;
 			else if (m_valid)

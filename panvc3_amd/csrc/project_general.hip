@@ -57,7 +57,13 @@ __global__ __launch_bounds__(256) void k_project_general(dev_entry const *__rest
 			if (skip && A.src_e < n_entries && A.dst_e < n_entries)
 			{
 				if (resolve_start(entries[A.src_e], entries[A.dst_e], A.dst_e, A.src_pos, A.col, A.r0, skip))
+				{
 					W.dst_pos[rec] = A.r0;
+					// The neighbouring record may be this record's mate, waiting for this position (k_project_fast).
+					uint64_t const nb = rec ^ 1;
+					if (nb < in.n && MATE_FROM_NEIGHBOUR == W.mate_dst_pos[nb]) W.mate_dst_pos[nb] = A.r0;
+					W.cig_n[rec] = 0;
+				}
 			}
 		}
 

@@ -264,6 +264,9 @@ __global__ __launch_bounds__(256, 4) void k_project_mid(dev_entry const *__restr
 			{
 				W.dst_pos[rec] = r0;
 				start_moved = true;
+				// The neighbouring record may be this record's mate, waiting for this position (k_project_fast).
+				uint64_t const nb = (uint64_t) rec ^ 1;
+				if (nb < in.n && MATE_FROM_NEIGHBOUR == W.mate_dst_pos[nb]) W.mate_dst_pos[nb] = r0;
 			}
 			uint32_t col = col0, r = r0, q = 0, steps = 0;
 			// The two rows' gap words, from the paired copy (one 128-byte line for both) when the destination is the source's

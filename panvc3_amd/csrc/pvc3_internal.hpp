@@ -87,6 +87,9 @@ static_assert(88 == sizeof(dev_entry), "dev_entry layout");
 constexpr uint32_t PWIN_HEADER = 16;			// bytes
 constexpr uint32_t PWIN_TEXT_BACK = 2;			// nibbles of text before base r0 in a window (the compare may start one nibble early)
 constexpr uint32_t PWIN_CLEAN_CAP = 1024;		// columns
+// mate_dst_pos of a record whose mate is the neighbouring record (rec ^ 1) while that record's own start is still to be
+// resolved (resolve_start): the walk kernel that resolves it stores the projected position here as well.
+constexpr uint32_t MATE_FROM_NEIGHBOUR = 0xFFFFFFFEu;
 constexpr uint32_t PWIN_NO_ANCHOR = 0xFFFFFFFFu;	// `skip` of a record whose start column has to be looked up from the select samples
 // The compare reads the run in 16-byte pieces from the byte of its first nibble: piece floor(U / 32) is the last one, so a
 // run of U <= 159 nibbles that starts in the first 96 nibbles of a line ends at byte 47 + 80 = 127 of it.

@@ -170,6 +170,7 @@ def main():
 	index = panvc3_amd.Index()
 	genome.fill_index(index)
 	ctx = panvc3_amd.Context(local_rank)
+	ctx.set_option("window_read_length", int(rp.read_len))		# position windows of 128 bytes up to 158 bases, 256 beyond (what a caller that knows its reads passes)
 	for kv in args.option:
 		k, v = kv.split("=", 1)
 		ctx.set_option(k, int(v))

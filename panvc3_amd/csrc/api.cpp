@@ -69,6 +69,7 @@ struct pvc3_context
 	uint32_t window_read_length{150};	// longest read whose compare is to be served from one window: up to 158 bases -> 128-byte windows, else 256
 	uint64_t window_reserve{UINT64_C(24) << 30};	// HBM that must stay free after the windows (batches, arenas, trace)
 	bool have_windows{};				// the uploaded index has them: k_project_fast runs, otherwise k_project_fast_probes
+	bool wide_windows{};				// ... of 256 bytes
 	uint8_t *scratch{};
 	uint64_t scratch_alloc{};
 	uint32_t *trace{};					// trace words of the packed alignment kernels
@@ -262,7 +263,8 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	HIP_TRY(hipMemsetAsync(b->work.counters, 0, sizeof(dev_counters), s));
 	HIP_TRY(hipMemsetAsync(b->work.wave_stats, 0, 3 * (uint64_t) project_wave_count(b->n) * WAVE_STATS * sizeof(unsigned long long), s));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
-	if (int const e = (ctx->have_windows ? launch_project_fast : launch_project_probes)(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s))
+	if (int const e = ctx->have_windows ? launch_project_fast(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, ctx->wide_windows, s)
+			: launch_project_probes(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s))
 		return set_error(PVC3_E_HIP, "k_project_fast launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
 	if (ctx->mid_path)
@@ -502,6 +504,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 		windows = need && (need + plain + ctx->window_reserve <= free_b);
 	}
 	ctx->have_windows = false;
+	ctx->wide_windows = pwin_shift > 6;
 	for (size_t i = 0; i < idx->entries.size(); ++i)
 	{
 		host_entry const &e = idx->entries[i];

@@ -119,6 +119,9 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 #define FAST_STAMP(k) do { } while (0)
 #endif
 
+// t_wide: 256-byte windows, for reads of up to 255 bases.  Only there can a record need a ninth piece of text, and the code
+// that fetches it costs the narrow kernel registers it does not have.
+template <bool t_wide>
 __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W, uint32_t use_fast_path)
 {
 	uint32_t const lane = lane_id();
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 
 		// ---- the record's window: header requested now, read after the compare ---------------------------------------------------------
 		bool const has_win = ok && S.pwin && S.partner == dst_e;
+		uint32_t const text_len = S.text_len;
 		uint32_t const sh = S.shift;
 		uint32_t const o = src_pos & ((1u << sh) - 1);		// the record starts o source positions into its window
 		uint8_t const *line = S.pwin + ((uint64_t) (src_pos >> sh) << (sh + 1));
@@ -355,6 +359,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			if (m_win && !nb_cand) mh = global_load16(M.pwin + ((uint64_t) (mate_pos >> M.shift) << (M.shift + 1)));
 		}
 		bool const count_mate = m_in && !nb_cand;
+		// The per-lane conditions that are needed again after the compare, as bits of one register: as booleans each of them
+		// is a lane mask in a pair of SGPRs, and the kernel has more such pairs alive than SGPRs.
+		enum : uint32_t { B_VALID = 1, B_OK = 2, B_HAS_WIN = 4, B_NB = 8, B_M_WIN = 16, B_M_VALID = 32, B_COUNT_MATE = 64, B_CAND = 128 };
+		uint32_t bits = (valid ? B_VALID : 0u) | (ok ? B_OK : 0u) | (has_win ? B_HAS_WIN : 0u) | (nb_cand ? B_NB : 0u) | (m_win ? B_M_WIN : 0u)
+			| (m_valid ? B_M_VALID : 0u) | (count_mate ? B_COUNT_MATE : 0u);
 		FAST_STAMP(2);		// window headers (the diagnostic build waits for them here; the kernel reads them after the compare)
 
 		// ---- fast path: the compare, on every record that can still turn out to be one --------------------------------------------------
@@ -376,8 +385,12 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			uint32_t const U = ref_consumed + phase;
 			uint32_t const pq = (2 * sb + U + 31) / 32, pt = (st + U + 31) / 32;
 			pieces = (pq > pt) ? pq : pt;
-			bool const fits = (pieces <= FAST_WORDS) && (PWIN_HEADER + 4 * (nib >> 3) + 16 * pieces <= (2u << sh));
+			// (A ninth piece — 250 bases and an unlucky shift — is never more than the one dword that the shift pulls in: the
+			// lane of the eighth piece loads it itself.)
+			uint32_t const bytes = (pieces <= FAST_WORDS) ? 16 * pieces : 16 * FAST_WORDS + 4;
+			bool const fits = (pieces <= FAST_WORDS + (t_wide ? 1 : 0)) && (PWIN_HEADER + 4 * (nib >> 3) + bytes <= (2u << sh));
 			cand = use_fast_path && has_win && simple && (U < FAST_MAX_BASES) && fits;
+			bits |= cand ? B_CAND : 0u;
 		}
 		bool fast = false;
 		uint32_t col = 0, r0 = 0, skip = PWIN_NO_ANCHOR;
@@ -391,7 +404,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 #endif
 		{
 			uint32_t const U = cand ? (ref_consumed + phase) : 0;
-			n_words = wave_max(cand ? pieces : 0);		// 1 .. FAST_WORDS
+			n_words = wave_max(cand ? ((pieces < FAST_WORDS) ? pieces : FAST_WORDS) : 0);		// 1 .. FAST_WORDS
 			// The compare is done by n_words lanes per record, one 32-position word each: a wave instruction then touches the
 			// lines of 64 / n_words records instead of one line per lane, which the memory pipeline serves 2-3x faster
 			// (tools/calib/random_access.hip).  Descriptors go to the lanes through LDS, the masks come back the same way.
@@ -408,25 +421,38 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				uint32_t const per = (64 * inv) >> 16;			// records per pass
 				uint32_t const sr = (lane * inv) >> 16;				// lane / n_words
 				uint32_t const w = lane - sr * n_words;
-				auto fetch = [&](uint32_t rr, bool act, u32x4 &qq, u32x4 &tt, uint32_t &left, uint32_t &shifts) {
+				// (`how`: bits 0-7 positions left to compare from this word on, 8-12 the two shifts, 13 "no lane holds the ninth piece")
+				auto fetch = [&](uint32_t rr, bool act, u32x4 &qq, u32x4 &tt, uint32_t &how) {
 					u64x2 const dd = my_desc[act ? rr : lane];
 					uint32_t const Ur = (uint32_t) (dd.x >> 48), meta = (uint32_t) (dd.y >> 48);
-					left = (act && Ur > 32 * w) ? (Ur - 32 * w) : 0;
-					shifts = meta & 31;
+					uint32_t const left = (act && Ur > 32 * w) ? (Ur - 32 * w) : 0;
+					uint32_t shifts = meta & 31;
 					if (act && w < (meta >> 5))		// both loads stay inside the record's SEQ (+ padding) and the window's line
 					{
 						qq = global_load16((uint32_t const *) (dd.x & UINT64_C(0xFFFFFFFFFFFF)) + 4 * w);
 						tt = global_load16((uint32_t const *) (dd.y & UINT64_C(0xFFFFFFFFFFFF)) + 4 * w);
 					}
+					if (t_wide) shifts |= (act && FAST_WORDS - 1 == w && FAST_WORDS < (meta >> 5)) ? 0x100u : 0u;		// no lane holds the ninth piece
+					how = left | (shifts << 8);
 				};
-				auto finish = [&](uint32_t rr, bool act, u32x4 const &qq, u32x4 const &tt, uint32_t left, uint32_t shifts) {
+				auto finish = [&](uint32_t rr, bool act, u32x4 const &qq, u32x4 const &tt, uint32_t how) {
+					uint32_t const left = how & 0xffu, shifts = how >> 8;
 					// The dword after a lane's 16 bytes is the first dword of the next lane's piece (a record's last piece
 					// never needs one: `pieces` counts what the shifts pull in).
-					uint32_t const nq = (uint32_t) __shfl_down((int) qq.x, 1), nt = (uint32_t) __shfl_down((int) tt.x, 1);
+					uint32_t nq = (uint32_t) __shfl_down((int) qq.x, 1), nt = (uint32_t) __shfl_down((int) tt.x, 1);
+					if (t_wide && (shifts & 0x100u))
+					{
+						// The ninth piece's first dword, from lines this lane has just read (a dependent load, but rare:
+						// 250 bases and a shift of seven nibbles; kept out of `fetch` for the registers it would hold there).
+						typedef uint32_t __attribute__((address_space(1))) const *gptr;
+						u64x2 const dd = my_desc[rr];
+						nq = ((gptr) (uintptr_t) (dd.x & UINT64_C(0xFFFFFFFFFFFF)))[4 * FAST_WORDS];
+						nt = ((gptr) (uintptr_t) (dd.y & UINT64_C(0xFFFFFFFFFFFF)))[4 * FAST_WORDS];
+					}
 					uint32_t m = 0;
 					if (left)
 					{
-						uint32_t const bq = 8 * (shifts & 3), bt = 4 * (shifts >> 2);
+						uint32_t const bq = 8 * (shifts & 3), bt = 4 * ((shifts >> 2) & 7);
 						uint32_t const q0 = __builtin_amdgcn_alignbit(qq.y, qq.x, bq), q1 = __builtin_amdgcn_alignbit(qq.z, qq.y, bq);
 						uint32_t const q2 = __builtin_amdgcn_alignbit(qq.w, qq.z, bq), q3 = __builtin_amdgcn_alignbit(nq, qq.w, bq);
 						uint32_t const t0 = __builtin_amdgcn_alignbit(tt.y, tt.x, bt), t1 = __builtin_amdgcn_alignbit(tt.z, tt.y, bt);
@@ -446,19 +472,19 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				for (uint32_t base = 0; base < 64; base += FAST_PASSES * per)
 				{
 					u32x4 qv[FAST_PASSES], tv[FAST_PASSES];
-					uint32_t left_v[FAST_PASSES], shift_v[FAST_PASSES];
+					uint32_t how_v[FAST_PASSES];
 #pragma unroll
 					for (uint32_t k = 0; k < FAST_PASSES; ++k)
 					{
 						uint32_t const rr = base + k * per + sr;
 						qv[k] = u32x4{0, 0, 0, 0}; tv[k] = u32x4{0, 0, 0, 0};
-						fetch(rr, (sr < per) & (rr < 64), qv[k], tv[k], left_v[k], shift_v[k]);
+						fetch(rr, (sr < per) & (rr < 64), qv[k], tv[k], how_v[k]);
 					}
 #pragma unroll
 					for (uint32_t k = 0; k < FAST_PASSES; ++k)
 					{
 						uint32_t const rr = base + k * per + sr;
-						finish(rr, (sr < per) & (rr < 64), qv[k], tv[k], left_v[k], shift_v[k]);
+						finish(rr, (sr < per) & (rr < 64), qv[k], tv[k], how_v[k]);
 					}
 				}
 			}
@@ -467,7 +493,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		}
 
 		// ---- what the window says (rewrite_cigar.hh:51-56) ---------------------------------------------------------------------------------
-		if (has_win)
+		if (bits & B_HAS_WIN)
 		{
 			uint32_t const clean = hdr.z;
 			// Clean columns hold one source position and one destination position each: inside the clean stretch the start
@@ -478,32 +504,33 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			r0 = hdr.y + adv;
 			skip = (o < clean) ? 0 : (o - clean + 1);
 			// No gap column in either row from the window's first column to the record's last.
-			fast = cand && (o + ref_consumed <= clean) && ((uint64_t) r0 + ref_consumed <= S.text_len);
+			fast = (bits & B_CAND) && (o + ref_consumed <= clean) && ((uint64_t) r0 + ref_consumed <= text_len);
 		}
-		bool const exact = has_win && (0 == skip);
+		bool const exact = (bits & B_HAS_WIN) && (0 == skip);
 		FAST_STAMP(3);		// window header
 
 		// ---- mate (project_alignments.cc:897-901) -----------------------------------------------------------------------------------
 		uint32_t mate = PVC3_NO_MATE;
 		{
 			uint32_t const n_r0 = (uint32_t) __shfl_xor((int) r0, 1);
-			bool const n_exact = 0 != __shfl_xor((int) exact, 1), n_has_win = 0 != __shfl_xor((int) has_win, 1);
-			if (nb_cand && n_exact)
+			bool const n_exact = 0 != __shfl_xor((int) exact, 1), n_has_win = 0 != (__shfl_xor((int) bits, 1) & B_HAS_WIN);
+			bool const nb = 0 != (bits & B_NB), mw = 0 != (bits & B_M_WIN);
+			if (nb && n_exact)
 				mate = n_r0;
-			else if (nb_cand && n_has_win)
+			else if (nb && n_has_win)
 				mate = MATE_FROM_NEIGHBOUR;		// the neighbour goes to k_project_mid, which resolves its start: it fills this in
-			else if (m_win && !nb_cand && mo < mh.z)
+			else if (mw && !nb && mo < mh.z)
 				mate = mh.y + mo;
-			else if (m_valid)
+			else if (bits & B_M_VALID)
 			{
 				// The rare cases: the mate's window is not clean up to the mate, the neighbour's own look-up is left to
 				// k_project_mid, or the pair of entries has no windows.  (The mate's descriptor is read again here rather than
 				// kept in registers across the compare.)
 				uint32_t const se = in.mate_src_entry[rl], de = in.mate_dst_entry[rl], pos = in.mate_pos[rl];
-				if (m_win)
+				if (mw)
 				{
 					dev_entry const &MS = entries[se];
-					if (nb_cand) mh = global_load16(MS.pwin + ((uint64_t) (pos >> MS.pwin_shift) << (MS.pwin_shift + 1)));
+					if (nb) mh = global_load16(MS.pwin + ((uint64_t) (pos >> MS.pwin_shift) << (MS.pwin_shift + 1)));
 					if (mo < mh.z)
 						mate = mh.y + mo;
 					else
@@ -516,7 +543,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 				else
 					mate = thread_project_position(entries[se], entries[de], de, pos);
 			}
-			if (count_mate)
+			if (bits & B_COUNT_MATE)
 				acc_bytes += 4 + 64 + 64;		// select sample, one source block, one destination block
 		}
 		FAST_STAMP(4);		// mate
@@ -622,7 +649,7 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 
 		// ---- work list of the records left for k_project_mid --------------------------------------------------------------------------
 		{
-			uint64_t const m = ballot(valid && ok && !fast);
+			uint64_t const m = ballot((bits & B_OK) && !fast);
 			if (g == g_begin) items_mode = popc64(m) <= 32;
 			if ((m >> lane) & 1)
 			{
@@ -643,11 +670,11 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 		}
 
 		// ---- per-record outputs (coalesced) ----------------------------------------------------------------------------------------------
-		if (valid)
+		if (bits & B_VALID)
 		{
-			bool const slow = ok && !fast;
+			bool const slow = (bits & B_OK) && !fast;
 			W.mate_dst_pos[rec] = mate;
-			W.dst_pos[rec] = ok ? r0 : 0;		// a rejected record has empty outputs; a record with skip != 0 gets its position from the walk kernels
+			W.dst_pos[rec] = (bits & B_OK) ? r0 : 0;		// a rejected record has empty outputs; a record with skip != 0 gets its position from the walk kernels
 			W.rec_flags[rec] = slow ? REC_SLOW : status;
 			W.cig_n[rec] = slow ? skip : f_n_out;	// (slow: see resolve_start; the walk kernels store the number of operations)
 			W.cig_loc[rec] = slow ? ((uint64_t) col | ((uint64_t) ref_consumed << 32)) : f_loc;
@@ -699,12 +726,15 @@ uint32_t grid_blocks(uint64_t n)
 
 uint32_t project_wave_count(uint64_t n) { return 4 * grid_blocks(n); }
 
-int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream)
+int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, bool wide_windows, void *stream)
 {
 	if (0 == in.n) return 0;
 	// PVC3_FAST_DYN_LDS: bytes of unused dynamic LDS per block — an occupancy experiment (fewer blocks per CU), not an option.
 	static uint32_t const dyn_lds = [] { char const *e = getenv("PVC3_FAST_DYN_LDS"); return e ? (uint32_t) atoi(e) : 0u; }();
-	hipLaunchKernelGGL(k_project_fast, dim3(grid_blocks(in.n)), dim3(256), dyn_lds, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
+	if (wide_windows)
+		hipLaunchKernelGGL(k_project_fast <true>, dim3(grid_blocks(in.n)), dim3(256), dyn_lds, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
+	else
+		hipLaunchKernelGGL(k_project_fast <false>, dim3(grid_blocks(in.n)), dim3(256), dyn_lds, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
 	return (int) hipGetLastError();
 }
 

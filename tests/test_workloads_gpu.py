@@ -36,9 +36,15 @@ def test_scaled_configs(pvc3, oracle_mod, synth, name, scale):
 	reads = synth.Reads(genome, rp)
 	batch = reads.batch()
 	for mode in (0, 1):
-		got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, batch, score_mode=mode)
+		# Position windows sized for the reads (256-byte windows for the 250-base reads of C5: k_project_fast <true>) in the
+		# second pass, the default (128 bytes: reads of more than 158 bases are left to k_project_mid) in the first.
+		ctx = pvc3.Context(0)
+		if mode: ctx.set_option("window_read_length", rp.read_len)
+		got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, batch, ctx=ctx, score_mode=mode)
 		assert stats["n_failed"] == 0
 		assert stats["attempts"] == 1
+		if mode and "default" == pvc3.paths_mode and "C3G" != name:
+			assert stats["n_fast_path"] > 0.5 * reads.n
 	if name == "C5":
 		assert stats["n_realigned_records"] > 0.02 * reads.n		# long events: a few percent of the reads are realigned
 	# mate symmetry: both reads of a pair see each other's projected position
@@ -477,6 +483,7 @@ def test_full_size_properties(pvc3, oracle_mod, synth, name):
 	index = pvc3.Index()
 	genome.fill_index(index)
 	ctx = pvc3.Context(0)
+	ctx.set_option("window_read_length", rp.read_len)		# as bench.py does
 	ctx.upload_index(index)
 	db = pvc3.DeviceBatch(ctx, batch)
 	db.project()

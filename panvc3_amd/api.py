@@ -403,6 +403,8 @@ class Pipeline:
 		res["run_off"] = out["run_off"][:n + 1]
 		res["out_cigar"] = out["out_cigar"][:int(stats["out_cigar_total"])]
 		res["runs"] = out["runs"][:int(stats["n_runs"])]
+		if "_owner" in out:
+			res["_owner"] = out["_owner"]		# the views above do not keep page-locked memory alive
 		return res, stats
 
 	def in_flight(self):

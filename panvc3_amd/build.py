@@ -145,7 +145,7 @@ def build_cpp_tests(force=False, verbose=False):
 		dst = os.path.join(BIN, "test_" + os.path.splitext(name)[0])
 		out.append(dst)
 		cmd = [os.environ.get("CXX", "g++"), "-O2", "-g", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(HERE, "..", "include"), "-o", dst, src,
-			   "-L" + HERE, "-lpvc3_hip", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]
+			   "-L" + HERE, "-lpvc3_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]
 		host_headers = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp"))
 		key = _key([src, os.path.join(HERE, "..", "include", "pvc3.hpp"), os.path.join(HERE, "..", "include", "pvc3.h"), os.path.join(OBJ, "libpvc3_hip.so.key")] + host_headers, cmd[1:])
 		if force or _stale(dst, key):

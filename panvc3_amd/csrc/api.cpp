@@ -105,6 +105,7 @@ struct pvc3_dbatch
 	uint32_t *d_invalid{};				// the first malformed record, 0xFFFFFFFF if the layout is sound (k_validate_batch)
 	bool projected{};
 	bool finished{};
+	bool timed{};						// the context's timing events bracket THIS batch's kernels (never in a pipeline: the next batch re-records them)
 	pvc3_params params{};
 	uint32_t attempts{};
 	dev_counters counters{};
@@ -262,6 +263,7 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	b->work.trace_cap = ctx->trace_cap;
 	HIP_TRY(hipMemsetAsync(b->work.counters, 0, sizeof(dev_counters), s));
 	HIP_TRY(hipMemsetAsync(b->work.wave_stats, 0, 3 * (uint64_t) project_wave_count(b->n) * WAVE_STATS * sizeof(unsigned long long), s));
+	b->timed = ctx->timing;
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
 	if (int const e = ctx->have_windows ? launch_project_fast(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, ctx->wide_windows, s)
 			: launch_project_probes(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s))
@@ -793,7 +795,9 @@ int dbatch_load(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_in const *in, hipS
 	// Offsets must not decrease and every record must own the SEQ / QUAL bytes its l_seq promises: the kernels read
 	// seq4 + seq_off and qual + qual_off without further checks.
 	HIP_TRY(hipMemsetAsync(b->d_invalid, 0xff, sizeof(uint32_t), s));
-	if (int const e = launch_validate(d, n_cigar, n_seq, lazy_qual ? 0 : n_qual, lazy_qual ? nullptr : d.qual_off, b->d_invalid, s)) return set_error(PVC3_E_HIP, "k_validate_batch launch: %s", hipGetErrorString((hipError_t) e));
+	// (QUAL that stays in the caller's page-locked arrays is read by k_gather_qual through those offsets: they are checked
+	// just the same, in place — eight bytes per record over PCIe.)
+	if (int const e = launch_validate(d, n_cigar, n_seq, n_qual, lazy_qual ? w.host_qual_off : d.qual_off, b->d_invalid, s)) return set_error(PVC3_E_HIP, "k_validate_batch launch: %s", hipGetErrorString((hipError_t) e));
 	b->projected = false; b->finished = false;
 	return PVC3_OK;
 }
@@ -925,7 +929,7 @@ void fill_stats(pvc3_context *ctx, pvc3_dbatch const *b, pvc3_batch_stats *stats
 	// Realignment: QUAL of realigned records, 16 bytes per realigned range.  Packing traffic is not algorithmic.
 	stats->algorithmic_bytes_project = c.fast_bytes;
 	stats->algorithmic_bytes = c.fast_bytes + c.general_bytes + c.qual_bytes + sizeof(pvc3_run) * b->totals[1];
-	if (ctx->timing)
+	if (b->timed)
 	{
 		(void) hipEventElapsedTime(&stats->ms_project, ctx->ev[0], ctx->ev[1]);
 		(void) hipEventElapsedTime(&stats->ms_mid, ctx->ev[1], ctx->ev[5]);
@@ -1053,10 +1057,13 @@ int pipeline_start_download(pvc3_pipeline *p, pvc3_pipeline::slot &sl)
 	// Only this batch's kernels are waited for: later batches may already be queued on the same streams.
 	HIP_TRY(hipEventSynchronize(sl.projected));
 	hipStream_t const keep = ctx->stream;
+	bool const keep_timing = ctx->timing;
 	ctx->stream = p->s_kernels;
+	ctx->timing = false;
 	int rc = dbatch_check_valid(b, nullptr);
 	if (!rc) rc = dbatch_complete(ctx, b, true);
 	ctx->stream = keep;
+	ctx->timing = keep_timing;
 	if (rc) return rc;
 	uint64_t const n = b->n, n_cig = b->totals[0], n_runs = b->totals[1];
 	pvc3_batch_out const &out = sl.out;
@@ -1147,7 +1154,17 @@ int pvc3_pipeline_submit(pvc3_pipeline *p, pvc3_batch_in const *in, pvc3_batch_o
 		return set_error(PVC3_E_INVALID, "pvc3_pipeline_submit: a required output array is null");
 	pvc3_context *ctx = p->ctx;
 	PVC3_TRY(check_device(ctx));
-	PVC3_TRY(upload_params(ctx, *params));
+	{
+		// A change of the parameters is ordered on the stream the kernels of the batches in flight read them on.
+		hipStream_t const keep = ctx->stream;
+		ctx->stream = p->s_kernels;
+		int const rc = upload_params(ctx, *params);
+		ctx->stream = keep;
+		PVC3_TRY(rc);
+	}
+	// ensure_scratch / ensure_trace (and the growth after an overflow) free the buffers that queued batches hold as kernel
+	// arguments; that is safe only because hipFree waits for everything queued on the device — which also stalls the overlap,
+	// so the capacities should be set to what the batches need (options trace_initial, scratch_per_wave) before the first batch.
 	PVC3_TRY(ensure_scratch(ctx));
 	auto &sl = p->slots[p->submitted % depth];
 	pvc3_dbatch *b = sl.b;
@@ -1157,10 +1174,13 @@ int pvc3_pipeline_submit(pvc3_pipeline *p, pvc3_batch_in const *in, pvc3_batch_o
 	HIP_TRY(hipEventRecord(sl.loaded, p->s_h2d));
 	HIP_TRY(hipStreamWaitEvent(p->s_kernels, sl.loaded, 0));
 	hipStream_t const keep = ctx->stream;
+	bool const keep_timing = ctx->timing;
 	ctx->stream = p->s_kernels;
+	ctx->timing = false;			// the context's events would be re-recorded by the next batch: pipelined batches report no kernel times
 	b->params = *params; b->attempts = 1; b->finished = false;
 	int const rc = enqueue_projection(ctx, b);
 	ctx->stream = keep;
+	ctx->timing = keep_timing;
 	PVC3_TRY(rc);
 	b->projected = true;
 	HIP_TRY(hipEventRecord(sl.projected, p->s_kernels));

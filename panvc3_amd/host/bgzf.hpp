@@ -172,6 +172,9 @@ class byte_reader
 	}
 
 public:
+	// Length of the BGZF block at p and where its deflate data begin (the BC subfield is found by walking the extra field).
+	static std::size_t bgzf_block_size(uint8_t const *p, std::size_t n, std::size_t &data_off) { return block_size(p, n, data_off); }
+
 	byte_reader() = default;
 	byte_reader(byte_reader const &) = delete;
 	~byte_reader() { close(); }
@@ -450,6 +453,15 @@ public:
 	void close()
 	{
 		if (!m_file) return;
+		// Whatever happens below, this object is closed afterwards: the destructor must not run close() again over the same
+		// pending data after an error.
+		FILE *f = m_file;
+		bool const owns = m_owns;
+		struct closer
+		{
+			byte_writer &w; FILE *f; bool owns; bool done;
+			~closer() { if (!done) { w.m_pending.clear(); w.m_file = nullptr; if (owns) std::fclose(f); } }
+		} guard{*this, f, owns, false};
 		if (m_bgzf)
 		{
 			flush_blocks(true);
@@ -458,9 +470,14 @@ public:
 			static uint8_t const eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 			write_raw(eof, sizeof(eof));
 		}
-		std::fflush(m_file);
-		if (m_owns) std::fclose(m_file);
+		// The last buffered bytes (the EOF block among them) reach the file only here: a full disk must not end in a truncated
+		// file and exit code 0.
+		bool const flushed = 0 == std::fflush(f);
+		bool const closed = !owns || 0 == std::fclose(f);
+		guard.done = true;
+		m_pending.clear();
 		m_file = nullptr;
+		if (!flushed || !closed) throw io_error("write error while closing the output (disk full?)");
 	}
 };
 

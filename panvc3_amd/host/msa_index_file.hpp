@@ -211,9 +211,10 @@ public:
 			uint8_t const *p = comp.data() + (m_blocks[b0 + i].first - c_begin);
 			std::size_t const avail = comp.size() - (m_blocks[b0 + i].first - c_begin);
 			if (avail < 18 + 8) throw io_error("corrupt BGZF block");
-			std::size_t const xlen = p[10] | ((std::size_t) p[11] << 8);
-			std::size_t const bsize = (std::size_t) (p[16] | ((std::size_t) p[17] << 8)) + 1;		// bgzip writes the BC field first
-			if (bsize > avail || bsize < 12 + xlen + 8) throw io_error("corrupt BGZF block");
+			std::size_t data_off = 0;
+			std::size_t const bsize = byte_reader::bgzf_block_size(p, avail, data_off);		// walks the extra field: BC need not be its first subfield
+			std::size_t const xlen = data_off - 12;
+			if (0 == bsize || bsize > avail || bsize < 12 + xlen + 8) throw io_error("corrupt BGZF block");
 			uint32_t isize; std::memcpy(&isize, p + bsize - 4, 4);
 			plain[i].resize(isize);
 			z_stream zs{};
@@ -254,8 +255,9 @@ inline bool read_fasta_contigs(char const *path, std::vector <std::string> const
 	{
 		auto const it = std::find_if(fai.begin(), fai.end(), [&](fai_entry const &e) { return e.name == name; });
 		if (fai.end() == it) continue;		// the caller reports what is missing
+		// Up to the contig's last base: the terminator of its last line is not asked for (a FASTA may end without one).
 		uint64_t const full_lines = it->length / it->line_bases, rest = it->length % it->line_bases;
-		uint64_t const bytes = full_lines * it->line_width + rest;
+		uint64_t const bytes = rest ? (full_lines * it->line_width + rest) : (full_lines ? ((full_lines - 1) * it->line_width + it->line_bases) : 0);
 		ra.read(it->offset, it->offset + bytes, raw);
 		std::vector <char> seq;
 		seq.reserve(it->length);

@@ -1,0 +1,82 @@
+"""Host-side I/O pieces that need no GPU: per-contig FASTA access through .fai / .gzi (the reference requires both files,
+libpanvc3/compressed_fasta_reader.cc:163-248) and the BGZF writer's behaviour when the last bytes cannot be written."""
+import os
+import struct
+import subprocess
+import zlib
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "bin", "test_fasta_access_test")
+
+
+@pytest.fixture(scope="module")
+def tool():
+	from panvc3_amd import build
+	build.build_cpp_tests()
+	assert os.path.exists(TOOL)
+	return TOOL
+
+
+def _fasta(contigs, width, final_newline=True):
+	text, fai = b"", []
+	for name, seq in contigs:
+		text += b">" + name.encode() + b"\n"
+		off = len(text)
+		for i in range(0, len(seq), width):
+			text += seq[i:i + width].encode() + b"\n"
+		fai.append("%s\t%d\t%d\t%d\t%d\n" % (name, len(seq), off, width, width + 1))
+	if not final_newline:
+		text = text[:-1]
+	return text, "".join(fai)
+
+
+def _bgzf_block(data, extra_first=b""):
+	"""One BGZF block; extra_first: other subfields placed BEFORE the BC subfield."""
+	comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+	body = comp.compress(data) + comp.flush()
+	xlen = len(extra_first) + 6
+	bsize = 12 + xlen + len(body) + 8
+	return (struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, xlen) + extra_first + b"BC" + struct.pack("<HH", 2, bsize - 1)
+			+ body + struct.pack("<II", zlib.crc32(data), len(data)))
+
+
+CONTIGS = [("chrA", "ACGT" * 30), ("chrB", "TTGACCA" * 9 + "GG"), ("chrC", "G" * 120)]		# chrA and chrC: whole lines only (width 60)
+
+
+@pytest.mark.parametrize("final_newline", [True, False])
+def test_contigs_through_fai(tool, tmp_path, final_newline):
+	text, fai = _fasta(CONTIGS, 60, final_newline)
+	p = tmp_path / "ref.fa"
+	p.write_bytes(text)
+	(tmp_path / "ref.fa.fai").write_text(fai)
+	out = subprocess.run([tool, "contigs", str(p), "chrC", "chrA", "nosuch", "chrB"], capture_output=True, text=True)
+	assert out.returncode == 0, out.stderr
+	assert out.stdout == "".join(">%s\n%s\n" % (n, dict(CONTIGS)[n]) for n in ("chrC", "chrA", "chrB"))
+
+
+@pytest.mark.parametrize("extra_first", [b"", b"XY" + struct.pack("<H", 3) + b"abc"])
+def test_contigs_through_gzi(tool, tmp_path, extra_first):
+	text, fai = _fasta(CONTIGS, 60, final_newline=False)
+	# blocks of 100 uncompressed bytes, .gzi = pairs (compressed offset, uncompressed offset) of every block but the first
+	blocks, gzi, c_off = [], [], 0
+	for u in range(0, len(text), 100):
+		b = _bgzf_block(text[u:u + 100], extra_first)
+		if u: gzi.append((c_off, u))
+		blocks.append(b); c_off += len(b)
+	blocks.append(_bgzf_block(b""))
+	p = tmp_path / "ref.fa.gz"
+	p.write_bytes(b"".join(blocks))
+	(tmp_path / "ref.fa.gz.fai").write_text(fai)
+	(tmp_path / "ref.fa.gz.gzi").write_bytes(struct.pack("<Q", len(gzi)) + b"".join(struct.pack("<QQ", c, u) for c, u in gzi))
+	out = subprocess.run([tool, "contigs", str(p), "chrB", "chrC"], capture_output=True, text=True)
+	assert out.returncode == 0, out.stderr
+	assert out.stdout == "".join(">%s\n%s\n" % (n, dict(CONTIGS)[n]) for n in ("chrB", "chrC"))
+
+
+def test_writer_reports_a_failed_close(tool):
+	if not os.path.exists("/dev/full"):
+		pytest.skip("no /dev/full")
+	out = subprocess.run([tool, "full-device"], capture_output=True, text=True)
+	assert out.returncode == 3, (out.returncode, out.stderr)

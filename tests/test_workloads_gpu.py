@@ -700,4 +700,16 @@ def test_malformed_batches_are_refused(pvc3, oracle_mod):
 	assert ei.value.code == -1
 	res, st = pipe.wait()
 	assert_results_equal(good, res, o.batch_project(good))
+	# The same through page-locked arrays, whose QUAL is not uploaded but fetched by the kernels through the caller's offsets.
+	keep = []
+	for bad in (cases[5], cases[6], good):
+		pb, own = pvc3.pinned_batch(bad)
+		keep.append(own)
+		pipe.submit(pb, pvc3.Pipeline.output_arrays(64, 4096, 64))
+	for _ in range(2):
+		with pytest.raises(pvc3.Error) as ei:
+			pipe.wait()
+		assert ei.value.code == -1
+	res, st = pipe.wait()
+	assert_results_equal(good, res, o.batch_project(good))
 	pipe.close()

@@ -32,6 +32,19 @@ METRIC = {
 }
 
 
+def usable_cpus():
+	"""The CPUs this process can really use: the affinity mask, cut down by a cgroup CPU quota (the GPU boxes show every core of
+	their host but grant a share of them — `cores` of the CPU baseline must be that share, not the host's core count)."""
+	n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+	try:
+		quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+		if quota != "max" and int(period) > 0:
+			n = min(n, max(1, -(-int(quota) // int(period))))
+	except Exception:
+		pass
+	return max(1, n)
+
+
 def log(msg):
 	if int(os.environ.get("RANK", "0")) == 0:
 		print("[bench] " + msg, file=sys.stderr, flush=True)
@@ -145,7 +158,7 @@ def main():
 	from panvc3_amd.shard import reduce_job
 	from tests.synth import synth
 
-	cores = os.cpu_count() or 1
+	cores = usable_cpus()
 	threads = max(1, cores // max(1, world))
 	config = args.config.upper()
 

@@ -10,8 +10,13 @@
 #include <cstring>
 #include <stdexcept>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <exception>
+#include <functional>
 #include <future>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,7 +30,91 @@ struct io_error : public std::runtime_error
 	using std::runtime_error::runtime_error;
 };
 
-// Runs fn(i) for i in [0, n) on up to n_threads threads (fork / join; the pieces are tens of kilobytes of zlib work each).
+// A pool of worker threads shared by everything in the process that calls parallel_for (the BGZF reader, the writer, the
+// stages of panvc3_project_alignments, each from a thread of its own).  Starting threads per call — several calls per batch,
+// dozens of threads each — was a tenth of the tool's CPU time.
+class worker_pool
+{
+	struct job
+	{
+		std::function <void(std::size_t)> const *fn{};
+		std::size_t n{};
+		std::atomic <std::size_t> next{0};
+		std::atomic <unsigned> running{0};		// tickets not finished yet
+		std::mutex m;
+		std::condition_variable done;
+		std::exception_ptr error;
+
+		void work()
+		{
+			try { for (std::size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n; ) (*fn)(i); }
+			catch (...) { std::lock_guard <std::mutex> l(m); if (!error) error = std::current_exception(); next.store(n); }
+		}
+	};
+	std::mutex m_mutex;
+	std::condition_variable m_cv;
+	std::deque <job *> m_tickets;
+	std::vector <std::thread> m_threads;
+	bool m_stop{};
+
+	void loop()
+	{
+		for (;;)
+		{
+			job *j{};
+			{
+				std::unique_lock <std::mutex> l(m_mutex);
+				m_cv.wait(l, [&]() { return m_stop || !m_tickets.empty(); });
+				if (m_tickets.empty()) return;
+				j = m_tickets.front(); m_tickets.pop_front();
+			}
+			j->work();
+			// (Notified under the job's lock: the caller, who owns the job, cannot wake up and destroy it before this thread is
+			// done with it.)
+			{ std::lock_guard <std::mutex> l(j->m); if (0 == --j->running) j->done.notify_all(); }
+		}
+	}
+
+public:
+	~worker_pool()
+	{
+		{ std::lock_guard <std::mutex> l(m_mutex); m_stop = true; }
+		m_cv.notify_all();
+		for (auto &t : m_threads) t.join();
+	}
+
+	static worker_pool &instance() { static worker_pool p; return p; }
+
+	// fn(i) for i in [0, n) on the calling thread and up to helpers pool threads.
+	void run(std::size_t n, unsigned helpers, std::function <void(std::size_t)> const &fn)
+	{
+		job j;
+		j.fn = &fn; j.n = n;
+		{
+			std::lock_guard <std::mutex> l(m_mutex);
+			while (m_threads.size() < helpers && m_threads.size() < 256) m_threads.emplace_back([this]() { loop(); });
+			j.running = helpers;
+			for (unsigned t = 0; t < helpers; ++t) m_tickets.push_back(&j);
+		}
+		m_cv.notify_all();
+		j.work();
+		{
+			// Tickets nobody has taken yet are taken back (the work is done); the others are waited for.
+			std::lock_guard <std::mutex> l(m_mutex);
+			for (auto it = m_tickets.begin(); it != m_tickets.end(); )
+				if (*it == &j) { it = m_tickets.erase(it); std::lock_guard <std::mutex> lj(j.m); --j.running; }
+				else ++it;
+		}
+		{
+			std::unique_lock <std::mutex> l(j.m);
+			j.done.wait(l, [&]() { return 0 == j.running; });
+		}
+		if (j.error) std::rethrow_exception(j.error);
+	}
+};
+
+// Runs fn(i) for i in [0, n) on up to n_threads threads: the caller and n_threads - 1 threads of the shared pool (the pieces
+// are tens of kilobytes of zlib work, or a slice of a batch, each).
 template <typename t_fn>
 inline void parallel_for(std::size_t n, unsigned n_threads, t_fn &&fn)
 {
@@ -35,21 +124,28 @@ inline void parallel_for(std::size_t n, unsigned n_threads, t_fn &&fn)
 		return;
 	}
 	unsigned const k = (unsigned) std::min <std::size_t>(n_threads, n);
-	std::vector <std::thread> pool;
-	std::vector <std::exception_ptr> errors(k);
-	for (unsigned t = 0; t < k; ++t)
-		pool.emplace_back([&, t]() {
-			try { for (std::size_t i = t; i < n; i += k) fn(i); }
-			catch (...) { errors[t] = std::current_exception(); }
-		});
-	for (auto &th : pool) th.join();
-	for (auto &e : errors) if (e) std::rethrow_exception(e);
+	std::function <void(std::size_t)> const f(std::ref(fn));
+	worker_pool::instance().run(n, k - 1, f);
 }
 
+// The CPUs this process may use: the machine's, or fewer under a cgroup CPU quota (a container on a large host — more
+// threads than the quota only take each other's time slices).
 inline unsigned default_io_threads()
 {
-	unsigned const hc = std::thread::hardware_concurrency();
-	return hc ? std::min(hc, 32u) : 4u;
+	unsigned hc = std::thread::hardware_concurrency();
+	if (0 == hc) hc = 4;
+	if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r"))		// cgroup v2: "<quota> <period>" or "max <period>"
+	{
+		char quota[32] = "";
+		long period = 0;
+		if (2 == std::fscanf(f, "%31s %ld", quota, &period) && period > 0 && 0 != std::strcmp(quota, "max"))
+		{
+			long const q = std::atol(quota);
+			if (q > 0) hc = std::min <unsigned>(hc, (unsigned) std::max <long>(1, (q + period - 1) / period));
+		}
+		std::fclose(f);
+	}
+	return std::min(hc, 32u);
 }
 
 // Sequential byte source: a file or stdin.  BGZF input (BAM, bgzip'ed SAM) is inflated block-parallel; plain gzip and

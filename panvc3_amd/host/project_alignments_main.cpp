@@ -223,6 +223,32 @@ struct batch_store
 	void swap(batch_store &o) { raw.swap(o.raw); begin.swap(o.begin); len.swap(o.len); input_index.swap(o.input_index); }
 };
 
+// A growable array in page-locked host memory (pvc3_host_alloc): what the pipelined entry point copies from and to without
+// staging.  Contents are not kept when it grows.
+template <typename t_value>
+struct pinned_array
+{
+	t_value *p{};
+	std::size_t cap{};
+	pinned_array() = default;
+	pinned_array(pinned_array const &) = delete;
+	pinned_array &operator=(pinned_array const &) = delete;
+	~pinned_array() { if (p) pvc3_host_free(p); }
+	void reserve(std::size_t n)
+	{
+		if (n <= cap) return;
+		if (p) { pvc3_host_free(p); p = nullptr; cap = 0; }
+		std::size_t const want = n + n / 4 + 64;
+		void *q{};
+		check(pvc3_host_alloc(want * sizeof(t_value), &q), "pvc3_host_alloc");
+		p = (t_value *) q; cap = want;
+	}
+	t_value *data() { return p; }
+	t_value const *data() const { return p; }
+	t_value &operator[](std::size_t i) { return p[i]; }
+	t_value const &operator[](std::size_t i) const { return p[i]; }
+};
+
 // Finished batches on their way to the output file: the formatted bytes of the slices, in order.
 struct write_job
 {
@@ -350,71 +376,82 @@ int main(int argc, char **argv)
 		process_headers(in_header, opt, out_header, ref_id_mapping);
 		append_program_info(in_header, out_header, argc, argv);
 
-		// ---- index, reference, GPU ---------------------------------------------------------------------------------------------
-		// The GPU contexts come up on a thread of their own (the HIP runtime takes a few tenths of a second to start) while the
-		// index file and the reference are read.
-		std::future <std::vector <pvc3_context *>> contexts_coming = std::async(std::launch::async, [&]() {
-			std::vector <pvc3_context *> made;
-			for (int const dev : opt.devices)
-			{
-				pvc3_context *ctx{};
-				if (pvc3_context_create(dev, &ctx)) throw std::runtime_error(std::string("pvc3_context_create: ") + pvc3_last_error());
-				made.push_back(ctx);
-			}
-			return made;
-		});
-		msa_index_file msa;
-		msa.load(opt.msa_index);
+		// ---- index, reference, GPUs: prepare_devices(), called once the reader thread is at work ------------------------------------
 		pvc3_index *index{};
-		check(pvc3_index_create(&index), "pvc3_index_create");
-		std::map <std::pair <std::string, std::string>, uint32_t> entry_ids;
-		auto entry_for = [&](std::string const &chr_id, std::string const &seq_id) -> uint32_t {
-			auto const key = std::make_pair(chr_id, seq_id);
-			auto const it = entry_ids.find(key);
-			if (entry_ids.end() != it) return it->second;
-			auto const *ce = msa.find_chr(chr_id);
-			if (!ce) die("Did not find an entry for chromosome ID “" + chr_id + "” in the MSA index.");
-			auto const *se = msa_index_file::find_seq(*ce, seq_id);
-			if (!se) die("Did not find an entry for sequence ID “" + seq_id + "” in the MSA index.");
-			uint32_t id{};
-			check(pvc3_index_add_bits(index, se->gap_words.data(), se->n_cols, &id), "pvc3_index_add_bits");
-			entry_ids.emplace(key, id);
-			return id;
-		};
-		// fill_sequence_entries (:1271-1316); the separator is matched as a substring here (quirk Q13).
 		std::vector <uint32_t> src_entries(in_header.refs.size()), dst_entries(out_header.refs.size(), UINT32_MAX);
-		for (std::size_t i = 0; i < in_header.refs.size(); ++i)
-		{
-			auto const &name = in_header.refs[i].name;
-			auto const pos = name.find(opt.separator);
-			if (std::string::npos == pos) die("Unable to find the separator “" + opt.separator + "” in the RNAME “" + name + "”.");
-			std::string const chr_id = name.substr(0, pos), seq_id = name.substr(pos + 1);
-			std::size_t const out_idx = ref_id_mapping[i];
-			if (UINT32_MAX == dst_entries[out_idx]) dst_entries[out_idx] = entry_for(chr_id, opt.reference_msa_id);
-			src_entries[i] = entry_for(chr_id, seq_id);
-		}
-		{
-			// The destination contigs only, through <reference>.fai (+ .gzi) when the indexes are there
-			// (libpanvc3/compressed_fasta_reader.cc:163-248 requires them); the whole file otherwise.
-			std::vector <std::pair <std::string, std::vector <char>>> fasta;
-			std::vector <std::string> wanted;
-			for (std::size_t o = 0; o < out_header.refs.size(); ++o)
-				if (UINT32_MAX != dst_entries[o]) wanted.push_back(out_header.refs[o].name);
-			bool const indexed = read_fasta_contigs(opt.reference, wanted, opt.threads, fasta);
-			if (!indexed) read_fasta(opt.reference, fasta);
-			if (opt.debugging_output) std::cerr << "Reference: " << fasta.size() << " sequences read " << (indexed ? "through the .fai index" : "from the whole file") << ".\n";
-			for (std::size_t o = 0; o < out_header.refs.size(); ++o)
-			{
-				if (UINT32_MAX == dst_entries[o]) continue;
-				auto const it = std::find_if(fasta.begin(), fasta.end(), [&](auto const &kv) { return kv.first == out_header.refs[o].name; });
-				if (fasta.end() == it) die("Unable to load sequence ‘" + out_header.refs[o].name + "’ from the input FASTA.");
-				check(pvc3_index_set_reference(index, dst_entries[o], it->second.data(), it->second.size()), "pvc3_index_set_reference");
-			}
-		}
+		std::vector <pvc3_context *> device_contexts;
 		double t_startup = 0.0;
-		std::vector <pvc3_context *> contexts = contexts_coming.get();
-		for (pvc3_context *ctx : contexts)
-			check(pvc3_context_upload_index(ctx, index), "pvc3_context_upload_index");		// the index is replicated on every GPU
+		auto prepare_devices = [&]() {
+			// The GPU contexts come up on a thread of their own (the HIP runtime takes a few tenths of a second to start) while the
+			// index file and the reference are read.
+			std::future <std::vector <pvc3_context *>> contexts_coming = std::async(std::launch::async, [&]() {
+				std::vector <pvc3_context *> made;
+				for (int const dev : opt.devices)
+				{
+					pvc3_context *ctx{};
+					if (pvc3_context_create(dev, &ctx)) throw std::runtime_error(std::string("pvc3_context_create: ") + pvc3_last_error());
+					made.push_back(ctx);
+				}
+				return made;
+			});
+			msa_index_file msa;
+			msa.load(opt.msa_index);
+			check(pvc3_index_create(&index), "pvc3_index_create");
+			std::map <std::pair <std::string, std::string>, uint32_t> entry_ids;
+			auto entry_for = [&](std::string const &chr_id, std::string const &seq_id) -> uint32_t {
+				auto const key = std::make_pair(chr_id, seq_id);
+				auto const it = entry_ids.find(key);
+				if (entry_ids.end() != it) return it->second;
+				auto const *ce = msa.find_chr(chr_id);
+				if (!ce) die("Did not find an entry for chromosome ID “" + chr_id + "” in the MSA index.");
+				auto const *se = msa_index_file::find_seq(*ce, seq_id);
+				if (!se) die("Did not find an entry for sequence ID “" + seq_id + "” in the MSA index.");
+				uint32_t id{};
+				check(pvc3_index_add_bits(index, se->gap_words.data(), se->n_cols, &id), "pvc3_index_add_bits");
+				entry_ids.emplace(key, id);
+				return id;
+			};
+			// fill_sequence_entries (:1271-1316); the separator is matched as a substring here (quirk Q13).
+			for (std::size_t i = 0; i < in_header.refs.size(); ++i)
+			{
+				auto const &name = in_header.refs[i].name;
+				auto const pos = name.find(opt.separator);
+				if (std::string::npos == pos) die("Unable to find the separator “" + opt.separator + "” in the RNAME “" + name + "”.");
+				std::string const chr_id = name.substr(0, pos), seq_id = name.substr(pos + 1);
+				std::size_t const out_idx = ref_id_mapping[i];
+				if (UINT32_MAX == dst_entries[out_idx]) dst_entries[out_idx] = entry_for(chr_id, opt.reference_msa_id);
+				src_entries[i] = entry_for(chr_id, seq_id);
+			}
+			{
+				// The destination contigs only, through <reference>.fai (+ .gzi) when the indexes are there
+				// (libpanvc3/compressed_fasta_reader.cc:163-248 requires them); the whole file otherwise.
+				std::vector <std::pair <std::string, std::vector <char>>> fasta;
+				std::vector <std::string> wanted;
+				for (std::size_t o = 0; o < out_header.refs.size(); ++o)
+					if (UINT32_MAX != dst_entries[o]) wanted.push_back(out_header.refs[o].name);
+				bool const indexed = read_fasta_contigs(opt.reference, wanted, opt.threads, fasta);
+				if (!indexed) read_fasta(opt.reference, fasta);
+				if (opt.debugging_output) std::cerr << "Reference: " << fasta.size() << " sequences read " << (indexed ? "through the .fai index" : "from the whole file") << ".\n";
+				for (std::size_t o = 0; o < out_header.refs.size(); ++o)
+				{
+					if (UINT32_MAX == dst_entries[o]) continue;
+					auto const it = std::find_if(fasta.begin(), fasta.end(), [&](auto const &kv) { return kv.first == out_header.refs[o].name; });
+					if (fasta.end() == it) die("Unable to load sequence ‘" + out_header.refs[o].name + "’ from the input FASTA.");
+					check(pvc3_index_set_reference(index, dst_entries[o], it->second.data(), it->second.size()), "pvc3_index_set_reference");
+				}
+			}
+			device_contexts = contexts_coming.get();
+			// The index is replicated on every GPU, all of them at the same time.
+			{
+				std::vector <std::future <int>> uploads;
+				std::vector <std::string> errors(device_contexts.size());
+				for (std::size_t d = 0; d < device_contexts.size(); ++d)
+					uploads.push_back(std::async(std::launch::async, [&, d]() { int const rc = pvc3_context_upload_index(device_contexts[d], index); if (rc) errors[d] = pvc3_last_error(); return rc; }));
+				for (std::size_t d = 0; d < uploads.size(); ++d)
+					if (uploads[d].get()) die("pvc3_context_upload_index: " + errors[d]);
+			}
+
+		};
 
 		alignment_writer writer;
 		writer.set_threads(opt.threads);
@@ -452,6 +489,13 @@ int main(int argc, char **argv)
 		struct join_writer { std::thread &t; std::mutex &m; std::condition_variable &cv; bool &done; ~join_writer() { { std::lock_guard <std::mutex> l(m); done = true; } cv.notify_all(); if (t.joinable()) t.join(); } } writer_joiner{writer_thread, wq_mutex, wq_cv, wq_done};
 
 		// ---- records ----------------------------------------------------------------------------------------------------------------
+		// Three kinds of threads work on different batches at the same time (project_alignments.cc:600-627 is one loop):
+		//   the reader      inflates the input and frames the records of batch k + 2 .. (read_batch, below);
+		//   this thread     fills the page-locked arrays of batch k and hands it to its GPU (pvc3_pipeline_submit: upload, kernels
+		//                   and download are asynchronous), then takes the results of batch k - 2 x GPUs and rewrites its records;
+		//   the writer      deflates and writes batch k - 2 x GPUs - 1.
+		// Batch k goes to GPU k mod D, every GPU has two batches of its own in flight, and the batches are retired in the order they
+		// were read, so the output does not depend on the number of GPUs or threads.
 		struct { uint64_t flags_not_matched{}, ref_id_missing{}, seq_missing{}, matched_reads{}; } st;
 		std::map <uint16_t, uint64_t> removed_tag_counts;
 		std::vector <std::pair <uint32_t, uint32_t>> realigned_ranges;
@@ -464,18 +508,9 @@ int main(int argc, char **argv)
 		auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration <double>(std::chrono::steady_clock::now() - t0).count(); };
 		uint64_t records_done = 0;
 		double next_status = 60.0 * (double) opt.status_interval;
-		batch_store batch, next_batch;
-		t_startup = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
-		uint64_t input_index = 0, batch_no = 0;
+		uint64_t input_index = 0;
 		bool eof = false;
 		bam_record scratch;
-		std::vector <uint32_t> b_src_pos, b_src_entry, b_dst_entry, b_flags, b_cigar, b_l_seq, b_mate_se, b_mate_de, b_mate_pos;
-		std::vector <uint64_t> b_cigar_off, b_seq_off, b_qual_off;
-		std::vector <uint8_t> b_seq4, b_qual;
-		std::vector <uint32_t> o_dst_pos, o_mate, o_cigar;
-		std::vector <int32_t> o_status;
-		std::vector <uint64_t> o_cigar_off, o_run_off;
-		std::vector <pvc3_run> o_runs;
 		struct slice_state		// per-thread scratch and results of one slice of a batch
 		{
 			std::string bytes, oa;
@@ -549,33 +584,79 @@ int main(int argc, char **argv)
 				dst.input_index.push_back(idx);
 			}
 		};
-		read_batch(batch);
-		while (!batch.empty())
-		{
-			std::future <void> prefetch;
-			if (!eof) prefetch = std::async(std::launch::async, [&]() { read_batch(next_batch); });
-			struct join_prefetch { std::future <void> &f; ~join_prefetch() { if (f.valid()) f.wait(); } } joiner{prefetch};
-			uint64_t const n = batch.size();
-			pvc3_context *ctx = contexts[batch_no++ % contexts.size()];
-			// The reference's periodic status line (project_alignments.cc:446-481): time spent, records processed, µs per record.
-			if (opt.status_interval > 0)
+
+		// The reader runs ahead by up to two batches; the stores it fills are handed back when their records have been rewritten.
+		// (At most two filled stores wait in the queue: a reader far ahead of the GPUs would only hold memory.)
+		std::mutex rq_mutex;
+		std::condition_variable rq_cv;
+		std::deque <std::unique_ptr <batch_store>> rq, rq_free;
+		bool rq_done = false;
+		std::exception_ptr reader_error;
+		for (std::size_t i = 0; i < 2 * opt.devices.size() + 3; ++i) rq_free.emplace_back(new batch_store);		// two per GPU in flight, two read ahead, one being read
+		std::thread reader_thread([&]() {
+			try
 			{
-				double const running = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
-				if (running >= next_status)
+				for (;;)
 				{
-					std::cerr << "Time spent processing: " << (uint64_t) running << " s; processed " << records_done << " records";
-					if (records_done) std::cerr << " (in " << (running * 1e6 / (double) records_done) << " µs / record)";
-					std::cerr << ".\n";
-					next_status = running + 60.0 * (double) opt.status_interval;
+					std::unique_ptr <batch_store> bs;
+					{
+						std::unique_lock <std::mutex> lock(rq_mutex);
+						rq_cv.wait(lock, [&]() { return rq_done || (!rq_free.empty() && rq.size() < 2); });
+						if (rq_done) return;
+						bs = std::move(rq_free.front()); rq_free.pop_front();
+					}
+					read_batch(*bs);
+					bool const last = bs->empty();
+					{
+						std::lock_guard <std::mutex> lock(rq_mutex);
+						if (!last) rq.push_back(std::move(bs));
+						if (last) rq_done = true;
+					}
+					rq_cv.notify_all();
+					if (last) return;
 				}
 			}
-			records_done += n;
-			auto t_stage = now();
+			catch (...) { reader_error = std::current_exception(); std::lock_guard <std::mutex> lock(rq_mutex); rq_done = true; rq_cv.notify_all(); }
+		});
+		struct join_reader { std::thread &t; std::mutex &m; std::condition_variable &cv; bool &done; ~join_reader() { { std::lock_guard <std::mutex> l(m); done = true; } cv.notify_all(); if (t.joinable()) t.join(); } } reader_joiner{reader_thread, rq_mutex, rq_cv, rq_done};
 
+		// ---- index, reference, GPUs (the reader is already at work) ---------------------------------------------------------------
+		prepare_devices();
+		std::vector <pvc3_context *> const &contexts = device_contexts;
+		std::size_t const n_dev = contexts.size();
+		t_startup = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+
+		// One slot per batch in flight: the records, the page-locked SoA arrays (include/pvc3.h) and the page-locked results.
+		struct slot_state
+		{
+			std::unique_ptr <batch_store> store;
+			pinned_array <uint32_t> b_src_pos, b_src_entry, b_dst_entry, b_flags, b_cigar, b_l_seq, b_mate_se, b_mate_de, b_mate_pos;
+			pinned_array <uint64_t> b_cigar_off, b_seq_off, b_qual_off;
+			pinned_array <uint8_t> b_seq4, b_qual;
+			pinned_array <uint32_t> o_dst_pos, o_mate, o_cigar;
+			pinned_array <int32_t> o_status;
+			pinned_array <uint64_t> o_cigar_off, o_run_off;
+			pinned_array <pvc3_run> o_runs;
+			uint64_t n{};
+			std::size_t device{};
+			bool in_flight{}, pipelined{};
+		};
+		std::vector <slot_state> slot_states(2 * n_dev);
+		std::vector <pvc3_pipeline *> pipelines(n_dev, nullptr);
+		struct destroy_pipelines { std::vector <pvc3_pipeline *> &v; ~destroy_pipelines() { for (auto *p : v) if (p) pvc3_pipeline_destroy(p); } } pipeline_guard{pipelines};
+		pvc3_pipeline_caps pipe_caps{};
+
+		// Batch arrays of the slot's records (the reference builds one task per record, project_alignments.cc:627, 699).
+		auto fill = [&](slot_state &sl) {
+			batch_store const &batch = *sl.store;
+			uint64_t const n = sl.n;
+			auto &b_src_pos = sl.b_src_pos; auto &b_src_entry = sl.b_src_entry; auto &b_dst_entry = sl.b_dst_entry; auto &b_flags = sl.b_flags; auto &b_cigar = sl.b_cigar;
+			auto &b_l_seq = sl.b_l_seq; auto &b_mate_se = sl.b_mate_se; auto &b_mate_de = sl.b_mate_de; auto &b_mate_pos = sl.b_mate_pos;
+			auto &b_cigar_off = sl.b_cigar_off; auto &b_seq_off = sl.b_seq_off; auto &b_qual_off = sl.b_qual_off; auto &b_seq4 = sl.b_seq4; auto &b_qual = sl.b_qual;
 			// SoA batch (include/pvc3.h): offsets first (one cheap pass), then the slices are filled by all threads.
-			b_src_pos.resize(n); b_src_entry.resize(n); b_dst_entry.resize(n); b_flags.resize(n); b_l_seq.resize(n);
-			b_mate_se.resize(n); b_mate_de.resize(n); b_mate_pos.resize(n);
-			b_cigar_off.resize(n + 1); b_seq_off.resize(n + 1); b_qual_off.resize(n + 1);
+			b_src_pos.reserve(n); b_src_entry.reserve(n); b_dst_entry.reserve(n); b_flags.reserve(n); b_l_seq.reserve(n);
+			b_mate_se.reserve(n); b_mate_de.reserve(n); b_mate_pos.reserve(n);
+			b_cigar_off.reserve(n + 1); b_seq_off.reserve(n + 1); b_qual_off.reserve(n + 1);
 			// The sizes are read out of the records by all threads (a record header is a cache miss of its own), the prefix sums
 			// are one pass over three dense arrays.
 			std::size_t const n_fill = std::min <std::size_t>(n, 4 * (std::size_t) opt.threads);
@@ -595,7 +676,7 @@ int main(int argc, char **argv)
 				b_seq_off[i + 1] += b_seq_off[i];
 				b_qual_off[i + 1] += b_qual_off[i];
 			}
-			b_cigar.resize(b_cigar_off[n]); b_seq4.resize(b_seq_off[n]); b_qual.resize(b_qual_off[n]);
+			b_cigar.reserve(b_cigar_off[n] + 64); b_seq4.reserve(b_seq_off[n] + 64); b_qual.reserve(b_qual_off[n] + 64);
 			parallel_for(n_fill, opt.threads, [&](std::size_t si) {
 				for (uint64_t i = n * si / n_fill; i < n * (si + 1) / n_fill; ++i)
 				{
@@ -621,27 +702,80 @@ int main(int argc, char **argv)
 					if (r.has_qual()) std::memcpy(b_qual.data() + b_qual_off[i], p + r.qual_offset(), r.l_seq());
 				}
 			});
+		};
+		auto batch_in_of = [&](slot_state &sl) {
 			pvc3_batch_in in{};
-			in.n = n; in.src_pos = b_src_pos.data(); in.src_entry = b_src_entry.data(); in.dst_entry = b_dst_entry.data(); in.flags = b_flags.data();
-			in.cigar_off = b_cigar_off.data(); in.cigar = b_cigar.data(); in.seq_off = b_seq_off.data(); in.l_seq = b_l_seq.data(); in.seq4 = b_seq4.data();
-			in.qual_off = b_qual_off.data(); in.qual = b_qual.data();
-			in.mate_src_entry = b_mate_se.data(); in.mate_dst_entry = b_mate_de.data(); in.mate_pos = b_mate_pos.data();
-			tm.fill += since(t_stage); t_stage = now();
-
+			in.n = sl.n; in.src_pos = sl.b_src_pos.data(); in.src_entry = sl.b_src_entry.data(); in.dst_entry = sl.b_dst_entry.data(); in.flags = sl.b_flags.data();
+			in.cigar_off = sl.b_cigar_off.data(); in.cigar = sl.b_cigar.data(); in.seq_off = sl.b_seq_off.data(); in.l_seq = sl.b_l_seq.data(); in.seq4 = sl.b_seq4.data();
+			in.qual_off = sl.b_qual_off.data(); in.qual = sl.b_qual.data();
+			in.mate_src_entry = sl.b_mate_se.data(); in.mate_dst_entry = sl.b_mate_de.data(); in.mate_pos = sl.b_mate_pos.data();
+			return in;
+		};
+		auto batch_out_of = [&](slot_state &sl) {
+			pvc3_batch_out out{};
+			out.dst_pos = sl.o_dst_pos.data(); out.mate_dst_pos = sl.o_mate.data(); out.status = sl.o_status.data();
+			out.out_cigar_off = sl.o_cigar_off.data(); out.out_cigar = sl.o_cigar.data(); out.out_cigar_cap = sl.o_cigar.cap;
+			out.run_off = sl.o_run_off.data(); out.runs = sl.o_runs.data(); out.run_cap = sl.o_runs.cap;
+			return out;
+		};
+		// The batch on its own, start to finish, with device arrays made for it: for a batch that does not fit the pipeline's
+		// capacities or whose results do not fit the arrays they were to land in.
+		auto project_alone = [&](slot_state &sl) {
+			pvc3_context *ctx = contexts[sl.device];
+			pvc3_batch_in const in = batch_in_of(sl);
 			pvc3_dbatch *db{};
 			pvc3_batch_stats stats{};
 			check(pvc3_dbatch_create(ctx, &in, &db), "pvc3_dbatch_create");
 			check(pvc3_dbatch_project(ctx, db, &params), "pvc3_dbatch_project");
 			check(pvc3_dbatch_finish(ctx, db, &stats), "pvc3_dbatch_finish");
-			o_dst_pos.resize(n); o_mate.resize(n); o_status.resize(n); o_cigar_off.resize(n + 1); o_run_off.resize(n + 1);
-			o_cigar.resize(stats.out_cigar_total + 1); o_runs.resize(stats.n_runs + 1);
-			pvc3_batch_out out{};
-			out.dst_pos = o_dst_pos.data(); out.mate_dst_pos = o_mate.data(); out.status = o_status.data();
-			out.out_cigar_off = o_cigar_off.data(); out.out_cigar = o_cigar.data(); out.out_cigar_cap = o_cigar.size();
-			out.run_off = o_run_off.data(); out.runs = o_runs.data(); out.run_cap = o_runs.size();
+			sl.o_cigar.reserve(stats.out_cigar_total + 1); sl.o_runs.reserve(stats.n_runs + 1);
+			pvc3_batch_out out = batch_out_of(sl);
 			check(pvc3_dbatch_download(ctx, db, &out), "pvc3_dbatch_download");
 			pvc3_dbatch_destroy(db);
+		};
+		auto submit = [&](slot_state &sl) {
+			uint64_t const n = sl.n;
+			pvc3_batch_in const in = batch_in_of(sl);
+			if (!pipelines[0])
+			{
+				// Capacities from the first batch, with room: twice its CIGAR operations and SEQ bytes per record.
+				pipe_caps.max_records = std::max <uint64_t>(n, opt.batch_size + 4);
+				pipe_caps.max_cigar_ops = std::max <uint64_t>(2 * in.cigar_off[n], 8 * pipe_caps.max_records) * pipe_caps.max_records / std::max <uint64_t>(n, 1) + 1024;
+				pipe_caps.max_seq_bytes = 2 * in.seq_off[n] * pipe_caps.max_records / std::max <uint64_t>(n, 1) + 4096;
+				pipe_caps.max_qual_bytes = 0;		// QUAL stays in the page-locked arrays and is fetched for the realigned records only
+				pipe_caps.depth = 2;
+				for (std::size_t d = 0; d < n_dev; ++d)
+					check(pvc3_pipeline_create(contexts[d], &pipe_caps, &pipelines[d]), "pvc3_pipeline_create");
+			}
+			sl.o_dst_pos.reserve(n); sl.o_mate.reserve(n); sl.o_status.reserve(n); sl.o_cigar_off.reserve(n + 1); sl.o_run_off.reserve(n + 1);
+			sl.o_cigar.reserve(std::max <uint64_t>(4 * in.cigar_off[n], 16 * n)); sl.o_runs.reserve(n + 1024);
+			sl.pipelined = n <= pipe_caps.max_records && in.cigar_off[n] <= pipe_caps.max_cigar_ops && in.seq_off[n] <= pipe_caps.max_seq_bytes;
+			if (sl.pipelined)
+			{
+				pvc3_batch_out const out = batch_out_of(sl);
+				check(pvc3_pipeline_submit(pipelines[sl.device], &in, &out, &params), "pvc3_pipeline_submit");
+			}
+			sl.in_flight = true;
+		};
+
+		// Results of the slot's batch (waits for them), its records rewritten, the bytes on their way to the file.
+		auto retire = [&](slot_state &sl) {
+			auto t_stage = now();
+			if (sl.pipelined)
+			{
+				pvc3_batch_stats stats{};
+				int const rc = pvc3_pipeline_wait(pipelines[sl.device], &stats);
+				if (PVC3_E_CAPACITY == rc) project_alone(sl);		// more operations or runs than the arrays were sized for
+				else check(rc, "pvc3_pipeline_wait");
+			}
+			else
+				project_alone(sl);
+			sl.in_flight = false;
 			tm.gpu += since(t_stage); t_stage = now();
+			batch_store const &batch = *sl.store;
+			uint64_t const n = sl.n;
+			auto const &o_dst_pos = sl.o_dst_pos; auto const &o_mate = sl.o_mate; auto const &o_cigar = sl.o_cigar; auto const &o_status = sl.o_status;
+			auto const &o_cigar_off = sl.o_cigar_off; auto const &o_run_off = sl.o_run_off; auto const &o_runs = sl.o_runs;
 
 			// Rewrite the records: contiguous slices of the batch on separate threads, each into its own byte string; the strings
 			// are written in slice order, so the output does not depend on the number of threads.
@@ -805,16 +939,61 @@ int main(int argc, char **argv)
 				wq.push_back(std::move(job));
 			}
 			wq_cv.notify_all();
-			tm.wait_write += since(t_stage); t_stage = now();
-			if (prefetch.valid())
+			tm.wait_write += since(t_stage);
+			// the store goes back to the reader
+			sl.store->clear();
 			{
-				prefetch.get();		// rethrows what the reader threw
-				tm.wait_read += since(t_stage);
-				batch.swap(next_batch);
+				std::lock_guard <std::mutex> lock(rq_mutex);
+				rq_free.push_back(std::move(sl.store));
 			}
-			else
-				batch.clear();
+			rq_cv.notify_all();
+		};
+
+		uint64_t batch_no = 0;
+		for (;; ++batch_no)
+		{
+			auto t_stage = now();
+			std::unique_ptr <batch_store> bs;
+			{
+				std::unique_lock <std::mutex> lock(rq_mutex);
+				rq_cv.wait(lock, [&]() { return rq_done || !rq.empty(); });
+				if (!rq.empty()) { bs = std::move(rq.front()); rq.pop_front(); }
+			}
+			rq_cv.notify_all();		// room in the queue: the reader may go on
+			if (reader_error) std::rethrow_exception(reader_error);
+			tm.wait_read += since(t_stage);
+			if (!bs) break;
+			slot_state &sl = slot_states[batch_no % slot_states.size()];
+			if (sl.in_flight) retire(sl);		// batch_no - 2 x GPUs: the same GPU's older batch
+			// The reference's periodic status line (project_alignments.cc:446-481): time spent, records processed, µs per record.
+			if (opt.status_interval > 0)
+			{
+				double const running = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+				if (running >= next_status)
+				{
+					std::cerr << "Time spent processing: " << (uint64_t) running << " s; processed " << records_done << " records";
+					if (records_done) std::cerr << " (in " << (running * 1e6 / (double) records_done) << " µs / record)";
+					std::cerr << ".\n";
+					next_status = running + 60.0 * (double) opt.status_interval;
+				}
+			}
+			sl.store = std::move(bs);
+			sl.n = sl.store->size();
+			sl.device = batch_no % n_dev;
+			records_done += sl.n;
+			t_stage = now();
+			fill(sl);
+			tm.fill += since(t_stage); t_stage = now();
+			submit(sl);
+			tm.gpu += since(t_stage);
 		}
+		// what is still in flight, oldest first
+		for (uint64_t k = (batch_no > slot_states.size()) ? (batch_no - slot_states.size()) : 0; k < batch_no; ++k)
+		{
+			slot_state &sl = slot_states[k % slot_states.size()];
+			if (sl.in_flight) retire(sl);
+		}
+		for (auto *&pl : pipelines) if (pl) { pvc3_pipeline_destroy(pl); pl = nullptr; }
 		{
 			std::lock_guard <std::mutex> lock(wq_mutex);
 			wq_done = true;

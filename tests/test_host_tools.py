@@ -27,7 +27,7 @@ def tools():
 
 
 def _run(cmd, cwd=None, check=True, env=None):
-	p = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=None if env is None else dict(os.environ, **env))
+	p = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=None if env is None else dict(os.environ, **env), timeout=600)		# (a tool that hangs must fail the test, not the run)
 	if check and p.returncode != 0:
 		raise AssertionError("%s failed (%d): %s" % (cmd[0], p.returncode, p.stderr.decode()[-2000:]))
 	return p

@@ -88,7 +88,7 @@ def main():
 
 	def run(cmd):
 		t = time.perf_counter()
-		p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+		p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
 		if p.returncode:
 			sys.stderr.write(p.stderr.decode())
 			raise SystemExit("command failed: " + " ".join(cmd))

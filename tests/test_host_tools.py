@@ -333,6 +333,13 @@ def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_m
 	assert open(tmp_path / "ranges.tsv").read() == "Location\tLength\n" + "".join("%d\t%d\n" % r for r in ranges)
 	assert b"Matched reads:" in p.stderr
 
+	# Several GPUs (here: the one GPU twice, each with a context, an index replica and a pipeline of its own), batches of 64
+	# records going to them in turn and coming back in input order; and one thread instead of the default.
+	for extra in (["--devices=0,0", "--batch-size=64"], ["--devices=0,0,0", "--batch-size=100", "--threads=3"], ["--threads=1"]):
+		pd = _run(cmd + extra, cwd=tmp_path)
+		assert [l for l in pd.stdout.decode().split("\n") if l and not l.startswith("@")] == expect, extra
+		assert open(tmp_path / "ranges.tsv").read() == "Location\tLength\n" + "".join("%d\t%d\n" % r for r in ranges)
+
 	# A BGZF-compressed multi-contig FASTA with its .gzi and .fai (what the reference requires: compressed_fasta_reader.cc:163-248):
 	# only the destination contig is read, through the indexes; the output does not change.  Also the uncompressed file + .fai.
 	decoy = "".join("ACGT"[x] for x in np.random.default_rng(1).integers(0, 4, size=30011))

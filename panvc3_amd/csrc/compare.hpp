@@ -19,6 +19,33 @@ __device__ __forceinline__ u64x2 load_u128_unaligned(uint8_t const *p)
 	return v;
 }
 
+// A load from global memory through a pointer whose address space the compiler cannot see (it came out of a structure in
+// memory): as a flat load it would also count against the LDS counter and wait with the LDS traffic around it.
+template <typename t_value>
+__device__ __forceinline__ t_value global_load(t_value const *p)
+{
+	typedef t_value __attribute__((address_space(1))) const *gptr;
+	return *(gptr) (uintptr_t) p;
+}
+
+// 40 consecutive bytes from any address in global memory as five 64-bit words, fetched as 44 bytes from the dword-aligned
+// address below it and shifted into place.  A 16-byte load from an address that is not a multiple of four costs the texture
+// addresser three to four times as much (tools/calib/ta_cost.hip: 258 against 71 cycles with one line per lane).  Reads up
+// to 3 bytes before p and 4 after p + 40: the buffers this is used on are padded.
+__device__ __forceinline__ void load_bytes40(uint8_t const *p, uint64_t (&w)[5])
+{
+	typedef uint32_t __attribute__((address_space(1))) const *gptr;
+	uintptr_t const a = (uintptr_t) p;
+	gptr const q = (gptr) (a & ~(uintptr_t) 3);
+	uint32_t const sh = 8 * (uint32_t) (a & 3);
+	uint32_t d[11];
+#pragma unroll
+	for (uint32_t i = 0; i < 11; ++i) d[i] = q[i];
+#pragma unroll
+	for (uint32_t k = 0; k < 5; ++k)
+		w[k] = (uint64_t) __builtin_amdgcn_alignbit(d[2 * k + 1], d[2 * k], sh) | ((uint64_t) __builtin_amdgcn_alignbit(d[2 * k + 2], d[2 * k + 1], sh) << 32);
+}
+
 // Packed BAM bases (high nibble first) -> nibble-linear: nibble n of the byte string at bits [4n, 4n + 4).
 __device__ __forceinline__ uint64_t nibble_linear(uint64_t w)
 {

@@ -12,7 +12,7 @@ import csv, glob, collections, re, sys
 f = glob.glob("gpurun_out/%s/**/*_counter_collection.csv" % sys.argv[1], recursive=True)[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-	m = re.search(r"(k_\w+)\(", r["Kernel_Name"])
+	m = re.search(r"(k_\w+)(?:<[^>]*>)?\(", r["Kernel_Name"])
 	if m:
 		acc[(m.group(1), r["Counter_Name"])].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):

@@ -18,7 +18,7 @@ import sys
 
 
 def short(name):
-	m = re.search(r"(k_\w+)\(", name)
+	m = re.search(r"(k_\w+)(?:<[^>]*>)?\(", name)		# (k_project_fast is a template: "k_project_fast<false>(...)")
 	return m.group(1) if m else name.split("(")[0]
 
 

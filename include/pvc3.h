@@ -190,10 +190,18 @@ PVC3_API int pvc3_context_synchronize(pvc3_context *ctx);
  * alignment scratch slots together never exceed it), "trace_initial" (32-bit words of the alignment trace buffer), "arena_initial", "runs_initial",
  * "fast_path" (0: no lane-parallel compare in k_project_fast), "mid_path" (0: skip k_project_mid; with both at 0 every
  * record goes through the cooperative column walk of k_project_general), "packed_dp" (0: every indel run is aligned by the
- * striped one-run-per-wavefront kernel instead of the packed kernels); and two that take effect at the next
- * pvc3_context_upload_index: "paired_blocks" (1: every entry's bit-vector blocks are also stored side by side with those of
- * the entry it is projected to, one 128-byte HBM line for both rows), "text_window" (1: the packed reference texts are
- * also stored as overlapping 128-byte lines, one line per read of up to 150 bases); both default to 1 and cost HBM only. */
+ * striped one-run-per-wavefront kernel instead of the packed kernels); and those that take effect at the next
+ * pvc3_context_upload_index and cost HBM only:
+ * "position_windows" (default 1): for every entry and the entry it is projected to, one 128- or 256-byte line per 64 or 128
+ *   source positions that holds what a record starting there needs of the index — start column, projected position, the
+ *   number of columns without a gap in either row, the destination text of those columns.  Two bytes per source position of
+ *   every entry; left out (and the look-ups done through the select samples and paired blocks alone) when they would not
+ *   leave "window_reserve" bytes (default 24 GiB) of the device free.
+ * "window_read_length" (default 150): the read length the windows are sized for — up to 158 bases 128-byte windows, beyond
+ *   that 256-byte windows (reads of up to 255 bases are then compared from their window; longer ones are walked).
+ * "paired_blocks" (default 1): every entry's bit-vector blocks also stored side by side with those of the entry it is
+ *   projected to, one 128-byte HBM line for both rows (what the walk kernels read).
+ * "text_window" (default 1): without position windows, the packed reference texts also stored as overlapping 128-byte lines. */
 PVC3_API int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value);
 /* Replicates the index (bit-vector blocks, select samples, reference texts, and the two copies above) into this context's HBM. */
 PVC3_API int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx);

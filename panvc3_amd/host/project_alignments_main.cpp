@@ -441,16 +441,6 @@ int main(int argc, char **argv)
 				}
 			}
 			device_contexts = contexts_coming.get();
-			// The index is replicated on every GPU, all of them at the same time.
-			{
-				std::vector <std::future <int>> uploads;
-				std::vector <std::string> errors(device_contexts.size());
-				for (std::size_t d = 0; d < device_contexts.size(); ++d)
-					uploads.push_back(std::async(std::launch::async, [&, d]() { int const rc = pvc3_context_upload_index(device_contexts[d], index); if (rc) errors[d] = pvc3_last_error(); return rc; }));
-				for (std::size_t d = 0; d < uploads.size(); ++d)
-					if (uploads[d].get()) die("pvc3_context_upload_index: " + errors[d]);
-			}
-
 		};
 
 		alignment_writer writer;
@@ -622,6 +612,30 @@ int main(int argc, char **argv)
 
 		// ---- index, reference, GPUs (the reader is already at work) ---------------------------------------------------------------
 		prepare_devices();
+		{
+			// The position windows of the index replicas are sized for the reads: the longest of the first batch (which the
+			// reader has had the whole start-up for) decides between 128- and 256-byte windows.
+			uint32_t longest = 0;
+			{
+				std::unique_lock <std::mutex> lock(rq_mutex);
+				rq_cv.wait(lock, [&]() { return rq_done || !rq.empty(); });
+				if (!rq.empty())
+					for (std::size_t i = 0; i < rq.front()->size(); ++i) longest = std::max(longest, (*rq.front())[i].l_seq());
+			}
+			if (reader_error) std::rethrow_exception(reader_error);
+			if (longest)
+				for (pvc3_context *ctx : device_contexts) check(pvc3_context_set_option(ctx, "window_read_length", longest), "pvc3_context_set_option");
+		}
+		// The index is replicated on every GPU, all of them at the same time.
+		{
+			std::vector <std::future <int>> uploads;
+			std::vector <std::string> errors(device_contexts.size());
+			for (std::size_t d = 0; d < device_contexts.size(); ++d)
+				uploads.push_back(std::async(std::launch::async, [&, d]() { int const rc = pvc3_context_upload_index(device_contexts[d], index); if (rc) errors[d] = pvc3_last_error(); return rc; }));
+			for (std::size_t d = 0; d < uploads.size(); ++d)
+				if (uploads[d].get()) die("pvc3_context_upload_index: " + errors[d]);
+		}
+
 		std::vector <pvc3_context *> const &contexts = device_contexts;
 		std::size_t const n_dev = contexts.size();
 		t_startup = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();

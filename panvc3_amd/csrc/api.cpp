@@ -673,7 +673,7 @@ int dbatch_alloc(pvc3_context *ctx, batch_caps const &caps, pvc3_dbatch **out)
 	if (caps.qual)
 	{
 		PVC3_TRY(in_alloc(&b->up_qual_off, n + 1, 0));
-		PVC3_TRY(in_alloc(&b->up_qual, caps.qual, 16));
+		PVC3_TRY(in_alloc(&b->up_qual, caps.qual, 64));		// padded: the alignment kernels read 8-byte pieces
 	}
 	if (caps.mates)
 	{
@@ -708,7 +708,7 @@ int dbatch_alloc(pvc3_context *ctx, batch_caps const &caps, pvc3_dbatch **out)
 	if (caps.qual_compact)
 	{
 		PVC3_TRY(dev_alloc(&w.qual_off_dev, n, &b->allocs, &b->bytes));
-		PVC3_TRY(dev_alloc(&w.qual_compact, caps.qual_compact, nullptr, &b->bytes));
+		PVC3_TRY(dev_alloc(&w.qual_compact, caps.qual_compact + 64, nullptr, &b->bytes));		// (+ 64: the alignment kernels read 8-byte pieces)
 		w.qual_compact_cap = caps.qual_compact;
 	}
 
@@ -781,7 +781,7 @@ int dbatch_load(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_in const *in, hipS
 	else if (has_qual)
 	{
 		PVC3_TRY(put(b->up_qual_off, in->qual_off, n + 1, 0));
-		PVC3_TRY(put(b->up_qual, in->qual, n_qual, 16));
+		PVC3_TRY(put(b->up_qual, in->qual, n_qual, 64));
 		d.qual = b->up_qual; d.qual_off = b->up_qual_off;
 	}
 	d.mate_src_entry = nullptr; d.mate_dst_entry = nullptr; d.mate_pos = nullptr;
@@ -898,7 +898,7 @@ int dbatch_complete(pvc3_context *ctx, pvc3_dbatch *b, bool already_waited = fal
 			b->bytes -= b->work.qual_compact_cap;
 			b->work.qual_compact = nullptr;
 			uint64_t const cap = 2 * (uint64_t) c.qual_head + 4096;
-			PVC3_TRY(dev_alloc(&b->work.qual_compact, cap, nullptr, &b->bytes));
+			PVC3_TRY(dev_alloc(&b->work.qual_compact, cap + 64, nullptr, &b->bytes));
 			b->work.qual_compact_cap = cap;
 			b->in.qual = b->work.qual_compact;
 		}

@@ -560,7 +560,14 @@ __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_pa
 		double own_m = gap(l + 1), own_b = neg_inf;		// M and the along-the-line gap score of the cell before the first one
 		double diag = gap(l);
 		double cur_m = 0.0, cur_a = neg_inf;			// what the next lane receives: this line's M and its across-the-lines gap score
-		double bnd = 0.0;								// lane 0: gap(t + 1) while stepping
+		// Lane 0 of a run receives the boundary from "above": M = gap(t + 1), gap score -inf.  Both arrive as ADDENDS that are
+		// 0.0 in every other lane (what a lane receives from its neighbour plus 0.0 is the same number, up to the sign of a
+		// zero, which no comparison and no later sum can tell): two adds per step instead of four selects.
+		double const bnd_step_l = (0 == l) ? bnd_step : 0.0, ninf_l = (0 == l) ? neg_inf : 0.0;
+		double bnd = go - bnd_step;						// (width 16: the value DPP feeds lane 0 of each row with) gap(t + 1) = go + t * bnd_step, small integers: exact
+		double bnd_l = (0 == l) ? (go - bnd_step) : 0.0;
+		// Lanes along the query compare every item with the same base at the same quality: their two scores stay in registers.
+		double const own_s_match = S.score[own_q][0], own_s_mismatch = S.score[own_q][1];
 		uint32_t acc = 0;
 		// Lane l uses item t - l in step t; the 64 entries in front of the stream make the index non-negative (whatever they
 		// hold is read by lanes that are not active yet).
@@ -569,14 +576,22 @@ __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_pa
 		for (uint32_t t = 0; t < steps; ++t)
 		{
 			double nb_m, nb_a;
-			bnd = (0 == t) ? go : bnd + bnd_step;
 			if constexpr (16 == t_width)
 			{
+				bnd += bnd_step;
 				nb_m = row_shr1_f64(cur_m, bnd);
 				nb_a = row_shr1_f64(cur_a, neg_inf);
 			}
+			else if constexpr (64 == t_width)
+			{
+				bnd_l += bnd_step_l;
+				nb_m = shfl_up_f64_zero(cur_m) + bnd_l;		// (lane 0 of the wave receives 0.0 from the shift)
+				nb_a = shfl_up_f64_zero(cur_a) + ninf_l;
+			}
 			else
 			{
+				// (two runs per wave: lane 32 receives lane 31's values from the shift and has to replace them)
+				bnd += bnd_step;
 				nb_m = shfl_up_f64_zero(cur_m);
 				nb_a = shfl_up_f64_zero(cur_a);
 				if (0 == l) { nb_m = bnd; nb_a = neg_inf; }
@@ -589,8 +604,9 @@ __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_pa
 			if (active)
 			{
 				bool const is_match = (item & 7) == own_rank;
-				uint32_t const qi = t_ref_lanes ? (item >> 8) : own_q;
-				double const s = S.score[qi][is_match ? 0 : 1];
+				double s;
+				if constexpr (t_ref_lanes) s = S.score[item >> 8][is_match ? 0 : 1];
+				else s = is_match ? own_s_match : own_s_mismatch;
 				// The larger value wins and ties keep the extension: max() gives the value (equal operands are the same number, no
 				// NaN can arise from finite scores and -inf), the comparison only feeds the trace bit.
 				double const a_open = nb_m + go, a_ext = nb_a + ge;

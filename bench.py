@@ -187,12 +187,14 @@ def main():
 	for kv in args.option:
 		k, v = kv.split("=", 1)
 		ctx.set_option(k, int(v))
+	t_up = time.time()
 	ctx.upload_index(index)
+	t_up = time.time() - t_up
 	ctx.set_timing(True)
 	t2 = time.time()
 	db = panvc3_amd.DeviceBatch(ctx, batch)
 	index_bytes, _ = ctx.hbm_bytes()
-	log("index %.2f GB in HBM; batch uploaded in %.1f s" % (index_bytes / 1e9, time.time() - t2))
+	log("index %.2f GB in HBM (replicated with its paired blocks and position windows in %.2f s); batch uploaded in %.1f s" % (index_bytes / 1e9, t_up, time.time() - t2))
 	params = panvc3_amd.api.make_params(0, -1, args.score_mode)
 	if world > 1:
 		# The host copies are only needed by the single-GPU legs (CPU baseline, host-buffer entry points): with one rank per

@@ -565,13 +565,32 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 			}
 			if (best < idx->entries.size())
 			{
-				host_entry const &o = idx->entries[best];
-				std::vector <uint64_t> both;
-				build_paired_blocks(e, o, both);
-				PVC3_TRY(dev_upload(&d.paired, both.data(), both.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
-				HIP_TRY(hipStreamSynchronize(ctx->stream));		// `both` is pageable and leaves scope
 				d.partner = (uint32_t) best;
+				if (PAIRED_STEP != BLOCK_COLS)
+				{
+					// (overlapping paired blocks, an experiment: built on the host)
+					host_entry const &o = idx->entries[best];
+					std::vector <uint64_t> both;
+					build_paired_blocks(e, o, both);
+					PVC3_TRY(dev_upload(&d.paired, both.data(), both.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
+					HIP_TRY(hipStreamSynchronize(ctx->stream));		// `both` is pageable and leaves scope
+				}
 			}
+		}
+	}
+	if (ctx->paired_blocks && PAIRED_STEP == BLOCK_COLS)
+	{
+		// The paired copies, interleaved on the device from the blocks uploaded above.
+		for (size_t i = 0; i < idx->entries.size(); ++i)
+		{
+			if (NO_PARTNER == table[i].partner) continue;
+			host_entry const &e = idx->entries[i], &o = idx->entries[table[i].partner];
+			uint64_t const n_paired = e.n_cols / PAIRED_STEP + 1 + PAD_BLOCKS, n_have = e.n_blocks + PAD_BLOCKS;
+			uint64_t *both{};
+			PVC3_TRY(dev_alloc(&both, n_paired * 2 * BLOCK_WORDS, &ctx->index_allocs, &ctx->index_bytes));
+			if (int const rc = launch_pair_blocks(table[i].blocks, table[table[i].partner].blocks, n_have, n_paired, e.n_zeros, o.n_zeros, both, ctx->stream))
+				return set_error(PVC3_E_HIP, "k_pair_blocks launch: %s", hipGetErrorString((hipError_t) rc));
+			table[i].paired = both;
 		}
 	}
 	if (windows)

@@ -353,6 +353,22 @@ __global__ __launch_bounds__(256) void k_window_text4(uint8_t const *__restrict_
 	}
 }
 
+// dev_entry::paired when the paired blocks start where the plain ones do (PAIRED_STEP == BLOCK_COLS): block b of the copy is
+// block b of either row, side by side — an interleave of what is already on the device (the host build of round 2 took
+// 1.3 s per context on C3).  Blocks past a row's own (the copy has up to one more) are all-gap with the row's total as rank.
+__global__ __launch_bounds__(256) void k_pair_blocks(uint64_t const *__restrict__ a, uint64_t const *__restrict__ b, uint64_t n_have, uint64_t n_paired, uint64_t zeros_a, uint64_t zeros_b, uint64_t *__restrict__ out)
+{
+	uint64_t const stride = (uint64_t) gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_paired * 2 * BLOCK_WORDS; i += stride)
+	{
+		uint64_t const blk = i / (2 * BLOCK_WORDS), r = (i / BLOCK_WORDS) & 1, w = i % BLOCK_WORDS;
+		uint64_t v;
+		if (blk < n_have) v = (r ? b : a)[blk * BLOCK_WORDS + w];
+		else v = (0 == w) ? (r ? zeros_b : zeros_a) : ~UINT64_C(0);
+		out[i] = v;
+	}
+}
+
 // ---- position windows (dev_entry::pwin) ---------------------------------------------------------------------------------------
 // Headers: one thread per window.  c0 = select0(P + 1) of the source row from the select samples, r0 = rank0 of the
 // destination row there, clean = the columns from c0 on without a gap in either row (the padding past the last column is
@@ -476,6 +492,12 @@ int launch_window_text4(uint8_t const *text4, uint64_t n_lines, uint8_t *out, vo
 {
 	if (n_lines)
 		hipLaunchKernelGGL(k_window_text4, dim3(grid_for(8 * n_lines, 256, 256 * 32)), dim3(256), 0, (hipStream_t) stream, text4, n_lines, out);
+	return (int) hipGetLastError();
+}
+
+int launch_pair_blocks(uint64_t const *a, uint64_t const *b, uint64_t n_have, uint64_t n_paired, uint64_t zeros_a, uint64_t zeros_b, uint64_t *out, void *stream)
+{
+	hipLaunchKernelGGL(k_pair_blocks, dim3(grid_for(n_paired * 2 * BLOCK_WORDS, 256, 256 * 32)), dim3(256), 0, (hipStream_t) stream, a, b, n_have, n_paired, zeros_a, zeros_b, out);
 	return (int) hipGetLastError();
 }
 

@@ -275,6 +275,7 @@ int launch_pack(uint64_t n, dev_batch_work const &work, dev_batch_packed const &
 int launch_checksum(uint64_t n, uint64_t first_record, dev_batch_work const &work, dev_batch_packed const &packed, unsigned long long *out, void *stream);
 int launch_pack_text4(uint8_t const *text, uint64_t len, uint8_t *out, void *stream);
 int launch_window_text4(uint8_t const *text4, uint64_t n_lines, uint8_t *out, void *stream);	// out[128 k + j] = text4[TEXT_WINDOW_STEP / 2 * k + j]
+int launch_pair_blocks(uint64_t const *a, uint64_t const *b, uint64_t n_have, uint64_t n_paired, uint64_t zeros_a, uint64_t zeros_b, uint64_t *out, void *stream);
 int launch_build_pwin(dev_entry const &src, dev_entry const &dst, uint32_t shift, uint64_t n_windows, uint8_t *out, void *stream);	// dev_entry::pwin of `src` towards `dst`
 int launch_project_probes(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, void *stream);	// k_project_fast's predecessor, for an index without position windows
 int launch_project_positions(dev_entry const *entries, uint32_t n_entries, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out, void *stream);

@@ -442,6 +442,25 @@ def test_select_guess_on_uneven_gap_density(pvc3, oracle_mod):
 		ctx.close()
 
 
+def test_position_windows_left_out_when_they_do_not_fit(pvc3, oracle_mod, synth):
+	"""pvc3_context_upload_index builds the position windows only if they leave `window_reserve` bytes of the device free; an
+	index without them is served by k_project_fast_probes with the same results (and less HBM)."""
+	gp, rp, _ = synth.config("C3", scale=0.004)
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	batch = reads.batch()
+	sizes = {}
+	for name, reserve in (("with", None), ("without", 1 << 50)):
+		ctx = pvc3.Context(0)
+		if reserve is not None: ctx.set_option("window_reserve", reserve)		# more than any device has
+		got, stats, ctx, o = _run_both(pvc3, oracle_mod, genome, batch, ctx=ctx)
+		assert stats["n_failed"] == 0
+		sizes[name] = ctx.hbm_bytes()[0]
+		ctx.close()
+	if "default" == pvc3.paths_mode:
+		assert sizes["with"] > sizes["without"] + 2 * 0.9 * sum(genome.entry(e)[2].size for e in range(genome.n_entries))		# two bytes per source position
+
+
 def test_plain_index_layout_matches_oracle(pvc3, oracle_mod, synth):
 	"""The same workloads without the position windows, the paired blocks and the windowed text (options at upload): the plain
 	64-byte blocks and the plain packed text are then what k_project_fast_probes and k_project_mid read."""

@@ -442,6 +442,54 @@ def test_select_guess_on_uneven_gap_density(pvc3, oracle_mod):
 		ctx.close()
 
 
+def test_many_entries_and_long_cigars(pvc3, oracle_mod):
+	"""What k_project_fast keeps in LDS has a size: the first 256 entries of the table (others are read from global memory and
+	handed over through LDS, their records left to k_project_mid) and the 256 CIGAR operations that follow the previous
+	group's (a group with more fetches the rest itself).  170 MSAs of two rows each = 340 entries; records on all of them,
+	with mates across the 256 boundary, plain CIGARs and CIGARs of nine and of seventy operations."""
+	rng = np.random.default_rng(11)
+	n_msa = 170
+	pairs, texts = [], []
+	for k in range(n_msa):
+		L = 400 + 3 * k
+		ref = "".join("ACGT"[x] for x in rng.integers(0, 4, size=L))
+		gaps_s = np.zeros(L, dtype=bool); gaps_d = np.zeros(L, dtype=bool)
+		if k % 3: gaps_s[100 + k:105 + k] = True			# a deletion of the founder ...
+		if k % 2: gaps_d[250:253] = True					# ... and an insertion of it (gap in the reference row)
+		src = "".join("-" if g else c for c, g in zip(ref, gaps_s))
+		dst = "".join("-" if g else c for c, g in zip(ref, gaps_d))
+		pairs.append((src, dst, dst.replace("-", "")))
+		texts.append(src.replace("-", ""))
+	ctx, o, ids = _edge_index(pvc3, oracle_mod, pairs)
+	assert max(max(p) for p in ids) == 2 * n_msa - 1
+	bb = BatchBuilder()
+	for rep in range(3):
+		for k in range(n_msa):
+			s, d = ids[k]
+			t = texts[k]
+			p0 = int(rng.integers(0, len(t) - 160))
+			L = int(rng.integers(80, 151))
+			q = list(t[p0:p0 + L])
+			for x in rng.integers(0, L, size=2): q[x] = "ACGT"[int(rng.integers(0, 4))]
+			ko = (k + 97) % n_msa							# the mate lies on another MSA, often across the 256-entry boundary
+			mate = (ids[ko][0], ids[ko][1], int(rng.integers(0, len(texts[ko]) - 1)))
+			kind = (k + rep) % 3
+			if 0 == kind:
+				bb.add(p0, s, d, "%dM" % L, "".join(q), qual=[30] * L, mate=mate)
+			elif 1 == kind:		# nine operations
+				cig = "3S" + "".join("%d%s" % (c, op) for c, op in zip([L // 4, 1, L // 4, 1, L // 4, 2, L - 3 * (L // 4) - 4], "M=XM=M=")) + "2S"
+				assert sum(int(x) for x in __import__("re").findall(r"(\d+)[M=X]", cig)) == L
+				bb.add(p0, s, d, cig, "AAA" + "".join(q) + "CC", qual=[20] * (L + 5), mate=mate)
+			else:				# seventy operations: 1M 1= 1X ... (every group of 64 such records has far more than 256)
+				ops = "".join("1%s" % "M=X"[i % 3] for i in range(70))
+				bb.add(p0, s, d, ops, "".join(q[:70]), qual=[40] * 70, mate=mate)
+	batch = bb.build()
+	got, stats = pvc3.project_batch(ctx, batch)
+	assert_results_equal(batch, got, o.batch_project(batch))
+	assert stats["n_failed"] == 0
+	ctx.close()
+
+
 def test_position_windows_left_out_when_they_do_not_fit(pvc3, oracle_mod, synth):
 	"""pvc3_context_upload_index builds the position windows only if they leave `window_reserve` bytes of the device free; an
 	index without them is served by k_project_fast_probes with the same results (and less HBM)."""

@@ -442,6 +442,55 @@ def test_select_guess_on_uneven_gap_density(pvc3, oracle_mod):
 		ctx.close()
 
 
+@pytest.mark.parametrize("window_read_length", [150, 250])
+def test_every_start_position_against_window_boundaries(pvc3, oracle_mod, window_read_length):
+	"""Position windows: a record is served from the window of its start position if the columns from the window's first to
+	the record's last are free of gaps in both rows, and from the window's last clean column otherwise.  Records of many
+	lengths (one base ... the longest the compare takes, across the 16-byte pieces of its loads) from EVERY source position of
+	an MSA with single gap columns and short gap runs in either row, with leading soft clips of both parities (the compare is
+	anchored at a byte boundary of SEQ) and mates on every position."""
+	rng = np.random.default_rng(77)
+	n_cols = 2600
+	ref = "".join("ACGT"[x] for x in rng.integers(0, 4, size=n_cols))
+	gs = np.zeros(n_cols, dtype=bool); gd = np.zeros(n_cols, dtype=bool)
+	for c in (70, 71, 133, 190, 191, 192, 260, 321, 500, 511, 512, 513, 700, 1023, 1024, 1500, 1501, 2000, 2047, 2048, 2300):
+		gs[c] = True
+	for c in (64, 129, 130, 255, 256, 400, 640, 641, 642, 643, 900, 1100, 1536, 1537, 1900, 2200, 2201, 2500):
+		gd[c] = True
+	gd &= ~gs		# (a column that is a gap in both rows is no column of either sequence)
+	src = "".join("-" if g else c for c, g in zip(ref, gs))
+	dst = "".join("-" if g else c for c, g in zip(ref, gd))
+	idx, o = pvc3.Index(), oracle_mod.Oracle()
+	s_id, d_id = idx.add_aligned(src), idx.add_aligned(dst)
+	assert (o.add_aligned(src), o.add_aligned(dst)) == (s_id, d_id)
+	idx.set_reference(d_id, dst.replace("-", "")); o.set_reference(d_id, dst.replace("-", ""))
+	ctx = pvc3.Context(0)
+	ctx.set_option("window_read_length", window_read_length)
+	ctx.upload_index(idx)
+	text = src.replace("-", "")
+	lengths = [1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 150, 151, 157, 158, 159, 160, 200, 249, 250, 251, 254, 255, 256, 300]
+	bb = BatchBuilder()
+	k = 0
+	for p0 in range(len(text)):
+		for rep in range(2):
+			L = lengths[k % len(lengths)]; k += 1
+			if p0 + L > len(text): L = len(text) - p0
+			q = list(text[p0:p0 + L])
+			if L > 4 and k % 3 == 0: q[L // 2] = "ACGT"[(("ACGT".index(q[L // 2])) + 1) % 4]		# one substitution
+			lead = k % 4				# 0 .. 3 soft-clipped bases in front: both parities of the SEQ offset
+			trail = (k // 4) % 3
+			cig = ("%dS" % lead if lead else "") + "%dM" % L + ("%dS" % trail if trail else "")
+			mate = (s_id, d_id, (p0 * 7 + rep) % len(text))
+			bb.add(p0, s_id, d_id, cig, "T" * lead + "".join(q) + "G" * trail, qual=[30] * (lead + L + trail), mate=mate)
+	batch = bb.build()
+	got, stats = pvc3.project_batch(ctx, batch)
+	assert_results_equal(batch, got, o.batch_project(batch, n_threads=8))
+	assert stats["n_failed"] == 0
+	if "default" == pvc3.paths_mode:
+		assert stats["n_fast_path"] > 0.15 * batch["src_pos"].size		# (a gap column every hundred columns or so: most longer records meet one)
+	ctx.close()
+
+
 def test_many_entries_and_long_cigars(pvc3, oracle_mod):
 	"""What k_project_fast keeps in LDS has a size: the first 256 entries of the table (others are read from global memory and
 	handed over through LDS, their records left to k_project_mid) and the 256 CIGAR operations that follow the previous

@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 
+#include "fast_crc32.hpp"
 #include "fast_deflate.hpp"
 
 namespace pvc3host {
@@ -240,7 +241,7 @@ class byte_reader
 				int const rc = inflate(&zs, Z_FINISH);
 				inflateEnd(&zs);
 				if (Z_STREAM_END != rc || zs.total_out != b.out_len) throw io_error("corrupt BGZF block");
-				if ((uint32_t) crc32(crc32(0L, Z_NULL, 0), dbuf + b.out_off, (uInt) b.out_len) != b.crc) throw io_error("BGZF block checksum mismatch");
+				if (fast_crc32(0, dbuf + b.out_off, b.out_len) != b.crc) throw io_error("BGZF block checksum mismatch");
 			});
 			std::memmove(m_cbuf.data(), m_cbuf.data() + off, m_clen - off);
 			m_clen -= off;
@@ -479,7 +480,7 @@ class byte_writer
 		static uint8_t const head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
 		std::memcpy(out.data(), head, 16);
 		out[16] = (uint8_t) ((bsize - 1) & 0xff); out[17] = (uint8_t) ((bsize - 1) >> 8);
-		uint32_t const crc = (uint32_t) crc32(crc32(0L, Z_NULL, 0), src, (uInt) len);
+		uint32_t const crc = fast_crc32(0, src, len);
 		uint32_t const isize = (uint32_t) len;
 		std::memcpy(out.data() + 18 + clen, &crc, 4);
 		std::memcpy(out.data() + 18 + clen + 4, &isize, 4);

@@ -80,3 +80,8 @@ def test_writer_reports_a_failed_close(tool):
 		pytest.skip("no /dev/full")
 	out = subprocess.run([tool, "full-device"], capture_output=True, text=True)
 	assert out.returncode == 3, (out.returncode, out.stderr)
+
+
+def test_fast_crc32_equals_zlib(tool):
+	out = subprocess.run([os.path.join(ROOT, "bin", "test_crc32_test")], capture_output=True, text=True)
+	assert out.returncode == 0, out.stdout

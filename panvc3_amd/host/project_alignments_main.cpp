@@ -1016,8 +1016,7 @@ int main(int argc, char **argv)
 		writer_thread.join();
 		if (writer_error) std::rethrow_exception(writer_error);
 		writer.close();
-		for (pvc3_context *ctx : contexts) pvc3_context_destroy(ctx);
-		pvc3_index_destroy(index);
+		(void) contexts; (void) index;		// not taken down one by one: see the end of this block
 
 		// ---- finish (:1033-1073) ---------------------------------------------------------------------------------------------------------
 		if (opt.realigned_ranges)
@@ -1049,6 +1048,12 @@ int main(int argc, char **argv)
 			for (auto const &kv : removed_tag_counts)
 				std::cerr << "\t\t" << (char) (kv.first >> 8) << (char) (kv.first & 0xff) << ": " << kv.second << '\n';
 		}
+		// Every output is written and closed.  The process ends here without taking the GPU contexts, the page-locked arrays,
+		// the worker pool and the HIP runtime down one by one: that took as long as projecting a million records, and the
+		// driver frees all of it with the process (the reference ends with exit(0) from its main queue as well,
+		// project_alignments.cc:1079-1089).
+		std::cout.flush(); std::cerr.flush(); std::fflush(nullptr);
+		std::_Exit(0);
 	}
 	catch (std::exception const &e)
 	{

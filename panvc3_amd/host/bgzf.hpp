@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "fast_crc32.hpp"
+#include "fast_inflate.hpp"
 #include "fast_deflate.hpp"
 
 namespace pvc3host {
@@ -234,6 +235,11 @@ class byte_reader
 			parallel_for(blocks.size(), m_threads, [&](std::size_t i) {
 				block const &b = blocks[i];
 				if (0 == b.out_len) return;
+				// The block's own decoder first (fast_inflate.hpp); whatever it does not accept, or whose checksum does not come
+				// out, goes through zlib, which then decides what is corrupt.
+				static thread_local fast_inflater quick;
+				if (quick.inflate(m_cbuf.data() + b.in_off, b.in_len, dbuf + b.out_off, b.out_len) && fast_crc32(0, dbuf + b.out_off, b.out_len) == b.crc)
+					return;
 				z_stream zs{};
 				if (Z_OK != inflateInit2(&zs, -15)) throw io_error("inflateInit2 failed");
 				zs.next_in = m_cbuf.data() + b.in_off; zs.avail_in = (uInt) b.in_len;

@@ -85,3 +85,8 @@ def test_writer_reports_a_failed_close(tool):
 def test_fast_crc32_equals_zlib(tool):
 	out = subprocess.run([os.path.join(ROOT, "bin", "test_crc32_test")], capture_output=True, text=True)
 	assert out.returncode == 0, out.stdout
+
+
+def test_fast_inflate_against_zlib_streams(tool):
+	out = subprocess.run([os.path.join(ROOT, "bin", "test_inflate_test")], capture_output=True, text=True)
+	assert out.returncode == 0, out.stdout

@@ -68,6 +68,7 @@ struct pvc3_context
 	uint32_t position_windows{1};		// upload_index: position windows (dev_entry::pwin) when they fit the device
 	uint32_t window_read_length{150};	// longest read whose compare is to be served from one window: up to 158 bases -> 128-byte windows, else 256
 	uint64_t window_reserve{UINT64_C(24) << 30};	// HBM that must stay free after the windows (batches, arenas, trace)
+	pvc3_dbatch *kept_batch{};			// pvc3_batch_project keeps its device batch for the next call (no hipMalloc / hipFree per batch)
 	bool have_windows{};				// the uploaded index has them: k_project_fast runs, otherwise k_project_fast_probes
 	bool wide_windows{};				// ... of 256 bytes
 	uint8_t *scratch{};
@@ -408,6 +409,7 @@ void pvc3_context_destroy(pvc3_context *ctx)
 	if (!ctx) return;
 	(void) hipSetDevice(ctx->device);
 	(void) hipStreamSynchronize(ctx->stream);
+	if (ctx->kept_batch) { pvc3_dbatch_destroy(ctx->kept_batch); ctx->kept_batch = nullptr; }
 	free_index_replica(ctx);
 	if (ctx->d_params) (void) hipFree(ctx->d_params);
 	if (ctx->scratch) (void) hipFree(ctx->scratch);
@@ -1031,12 +1033,35 @@ PVC3_API int pvc3_debug_wave_stats(pvc3_dbatch *b, unsigned long long *out, uint
 int pvc3_batch_project(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_batch_out *out, pvc3_params const *params, pvc3_batch_stats *stats)
 {
 	if (!ctx || !in || !out || !params) return set_error(PVC3_E_INVALID, "pvc3_batch_project: null argument");
-	pvc3_dbatch *b{};
-	PVC3_TRY(pvc3_dbatch_create(ctx, in, &b));
-	int rc = pvc3_dbatch_project(ctx, b, params);
+	PVC3_TRY(check_device(ctx));
+	if (!ctx->d_entries) return set_error(PVC3_E_STATE, "pvc3_batch_project: no index has been uploaded to this context");
+	uint64_t const n = in->n;
+	if (n && (!in->cigar_off || !in->seq_off))
+		return set_error(PVC3_E_INVALID, "pvc3_batch_project: a required input array is null");
+	// The device batch of the previous call is used again when this batch fits it (the device arrays of a batch are some
+	// thirty-five allocations: 5 - 13 ms of hipMalloc / hipFree per four million records); a larger batch gets a new one
+	// with a quarter of headroom.  It lives until the context is destroyed.
+	batch_caps need;
+	need.n = n;
+	need.cigar = n ? in->cigar_off[n] : 0;
+	need.seq = n ? in->seq_off[n] : 0;
+	need.qual = (n && in->qual_off && in->qual) ? in->qual_off[n] : 0;
+	need.mates = true;
+	pvc3_dbatch *b = ctx->kept_batch;
+	if (!b || need.n > b->caps.n || need.cigar > b->caps.cigar || need.seq > b->caps.seq || need.qual > b->caps.qual)
+	{
+		if (b) { HIP_TRY(hipStreamSynchronize(ctx->stream)); pvc3_dbatch_destroy(b); ctx->kept_batch = nullptr; b = nullptr; }
+		batch_caps caps = need;
+		caps.n += caps.n / 4; caps.cigar += caps.cigar / 4 + 64; caps.seq += caps.seq / 4 + 64; caps.qual += caps.qual / 4 + 64;
+		if (caps.n >= (UINT64_C(1) << 32)) caps.n = (UINT64_C(1) << 32) - 1;
+		PVC3_TRY(dbatch_alloc(ctx, caps, &b));
+		ctx->kept_batch = b;
+	}
+	int rc = dbatch_load(ctx, b, in, ctx->stream, false);
+	if (!rc) rc = dbatch_check_valid(b, ctx->stream);
+	if (!rc) rc = pvc3_dbatch_project(ctx, b, params);
 	if (!rc) rc = pvc3_dbatch_finish(ctx, b, stats);
 	if (!rc) rc = pvc3_dbatch_download(ctx, b, out);
-	pvc3_dbatch_destroy(b);
 	return rc;
 }
 

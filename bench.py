@@ -60,6 +60,7 @@ def parse_args(argv=None):
 	ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="target CPU time of the oracle sample; 0 disables")
 	ap.add_argument("--score-mode", type=int, default=0)
 	ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="pvc3_context_set_option (tuning experiments), e.g. realign_waves=5120")
+	ap.add_argument("--cli-records", type=int, default=4_000_000, help="records of the end-to-end command line leg (BAM file -> panvc3_project_alignments -> BAM file, SURVEY.md §8d protocol iii); 0 disables")
 	ap.add_argument("--skip-host-buffers", action="store_true", help="leave out the PCIe-inclusive legs (their smaller launches would enter rocprofv3's per-kernel averages)")
 	ap.add_argument("--sorted", action="store_true", help="sort the records by (source entry, position) like a coordinate-sorted BAM (secondary data point; the default is the unsorted worst case)")
 	ap.add_argument("--skip-sorted-leg", action="store_true", help="leave out the second measurement of the same records in coordinate order (the order of a sorted BAM, which is what the workflows feed project_alignments)")
@@ -106,6 +107,34 @@ def launch_children(args):
 		print("[bench] ranks failed: %s" % ", ".join("rank %d exit %s" % rc for rc in bad), file=sys.stderr, flush=True)
 		return 1
 	return 0
+
+
+def cli_end_to_end(n_records):
+	"""Wall clock of bin/panvc3_project_alignments on a synthetic BAM of config C2's reads (REF + 2 founders, 150 bp single-end),
+	BAM in, BAM out, the whole process each time: start-up, index file, FASTA, GPU contexts, the records, the output file."""
+	import tempfile
+	sys.path.insert(0, os.path.join(ROOT, "tools"))
+	import cli_e2e
+	here = os.getcwd()
+	work = tempfile.mkdtemp(prefix="pvc3_bench_cli_")
+	try:
+		unique = min(n_records, 250_000)
+		P = cli_e2e.prepare(work, scale=unique / 1_000_000.0, repeat=max(1, n_records // unique))
+		cmd = cli_e2e.project_command(P)
+		cli_e2e.timed(cmd, cwd=work)		# page cache, first GPU start-up
+		runs = [cli_e2e.timed(cmd, cwd=work) for _ in range(3)]
+		dt, stages = min(runs, key=lambda r: r[0])
+		t_empty, _ = cli_e2e.timed(cli_e2e.project_command(P, alignments="empty.bam", output="empty_out.bam"), cwd=work)
+		return {
+			"value": P["n"] / dt, "unit": "records/s", "records": P["n"], "seconds": dt, "seconds_without_records": t_empty,
+			"cores": usable_cpus(), "stages": stages,
+			"what": "bin/panvc3_project_alignments, BAM file in, BAM file out (built-in deflate), wall clock of the whole process, best of 3; "
+					"seconds_without_records: the same command on an input without records (index file, FASTA, GPU start-up)",
+		}
+	finally:
+		os.chdir(here)
+		import shutil
+		shutil.rmtree(work, ignore_errors=True)
 
 
 def traffic_for(config, scale):
@@ -310,6 +339,13 @@ def main():
 			del pb, owners, res0, owner0
 			if hasattr(panvc3_amd, "pipeline_bench"):
 				result["pipeline"] = panvc3_amd.pipeline_bench(ctx, batch, params)
+
+		# ---- end to end through the command line (protocol iii; never `value`): BAM file -> panvc3_project_alignments -> BAM file ----
+		if world == 1 and not args.skip_host_buffers and args.cli_records > 0:
+			try:
+				result["cli_end_to_end"] = cli_end_to_end(args.cli_records)
+			except Exception as exc:		# (a leg of its own: it must not take the bench line with it)
+				result["cli_end_to_end"] = {"error": str(exc)[-300:]}
 
 		# ---- CPU baseline: the oracle (a port of the reference algorithm) on a bounded sample, same box, rank 0 only ----
 		if world == 1 and args.cpu_baseline_seconds > 0:

@@ -20,21 +20,19 @@ from tests.synth import synth		# noqa: E402
 import bamio						# noqa: E402
 
 
-def main():
-	ap = argparse.ArgumentParser()
-	ap.add_argument("--scale", type=float, default=0.2)
-	ap.add_argument("--workdir", default="/tmp/pvc3_e2e")
-	ap.add_argument("--repeat", type=int, default=1, help="write the records this many times (a larger input without generating more reads)")
-	args = ap.parse_args()
-	os.makedirs(args.workdir, exist_ok=True)
-	os.chdir(args.workdir)
+def prepare(workdir, scale=0.2, repeat=1):
+	"""Synthetic inputs of the command line tools in `workdir`: the MSA rows, input.tsv, genome.fa, msa-index.dat (built with
+	panvc3_index_msa) and in.bam (config C2 scaled, the records written `repeat` times).  Returns a dict with the tool paths,
+	the number of records and what cli_e2e's report needs."""
+	os.makedirs(workdir, exist_ok=True)
+	os.chdir(workdir)
 	from panvc3_amd import build
 	build.build()
 	tools = build.build_host()
 	index_msa = [t for t in tools if t.endswith("panvc3_index_msa")][0]
 	project = [t for t in tools if t.endswith("panvc3_project_alignments")][0]
 
-	gp, rp, desc = synth.config("C2", scale=args.scale)
+	gp, rp, desc = synth.config("C2", scale=scale)
 	genome = synth.Genome(gp)
 	reads = synth.Reads(genome, rp)
 	b = reads.batch()
@@ -78,13 +76,47 @@ def main():
 		raw.append(struct.pack("<i", len(rec)))
 		raw.append(rec)
 	n_head = 4 + 4 * len(names)
-	blob = b"".join(raw[:n_head]) + b"".join(raw[n_head:]) * args.repeat
-	n *= args.repeat
+	# BGZF blocks are independent: the header is compressed on its own and the blocks of the records are written `repeat` times
+	# (a larger input for the price of compressing the records once).
+	head_bytes, body_bytes = b"".join(raw[:n_head]), b"".join(raw[n_head:])
+	head_blocks = b"".join(bamio._bgzf_block(head_bytes[i:i + 0xff00]) for i in range(0, len(head_bytes), 0xff00))
+	body_blocks = b"".join(bamio._bgzf_block(body_bytes[i:i + 0xff00]) for i in range(0, len(body_bytes), 0xff00))
+	n *= repeat
 	with open("in.bam", "wb") as f:
-		for i in range(0, len(blob), 0xff00):
-			f.write(bamio._bgzf_block(blob[i:i + 0xff00]))
+		f.write(head_blocks)
+		for _ in range(repeat):
+			f.write(body_blocks)
 		f.write(bamio._bgzf_block(b""))
-	in_size = os.path.getsize("in.bam")
+	with open("empty.bam", "wb") as f:		# the same header, no records: what the fixed part of a run costs
+		f.write(head_blocks)
+		f.write(bamio._bgzf_block(b""))
+	return dict(project=project, index_msa=index_msa, n=n, lens=lens, n_entries=genome.n_entries, t_index=t_index, in_size=os.path.getsize("in.bam"), workdir=workdir)
+
+
+def project_command(P, alignments="in.bam", output="out.bam", bam=True):
+	cmd = [P["project"], "-a", alignments, "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-o", output, "--debugging-output"]
+	return cmd + (["-b"] if bam else [])
+
+
+def timed(cmd, cwd=None):
+	"""(seconds, the tool's --debugging-output stage line or None)"""
+	t = time.perf_counter()
+	p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=cwd)
+	dt = time.perf_counter() - t
+	if p.returncode:
+		raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), p.stderr.decode()[-2000:]))
+	stages = [line.strip() for line in p.stderr.decode().split("\n") if "Stages" in line]
+	return dt, (stages[0] if stages else None)
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--scale", type=float, default=0.2)
+	ap.add_argument("--workdir", default="/tmp/pvc3_e2e")
+	ap.add_argument("--repeat", type=int, default=1, help="write the records this many times (a larger input without generating more reads)")
+	args = ap.parse_args()
+	P = prepare(args.workdir, args.scale, args.repeat)
+	project, n, lens, t_index, in_size = P["project"], P["n"], P["lens"], P["t_index"], P["in_size"]
 
 	def run(cmd):
 		t = time.perf_counter()
@@ -110,15 +142,11 @@ def main():
 	t_l1 = run(full + ["--batch-size=262144", "--threads=64", "--compression-level=1"])
 	t_l6 = run(full + ["--batch-size=262144", "--threads=64", "--compression-level=6"])
 	l6_size = os.path.getsize("out.bam")
-	# the fixed part (index file, FASTA, GPU start-up, index upload): the same command on an input without records
-	with open("empty.bam", "wb") as f:
-		head_len = 12 + len(header) + sum(8 + len(nm) + 1 for nm in names)
-		f.write(bamio._bgzf_block(blob[:head_len]))
-		f.write(bamio._bgzf_block(b""))
+	# the fixed part (index file, FASTA, GPU start-up, index upload): the same command on an input without records (empty.bam)
 	run(full)
 	out_size = os.path.getsize("out.bam")
 	t_empty = run([project, "-a", "empty.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-b", "-o", "empty_out.bam"])
-	print("records %d, genome %d bp x %d rows, in.bam %.1f MB, out.bam (built-in deflate) %.1f MB" % (n, lens[0], genome.n_entries, in_size / 1e6, out_size / 1e6))
+	print("records %d, genome %d bp x %d rows, in.bam %.1f MB, out.bam (built-in deflate) %.1f MB" % (n, lens[0], P["n_entries"], in_size / 1e6, out_size / 1e6))
 	print("index_msa --build-index: %.2f s" % t_index)
 	print("project_alignments --io-only BAM->BAM: %.2f s = %.2f M records/s" % (t_io, n / t_io / 1e6))
 	print("project_alignments BAM->BAM: %.2f s = %.2f M records/s" % (t_full, n / t_full / 1e6))

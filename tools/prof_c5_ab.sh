@@ -1,6 +1,8 @@
 #!/bin/bash
+# usage (on the GPU box, from the repo root): tools/prof_c5_ab.sh NAME [NAME ...] — bench.py --config C5 under rocprofv3 --kernel-trace
+# --stats once per diagnostic build (tools/diag_build.py; "main" = the product library): the realignment kernels' averages side by side.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for n in head main; do
+for n in "$@"; do
   lib=panvc3_amd/_build/diag_$n/libpvc3_hip.so; [ "$n" = main ] && lib=panvc3_amd/libpvc3_hip.so
   export PVC3_LIB_PATH=$lib
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/c5_$n -- python3 bench.py --warmup 1 --cpu-baseline-seconds 0 --skip-host-buffers --no-build --config C5 --steps 3 --skip-sorted-leg > gpurun_out/c5_$n.json 2> gpurun_out/c5_$n.err

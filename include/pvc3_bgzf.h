@@ -1,0 +1,64 @@
+/*
+ * pvc3_bgzf.h — C ABI of the BGZF block compressor on the GPU (libpvc3_bgzf.so).
+ *
+ * The BAM writer of panvc3_project_alignments spends most of the process's CPU time in DEFLATE.  BGZF blocks
+ * are independent gzip members of at most 65 280 uncompressed bytes (SAMv1 §4.1), so a group of them is compressed by one
+ * kernel launch, one wavefront per block.  What comes back is the raw DEFLATE stream of each block (RFC 1951, one final
+ * dynamic-Huffman or stored block); the caller adds the 18-byte gzip/BC header, CRC32 and ISIZE.
+ *
+ * Reference interface replaced: none of panvc3's own — the reference writes BAM through seqan3's bgzf_ostream
+ * (project-alignments/project_alignments.cc:1296-1330 opens the output; compression happens inside seqan3 / zlib).  Any inflate
+ * reads the streams; they are not byte-identical to zlib's (no two DEFLATE encoders are).
+ *
+ * Staging is page-locked memory owned by the library, `n_slots` of it, so that one group is filled while another is
+ * compressed:
+ *   in    pvc3_bgzf_slot_input(h, s):  block i's bytes at  i * PVC3_BGZF_IN_STRIDE + PVC3_BGZF_IN_PAD
+ *         pvc3_bgzf_slot_lengths(h, s)[i] = their number (0 .. PVC3_BGZF_BLOCK)
+ *   out   after pvc3_bgzf_wait: block i's stream at out + i * PVC3_BGZF_OUT_STRIDE, out_len[i] bytes
+ * One host thread per handle.  Functions return 0 or a negative code (the PVC3_E_* values of pvc3.h);
+ * pvc3_bgzf_last_error() gives the message of the calling thread's last failure.
+ */
+#ifndef PVC3_BGZF_H
+#define PVC3_BGZF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVC3_BGZF_API __attribute__((visibility("default")))
+
+#define PVC3_BGZF_BLOCK 65280u			/* uncompressed bytes per block at most (0xff00, as htslib) */
+#define PVC3_BGZF_IN_PAD 64u			/* unused bytes in front of a block's data in its slot */
+#define PVC3_BGZF_IN_STRIDE 65536u
+#define PVC3_BGZF_OUT_STRIDE 65536u
+
+typedef struct pvc3_bgzf pvc3_bgzf;
+
+/* device: HIP device ordinal; max_blocks: blocks per group at most; n_slots: 1 .. 4 staging areas. */
+PVC3_BGZF_API int pvc3_bgzf_create(int device, uint32_t max_blocks, uint32_t n_slots, pvc3_bgzf **out);
+PVC3_BGZF_API void pvc3_bgzf_destroy(pvc3_bgzf *h);
+PVC3_BGZF_API uint32_t pvc3_bgzf_max_blocks(pvc3_bgzf const *h);
+PVC3_BGZF_API uint8_t *pvc3_bgzf_slot_input(pvc3_bgzf *h, uint32_t slot);
+PVC3_BGZF_API uint32_t *pvc3_bgzf_slot_lengths(pvc3_bgzf *h, uint32_t slot);
+
+/* Starts copying the slot's first n_blocks blocks to the GPU, compressing them and copying the streams back; returns at once. */
+PVC3_BGZF_API int pvc3_bgzf_submit(pvc3_bgzf *h, uint32_t slot, uint32_t n_blocks);
+/* Waits for the slot's group.  *out / *out_len stay valid until the slot is submitted again.  kernel_ms (may be null): the
+ * kernel's time on the GPU. */
+PVC3_BGZF_API int pvc3_bgzf_wait(pvc3_bgzf *h, uint32_t slot, uint8_t const **out, uint32_t const **out_len, float *kernel_ms);
+
+/* One call for callers without staging of their own (tests, small outputs): src[0 .. n) is cut into pieces of `piece` bytes
+ * (1 .. PVC3_BGZF_BLOCK); piece i's stream goes to dst + i * PVC3_BGZF_OUT_STRIDE and its size to dst_len[i].  dst must hold
+ * ceil(n / piece) * PVC3_BGZF_OUT_STRIDE bytes. */
+PVC3_BGZF_API int pvc3_bgzf_deflate(pvc3_bgzf *h, uint8_t const *src, size_t n, uint32_t piece, uint8_t *dst, uint32_t *dst_len);
+
+PVC3_BGZF_API char const *pvc3_bgzf_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

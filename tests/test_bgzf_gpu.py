@@ -1,0 +1,149 @@
+"""The GPU's BGZF block compressor (panvc3_amd/bgzf/deflate.hip through include/pvc3_bgzf.h) against zlib's inflate: every
+stream must be one complete raw DEFLATE stream that inflates to its input, the same bytes on every run.  No reference
+counterpart (the reference writes BAM through seqan3 / zlib), so what is pinned here is the format, by zlib."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_the_header():
+	"""CPU: libpvc3_bgzf.so loads and exports every function include/pvc3_bgzf.h declares."""
+	import re
+	from panvc3_amd import bgzf, build
+	build.build_bgzf()
+	declared = set(re.findall(r"PVC3_BGZF_API [^;]*?\b(pvc3_bgzf_\w+)\(", open(os.path.join(ROOT, "include", "pvc3_bgzf.h")).read()))
+	assert declared == set(bgzf.SYMBOLS)
+	L = bgzf.lib()
+	for name in declared:
+		assert hasattr(L, name), name
+
+
+def _inflate(stream):
+	d = zlib.decompressobj(-15)
+	out = d.decompress(stream) + d.flush()
+	assert d.eof and not d.unused_data		# one complete final block, nothing behind it
+	return out
+
+
+def _bam_like(rng, n_records):
+	"""Records shaped like BAM's: a fixed part, a name, CIGAR, packed bases, qualities in runs, tags."""
+	out = []
+	pos = 0
+	for i in range(n_records):
+		pos += int(rng.integers(1, 400))
+		l_seq = 150
+		qual = np.repeat(rng.choice(np.array([2, 11, 25, 37], dtype=np.uint8), size=40), rng.integers(1, 12, size=40))[:l_seq]
+		qual = np.pad(qual, (0, l_seq - len(qual)), constant_values=37)
+		rec = (np.array([0, pos, 0x1e0a, 0x00630001, l_seq, -1, -1, 0], dtype="<i4").tobytes() + b"read%07d\0" % i
+			   + np.array([150 << 4], dtype="<u4").tobytes() + rng.integers(0, 256, size=75, dtype=np.uint8).tobytes() + qual.tobytes()
+			   + b"ASc\xfbXSc\xecYTZUU\0")
+		out.append(np.array([len(rec)], dtype="<i4").tobytes() + rec)
+	return b"".join(out)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+	from panvc3_amd import bgzf, build
+	build.build_bgzf()
+	c = bgzf.BlockCompressor(0, max_blocks=64, n_slots=2)
+	yield c
+	c.close()
+
+
+@pytest.mark.gpu
+def test_edge_cases(gpu):
+	rng = np.random.default_rng(3)
+	cases = (b"", b"a", b"ab", b"abc", b"abcd", b"abcdefg", b"aaaaaaaa", b"a" * 70000, bytes(range(256)) * 3, b"abcd" * 20000,
+			 bytes(rng.integers(0, 256, size=65280, dtype=np.uint8)), bytes(rng.integers(0, 256, size=65281, dtype=np.uint8)),
+			 bytes(rng.integers(0, 256, size=9, dtype=np.uint8)), bytes(rng.integers(0, 2, size=200000, dtype=np.uint8)),
+			 bytes(rng.integers(0, 256, size=63, dtype=np.uint8)), bytes(rng.integers(0, 256, size=64, dtype=np.uint8)),
+			 bytes(rng.integers(0, 256, size=65, dtype=np.uint8)), b"ab" * 129 + b"c", b"x" * 258, b"x" * 259, b"x" * 260, b"x" * 65280)
+	for data in cases:
+		streams = gpu.deflate(data)
+		assert len(streams) == max(1, -(-len(data) // 65280))
+		assert b"".join(_inflate(s) for s in streams) == data
+		assert sum(len(s) for s in streams) <= len(data) + 5 * len(streams)		# never larger than stored
+	# a block of incompressible bytes is stored: five bytes more than the input
+	assert len(gpu.deflate(cases[10])[0]) == 65285
+
+
+@pytest.mark.gpu
+def test_every_small_piece_size(gpu):
+	"""Pieces of 1 .. 300 bytes of the same text: the last window of a block ends at every offset of a wave."""
+	rng = np.random.default_rng(11)
+	text = bytes(rng.choice(np.frombuffer(b"ACGTN!#5F", dtype=np.uint8), size=40000))
+	for piece in list(range(1, 70)) + [127, 128, 129, 255, 256, 257, 258, 259, 300]:
+		data = text[:piece * 40]
+		streams = gpu.deflate(data, piece=piece)
+		assert len(streams) == 40
+		assert b"".join(_inflate(s) for s in streams) == data
+
+
+@pytest.mark.gpu
+def test_skewed_frequencies_need_length_limiting(gpu):
+	fib = [1, 1]
+	while len(fib) < 24:
+		fib.append(fib[-1] + fib[-2])
+	rng = np.random.default_rng(5)
+	sym = np.repeat(np.arange(24, dtype=np.uint8), fib)
+	rng.shuffle(sym)
+	data = bytes(sym[:65000])
+	(s,) = gpu.deflate(data)
+	assert _inflate(s) == data
+	words = [bytes(rng.integers(97, 123, size=int(rng.integers(4, 40)), dtype=np.uint8)) for _ in range(200)]
+	text = b" ".join(words[int(i)] for i in rng.zipf(1.3, size=6000) % 200)
+	streams = gpu.deflate(text)
+	assert b"".join(_inflate(s) for s in streams) == text
+	assert sum(len(s) for s in streams) < len(text) // 2
+
+
+@pytest.mark.gpu
+def test_bam_records_round_trip_and_are_deterministic(gpu):
+	from panvc3_amd import bgzf
+	rng = np.random.default_rng(7)
+	data = _bam_like(rng, 20000)		# about 5 MB, more blocks than the handle's group holds at once
+	streams = gpu.deflate(data)
+	assert b"".join(_inflate(s) for s in streams) == data
+	assert streams == gpu.deflate(data)
+	total = sum(len(s) for s in streams)
+	level1 = sum(len(zlib.compress(data[o:o + 65280], 1)) for o in range(0, len(data), 65280))
+	assert total < 1.05 * level1		# not worse than zlib's fastest level
+	# as BGZF members the blocks are a gzip file
+	import gzip
+	import io
+	blocks = b"".join(bgzf.bgzf_member(s, data[i * 65280:(i + 1) * 65280]) for i, s in enumerate(streams))
+	assert gzip.GzipFile(fileobj=io.BytesIO(blocks)).read() == data
+
+
+@pytest.mark.gpu
+def test_slots_are_independent(gpu):
+	"""Two groups in flight through the slot interface."""
+	import ctypes as C
+	from panvc3_amd import bgzf
+	L = bgzf.lib()
+	rng = np.random.default_rng(13)
+	datas = [_bam_like(rng, 700), _bam_like(rng, 900)]
+	counts = []
+	for slot, data in enumerate(datas):
+		inp = np.ctypeslib.as_array(C.cast(L.pvc3_bgzf_slot_input(gpu._h, slot), C.POINTER(C.c_uint8)), shape=(64 * bgzf.IN_STRIDE,))
+		lens = np.ctypeslib.as_array(C.cast(L.pvc3_bgzf_slot_lengths(gpu._h, slot), C.POINTER(C.c_uint32)), shape=(64,))
+		n = -(-len(data) // 65280)
+		for i in range(n):
+			chunk = np.frombuffer(data[i * 65280:(i + 1) * 65280], dtype=np.uint8)
+			inp[i * bgzf.IN_STRIDE + bgzf.IN_PAD:i * bgzf.IN_STRIDE + bgzf.IN_PAD + len(chunk)] = chunk
+			lens[i] = len(chunk)
+		assert 0 == L.pvc3_bgzf_submit(gpu._h, slot, n)
+		counts.append(n)
+	assert 0 != L.pvc3_bgzf_submit(gpu._h, 0, 1)		# busy until waited for
+	for slot, data in enumerate(datas):
+		out, out_len, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+		assert 0 == L.pvc3_bgzf_wait(gpu._h, slot, C.byref(out), C.byref(out_len), C.byref(ms))
+		ol = np.ctypeslib.as_array(C.cast(out_len, C.POINTER(C.c_uint32)), shape=(counts[slot],))
+		o = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(counts[slot] * bgzf.OUT_STRIDE,))
+		got = b"".join(_inflate(o[i * bgzf.OUT_STRIDE:i * bgzf.OUT_STRIDE + int(ol[i])].tobytes()) for i in range(counts[slot]))
+		assert got == data
+		assert ms.value > 0

@@ -129,13 +129,13 @@ def build_host(force=False, verbose=False):
 	"""The C++ host pipeline (g++): bin/panvc3_index_msa and bin/panvc3_project_alignments (the latter links libpvc3_hip.so)."""
 	build(force=False, verbose=verbose)
 	os.makedirs(BIN, exist_ok=True)
-	headers = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "pvc3.h")]
+	headers = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "pvc3.h"), os.path.join(HERE, "..", "include", "pvc3_bgzf.h")]
 	cxx = os.environ.get("CXX", "g++")
 	flags = ["-O2", "-g", "-std=c++17", "-Wall", "-Wextra", "-pthread"]
 	out = []
 	for name, extra in (
 		("panvc3_index_msa", ["-lz"]),
-		("panvc3_project_alignments", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
+		("panvc3_project_alignments", ["-L" + HERE, "-lpvc3_hip", "-lpvc3_bgzf", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
 		("panvc3_rewrite_cigar", ["-lz"]),
 		("panvc3_convert_bed_positions", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
 		("panvc3_recalculate_mapq", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
@@ -144,7 +144,7 @@ def build_host(force=False, verbose=False):
 		dst = os.path.join(BIN, name)
 		out.append(dst)
 		cmd = [cxx] + flags + ["-o", dst, src] + extra
-		key = _key([src, os.path.join(OBJ, "libpvc3_hip.so.key")] + headers, cmd[1:])
+		key = _key([src, os.path.join(OBJ, "libpvc3_hip.so.key"), os.path.join(OBJ, "libpvc3_bgzf.so.key")] + headers, cmd[1:])
 		if force or _stale(dst, key):
 			if verbose:
 				print(" ".join(cmd), file=sys.stderr)

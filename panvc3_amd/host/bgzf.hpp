@@ -437,6 +437,25 @@ public:
 	}
 };
 
+// A compressor of whole groups of BGZF blocks that lives elsewhere (the GPU: gpu_deflate.hpp over include/pvc3_bgzf.h).  The
+// writer fills the input of a slot — block i's bytes at i * in_stride() + in_pad(), their number in lengths()[i] — submits it and
+// goes on with the next slot; wait() gives the raw DEFLATE stream of block i at out + i * out_stride(), out_len[i] bytes.
+// Both calls throw io_error.
+class group_deflater
+{
+public:
+	virtual ~group_deflater() = default;
+	virtual unsigned slots() const = 0;
+	virtual std::size_t max_blocks() const = 0;
+	virtual std::size_t in_stride() const = 0;
+	virtual std::size_t in_pad() const = 0;
+	virtual std::size_t out_stride() const = 0;
+	virtual uint8_t *input(unsigned slot) = 0;
+	virtual uint32_t *lengths(unsigned slot) = 0;
+	virtual void submit(unsigned slot, std::size_t n_blocks) = 0;
+	virtual void wait(unsigned slot, uint8_t const *&out, uint32_t const *&out_len) = 0;
+};
+
 // Sequential byte sink: plain (SAM text) or BGZF blocks (BAM).  Blocks are cut every 0xff00 bytes whatever the number of
 // threads, so the file does not depend on it; they are deflated a group at a time, in parallel.
 class byte_writer
@@ -449,6 +468,14 @@ class byte_writer
 	std::vector <uint8_t> m_pending;	// uncompressed bytes not yet written
 	std::vector <std::vector <uint8_t>> m_out, m_out_writing;		// deflated blocks: being made / on their way to the file
 	std::future <void> m_writing;
+
+	// With a group_deflater attached the bytes go straight to its slots instead of m_pending.
+	group_deflater *m_group{};
+	unsigned m_slot{};							// the slot being filled
+	std::size_t m_blk{}, m_fill{};				// whole blocks in it, bytes of the block after them
+	std::deque <std::pair <unsigned, std::size_t>> m_in_flight;		// (slot, blocks) submitted, oldest first
+	std::vector <uint8_t> m_joined, m_joined_writing;				// a group's BGZF blocks back to back
+	std::vector <std::size_t> m_offsets;
 
 	static constexpr std::size_t BLOCK_DATA = 0xff00;	// uncompressed bytes per block (as htslib)
 
@@ -482,15 +509,83 @@ class byte_writer
 			clen = zs.total_out;
 			deflateEnd(&zs);
 		}
+		frame_block(out.data(), clen, src, len);
+		out.resize(18 + clen + 8);
+	}
+
+	// The gzip header with the BC field in front of the clen bytes of DEFLATE data at block + 18, CRC32 and ISIZE behind them.
+	static void frame_block(uint8_t *block, std::size_t clen, uint8_t const *src, std::size_t len)
+	{
 		std::size_t const bsize = 18 + clen + 8;
 		static uint8_t const head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-		std::memcpy(out.data(), head, 16);
-		out[16] = (uint8_t) ((bsize - 1) & 0xff); out[17] = (uint8_t) ((bsize - 1) >> 8);
+		std::memcpy(block, head, 16);
+		block[16] = (uint8_t) ((bsize - 1) & 0xff); block[17] = (uint8_t) ((bsize - 1) >> 8);
 		uint32_t const crc = fast_crc32(0, src, len);
 		uint32_t const isize = (uint32_t) len;
-		std::memcpy(out.data() + 18 + clen, &crc, 4);
-		std::memcpy(out.data() + 18 + clen + 4, &isize, 4);
-		out.resize(bsize);
+		std::memcpy(block + 18 + clen, &crc, 4);
+		std::memcpy(block + 18 + clen + 4, &isize, 4);
+	}
+
+	void group_write(uint8_t const *src, std::size_t n)
+	{
+		std::size_t const stride = m_group->in_stride(), pad = m_group->in_pad();
+		while (n)
+		{
+			std::size_t const k = std::min(n, BLOCK_DATA - m_fill);
+			std::memcpy(m_group->input(m_slot) + m_blk * stride + pad + m_fill, src, k);
+			m_fill += k; src += k; n -= k;
+			if (BLOCK_DATA == m_fill)
+			{
+				m_group->lengths(m_slot)[m_blk++] = (uint32_t) BLOCK_DATA;
+				m_fill = 0;
+				if (m_blk == m_group->max_blocks()) group_submit();
+			}
+		}
+	}
+
+	// The slot's blocks (a partial last one included: only close() calls this with one) go to the compressor, and the next slot
+	// is made free: its group, submitted a round ago, is framed and written.
+	void group_submit()
+	{
+		if (m_fill) { m_group->lengths(m_slot)[m_blk++] = (uint32_t) m_fill; m_fill = 0; }
+		if (m_blk)
+		{
+			m_group->submit(m_slot, m_blk);
+			m_in_flight.emplace_back(m_slot, m_blk);
+		}
+		m_blk = 0;
+		m_slot = (m_slot + 1) % m_group->slots();
+		while (std::any_of(m_in_flight.begin(), m_in_flight.end(), [this](auto const &g) { return g.first == m_slot; }))
+			group_retire();
+	}
+
+	void group_retire()
+	{
+		auto const [slot, n] = m_in_flight.front();
+		m_in_flight.pop_front();
+		uint8_t const *out{};
+		uint32_t const *out_len{};
+		m_group->wait(slot, out, out_len);
+		uint8_t const *in = m_group->input(slot);
+		uint32_t const *len = m_group->lengths(slot);
+		std::size_t const stride = m_group->in_stride(), pad = m_group->in_pad(), out_stride = m_group->out_stride();
+		m_offsets.resize(n + 1);
+		m_offsets[0] = 0;
+		for (std::size_t i = 0; i < n; ++i)
+		{
+			if (out_len[i] > BLOCK_DATA + 5) throw io_error("deflate failed");
+			m_offsets[i + 1] = m_offsets[i] + 18 + out_len[i] + 8;
+		}
+		if (m_joined.size() < m_offsets[n]) m_joined.resize(m_offsets[n]);
+		parallel_for(n, m_threads, [&](std::size_t i) {
+			uint8_t *block = m_joined.data() + m_offsets[i];
+			std::memcpy(block + 18, out + i * out_stride, out_len[i]);
+			frame_block(block, out_len[i], in + i * stride + pad, len[i]);
+		});
+		if (m_writing.valid()) m_writing.get();		// rethrows a write error
+		m_joined.swap(m_joined_writing);
+		std::size_t const total = m_offsets[n];
+		m_writing = std::async(std::launch::async, [this, total]() { write_raw(m_joined_writing.data(), total); });
 	}
 
 	// Writes all whole blocks of m_pending (and the partial last one if `all`).
@@ -528,6 +623,18 @@ public:
 
 	void set_threads(unsigned n) { m_threads = n ? n : 1; }
 
+	// From here on the blocks are compressed by `g` (which must outlive close()); what has been written and not yet compressed
+	// moves to its first slot, so the blocks are cut at the same bytes as without it.  Only for BGZF output with the built-in
+	// encoder (level < 0): a zlib level the user asked for stays zlib's.
+	void attach(group_deflater *g)
+	{
+		if (!g || !m_file || !m_bgzf || m_level >= 0 || m_group) return;
+		m_group = g; m_slot = 0; m_blk = 0; m_fill = 0;
+		std::vector <uint8_t> held;
+		held.swap(m_pending);
+		group_write(held.data(), held.size());
+	}
+
 	void open(char const *path, bool bgzf, int level = -1)		// nullptr or "-" = stdout
 	{
 		close();
@@ -546,6 +653,7 @@ public:
 	{
 		if (!m_bgzf) { write_raw(p, n); return; }
 		uint8_t const *src = (uint8_t const *) p;
+		if (m_group) { group_write(src, n); return; }
 		m_pending.insert(m_pending.end(), src, src + n);
 		if (m_pending.size() >= BLOCK_DATA * 16 * (std::size_t) m_threads)
 			flush_blocks(false);
@@ -563,11 +671,18 @@ public:
 		struct closer
 		{
 			byte_writer &w; FILE *f; bool owns; bool done;
-			~closer() { if (!done) { w.m_pending.clear(); w.m_file = nullptr; if (owns) std::fclose(f); } }
+			~closer() { if (!done) { w.m_pending.clear(); w.m_group = nullptr; w.m_in_flight.clear(); w.m_file = nullptr; if (owns) std::fclose(f); } }
 		} guard{*this, f, owns, false};
 		if (m_bgzf)
 		{
-			flush_blocks(true);
+			if (m_group)
+			{
+				group_submit();
+				while (!m_in_flight.empty()) group_retire();
+				m_group = nullptr;
+			}
+			else
+				flush_blocks(true);
 			if (m_writing.valid()) m_writing.get();
 			// The empty EOF marker block.
 			static uint8_t const eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};

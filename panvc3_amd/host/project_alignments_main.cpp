@@ -26,9 +26,14 @@
 #include <regex>
 #include <set>
 
+#include <memory>
+
+#include <sys/resource.h>
+
 #include "../../include/pvc3.h"
 #include "msa_index_file.hpp"
 #include "sam_bam.hpp"
+#include "gpu_deflate.hpp"
 
 using namespace pvc3host;
 
@@ -99,6 +104,7 @@ struct options
 	char const *alignments{}, *msa_index{}, *reference{}, *reference_msa_id{}, *ref_order{}, *output_path{}, *realigned_ranges{};
 	std::string separator{"_"};
 	bool bam_input{}, output_bam{}, keep_duplicate_ranges{}, print_invocation{}, print_pid{}, io_only{}, debugging_output{};
+	bool gpu_deflate{true};				// --bgzf-deflate=gpu|host: BAM output with the built-in encoder is compressed on the first GPU
 	std::vector <std::string> preserve_tags;
 	std::string rname_tag{"XR"}, pos_tag{"XP"}, rnext_tag{"YR"}, pnext_tag{"YP"}, query_ranges_tag{"XB"}, ref_ranges_tag{"YB"}, rec_idx_tag;
 	int gap_open{0}, gap_ext{-1}, compression_level{-1};
@@ -107,6 +113,25 @@ struct options
 	uint64_t batch_size{UINT64_C(1) << 18};		// records per GPU batch: small enough for reading, projecting and writing of consecutive batches to overlap
 	unsigned threads{default_io_threads()};		// BGZF inflate / deflate
 };
+
+double peak_rss_mb()
+{
+	struct rusage ru{};
+	getrusage(RUSAGE_SELF, &ru);
+	return (double) ru.ru_maxrss / 1024.0;
+}
+
+double rss_mb()		// resident now (/proc/self/statm, pages)
+{
+	double mb = 0.0;
+	if (FILE *f = std::fopen("/proc/self/statm", "r"))
+	{
+		unsigned long size = 0, resident = 0;
+		if (2 == std::fscanf(f, "%lu %lu", &size, &resident)) mb = (double) resident * (double) sysconf(_SC_PAGESIZE) / (1024.0 * 1024.0);
+		std::fclose(f);
+	}
+	return mb;
+}
 
 void usage()
 {
@@ -131,7 +156,8 @@ void usage()
 		"      --device=INT                     GPU to use (default 0)\n"
 		"      --devices=LIST                   GPUs to use, e.g. 0,1,2,3: batches go to them in turn (output order = input order)\n"
 		"      --threads=INT                    host threads for (de)compression, parsing and rewriting\n"
-		"      --compression-level=-1..9        BAM output: -1 (default) the built-in fast deflate encoder, 0..9 zlib at that level\n";
+		"      --compression-level=-1..9        BAM output: -1 (default) the built-in deflate encoders, 0..9 zlib at that level\n"
+		"      --bgzf-deflate=gpu|host          where the built-in encoder runs: on the first GPU (default) or on the host threads\n";
 }
 
 // process_headers (project_alignments.cc:1092-1253)
@@ -274,7 +300,7 @@ int main(int argc, char **argv)
 		{"gap-opening-cost", required_argument, nullptr, 'g'}, {"gap-extension-cost", required_argument, nullptr, 'e'},
 		{"print-invocation", no_argument, nullptr, 1009}, {"print-pid", no_argument, nullptr, 1010}, {"debugging-output", no_argument, nullptr, 1011},
 		{"device", required_argument, nullptr, 1012}, {"batch-size", required_argument, nullptr, 1013}, {"io-only", no_argument, nullptr, 1014}, {"threads", required_argument, nullptr, 1015},
-		{"devices", required_argument, nullptr, 1016}, {"compression-level", required_argument, nullptr, 1017},
+		{"devices", required_argument, nullptr, 1016}, {"compression-level", required_argument, nullptr, 1017}, {"bgzf-deflate", required_argument, nullptr, 1018},
 		{"help", no_argument, nullptr, 'h'}, {"version", no_argument, nullptr, 'V'}, {nullptr, 0, nullptr, 0}};
 	int c;
 	while (-1 != (c = getopt_long(argc, argv, "a:Bm:r:d:s:u:o:bl:t:qg:e:hV", long_opts, nullptr)))
@@ -316,6 +342,11 @@ int main(int argc, char **argv)
 				break;
 			}
 			case 1017: opt.compression_level = std::max(-1, std::min(9, std::atoi(optarg))); break;
+			case 1018:
+				if (0 == std::strcmp(optarg, "gpu")) opt.gpu_deflate = true;
+				else if (0 == std::strcmp(optarg, "host")) opt.gpu_deflate = false;
+				else die("--bgzf-deflate expects gpu or host");
+				break;
 			case 1013: opt.batch_size = std::strtoull(optarg, nullptr, 10); break;
 			case 1014: opt.io_only = true; break;
 			case 1015: opt.threads = (unsigned) std::max(1, std::atoi(optarg)); break;
@@ -344,6 +375,7 @@ int main(int argc, char **argv)
 	try
 	{
 		auto const t_start = std::chrono::steady_clock::now();
+		double const epoch_start = std::chrono::duration <double>(std::chrono::system_clock::now().time_since_epoch()).count();
 		// ---- input + headers -------------------------------------------------------------------------------------------------
 		alignment_reader reader;
 		reader.set_threads(opt.threads);
@@ -380,7 +412,12 @@ int main(int argc, char **argv)
 		pvc3_index *index{};
 		std::vector <uint32_t> src_entries(in_header.refs.size()), dst_entries(out_header.refs.size(), UINT32_MAX);
 		std::vector <pvc3_context *> device_contexts;
-		double t_startup = 0.0;
+		// BAM output with the built-in encoder: the blocks are compressed on the first GPU, 1024 at a time (64 MiB), one group
+		// being filled while the other is on the GPU (bgzf.hpp group_deflater; include/pvc3_bgzf.h).
+		std::unique_ptr <gpu_group_deflater> block_deflater;
+		std::future <std::unique_ptr <gpu_group_deflater>> deflater_coming;
+		bool const want_gpu_deflate = opt.gpu_deflate && opt.output_bam && opt.compression_level < 0;
+		double t_startup = 0.0, t_contexts_up = 0.0, t_deflater_up = 0.0, t_files_read = 0.0;
 		auto prepare_devices = [&]() {
 			// The GPU contexts come up on a thread of their own (the HIP runtime takes a few tenths of a second to start) while the
 			// index file and the reference are read.
@@ -392,6 +429,17 @@ int main(int argc, char **argv)
 					if (pvc3_context_create(dev, &ctx)) throw std::runtime_error(std::string("pvc3_context_create: ") + pvc3_last_error());
 					made.push_back(ctx);
 				}
+				t_contexts_up = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+				// The BGZF compressor's page-locked staging takes a while to allocate and is not needed before the first batch has been
+				// rewritten: it comes up on a thread of its own, behind the contexts (the HIP runtime is up by now).
+				if (want_gpu_deflate)
+					deflater_coming = std::async(std::launch::async, [&]() {
+						char const *group = std::getenv("PVC3_BGZF_GROUP_BLOCKS");		// tests: small groups, many of them
+						std::size_t const blocks = group ? (std::size_t) std::max(1, std::atoi(group)) : 512;
+						auto made_deflater = std::make_unique <gpu_group_deflater>(opt.devices.front(), blocks, 2);
+						t_deflater_up = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+						return made_deflater;
+					});
 				return made;
 			});
 			msa_index_file msa;
@@ -440,6 +488,7 @@ int main(int argc, char **argv)
 					check(pvc3_index_set_reference(index, dst_entries[o], it->second.data(), it->second.size()), "pvc3_index_set_reference");
 				}
 			}
+			t_files_read = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
 			device_contexts = contexts_coming.get();
 		};
 
@@ -612,6 +661,8 @@ int main(int argc, char **argv)
 
 		// ---- index, reference, GPUs (the reader is already at work) ---------------------------------------------------------------
 		prepare_devices();
+		double const t_prepared = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+		double const rss_prepared = rss_mb();
 		{
 			// The position windows of the index replicas are sized for the reads: the longest of the first batch (which the
 			// reader has had the whole start-up for) decides between 128- and 256-byte windows.
@@ -626,6 +677,7 @@ int main(int argc, char **argv)
 			if (longest)
 				for (pvc3_context *ctx : device_contexts) check(pvc3_context_set_option(ctx, "window_read_length", longest), "pvc3_context_set_option");
 		}
+		double const t_first_batch = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
 		// The index is replicated on every GPU, all of them at the same time.
 		{
 			std::vector <std::future <int>> uploads;
@@ -639,6 +691,7 @@ int main(int argc, char **argv)
 		std::vector <pvc3_context *> const &contexts = device_contexts;
 		std::size_t const n_dev = contexts.size();
 		t_startup = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+		double const rss_startup = rss_mb();
 
 		// One slot per batch in flight: the records, the page-locked SoA arrays (include/pvc3.h) and the page-locked results.
 		struct slot_state
@@ -946,6 +999,11 @@ int main(int argc, char **argv)
 				for (auto const &kv : S.removed) removed_tag_counts[kv.first] += kv.second;
 			}
 			tm.rewrite += since(t_stage); t_stage = now();
+			if (deflater_coming.valid())		// the first batch for the writer thread: from here on the GPU compresses the blocks
+			{
+				block_deflater = deflater_coming.get();
+				writer.attach(block_deflater.get());
+			}
 			{
 				std::unique_lock <std::mutex> lock(wq_mutex);
 				wq_cv.wait(lock, [&]() { return wq_done || wq.size() < 2; });		// at most two finished batches wait for the file
@@ -1007,6 +1065,8 @@ int main(int argc, char **argv)
 			slot_state &sl = slot_states[k % slot_states.size()];
 			if (sl.in_flight) retire(sl);
 		}
+		double const t_batches_done = since(t_start);
+		double const rss_batches_done = rss_mb();
 		for (auto *&pl : pipelines) if (pl) { pvc3_pipeline_destroy(pl); pl = nullptr; }
 		{
 			std::lock_guard <std::mutex> lock(wq_mutex);
@@ -1015,7 +1075,9 @@ int main(int argc, char **argv)
 		wq_cv.notify_all();
 		writer_thread.join();
 		if (writer_error) std::rethrow_exception(writer_error);
+		double const t_writer_joined = since(t_start);
 		writer.close();
+		double const t_closed = since(t_start);
 		(void) contexts; (void) index;		// not taken down one by one: see the end of this block
 
 		// ---- finish (:1033-1073) ---------------------------------------------------------------------------------------------------------
@@ -1042,6 +1104,14 @@ int main(int argc, char **argv)
 		if (opt.debugging_output)
 			std::cerr << "\tStages (s): start-up " << t_startup << ", reader thread " << tm.read << ", main: waiting for it " << tm.wait_read << ", batch arrays " << tm.fill
 					  << ", GPU " << tm.gpu << ", rewriting " << tm.rewrite << ", waiting for the writer " << tm.wait_write << ", writer thread " << tm_write << '\n';
+		if (opt.debugging_output)
+			std::cerr << "\tTimeline (s): GPU contexts " << t_contexts_up << " and BGZF compressor " << t_deflater_up << " (their thread), index file and FASTA " << t_files_read << ", both " << t_prepared << ", first batch read " << t_first_batch << ", index on the GPUs (start-up done) " << t_startup << ", last batch rewritten " << t_batches_done << ", writer thread joined " << t_writer_joined
+					  << ", output closed " << t_closed << "; wall clock at the start " << std::fixed << epoch_start << ", now "
+					  << std::chrono::duration <double>(std::chrono::system_clock::now().time_since_epoch()).count() << std::defaultfloat
+					  << "; resident set (MB): contexts up " << rss_prepared << ", index uploaded " << rss_startup << ", last batch rewritten " << rss_batches_done
+					  << ", peak " << peak_rss_mb() << '\n';
+		if (opt.debugging_output && block_deflater)
+			std::cerr << "\tBGZF on the GPU: " << block_deflater->blocks() << " blocks in " << block_deflater->groups() << " groups, kernel " << block_deflater->kernel_seconds() << " s\n";
 		if (!removed_tag_counts.empty())
 		{
 			std::cerr << "\tRemoved tags:\n";
@@ -1052,6 +1122,16 @@ int main(int argc, char **argv)
 		// the worker pool and the HIP runtime down one by one: that took as long as projecting a million records, and the
 		// driver frees all of it with the process (the reference ends with exit(0) from its main queue as well,
 		// project_alignments.cc:1079-1089).
+		if (std::getenv("PVC3_EXIT_PROFILE"))		// what the exit would cost, step by step (tools/cli_timeline.py)
+		{
+			auto lap = [&, t = now()](char const *what) mutable { std::cerr << "\tteardown: " << what << ' ' << since(t) << " s\n"; t = now(); };
+			slot_states.clear(); lap("page-locked batch arrays");
+			block_deflater.reset(); lap("BGZF compressor");
+			for (pvc3_context *ctx : device_contexts) pvc3_context_destroy(ctx);
+			lap("GPU contexts");
+			pvc3_index_destroy(index); lap("index");
+			std::cerr << "\twall clock after the teardown " << std::fixed << std::chrono::duration <double>(std::chrono::system_clock::now().time_since_epoch()).count() << std::defaultfloat << '\n';
+		}
 		std::cout.flush(); std::cerr.flush(); std::fflush(nullptr);
 		std::_Exit(0);
 	}

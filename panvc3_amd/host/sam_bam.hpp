@@ -642,6 +642,7 @@ class alignment_writer
 
 public:
 	void set_threads(unsigned n) { m_out.set_threads(n); }
+	void attach(group_deflater *g) { m_out.attach(g); }		// BAM blocks compressed elsewhere from here on (byte_writer::attach)
 
 	void open(char const *path, bool bam, sam_header const &hdr, int compression_level = -1)
 	{

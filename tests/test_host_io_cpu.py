@@ -90,3 +90,30 @@ def test_fast_crc32_equals_zlib(tool):
 def test_fast_inflate_against_zlib_streams(tool):
 	out = subprocess.run([os.path.join(ROOT, "bin", "test_inflate_test")], capture_output=True, text=True)
 	assert out.returncode == 0, out.stdout
+
+
+def test_writer_with_a_group_deflater(tmp_path):
+	"""byte_writer's group path (the GPU compressor's slot interface) with a host stand-in: the same bytes, cut into the same
+	blocks, whether the groups are attached from the start, after some output, or not at all; one slot or several."""
+	import gzip
+	import numpy as np
+	from panvc3_amd import build
+	build.build_cpp_tests()
+	tool = os.path.join(ROOT, "bin", "test_group_writer_test")
+	rng = np.random.default_rng(17)
+	for size in (0, 1, 65279, 65280, 65281, 3 * 65280, 3 * 65280 + 1, 6 * 65280, 1_500_000):
+		data = bytes(rng.integers(0, 7, size=size, dtype=np.uint8))
+		cuts = {}
+		for mode, slots in (("plain", 1), ("group", 1), ("group", 2), ("group", 3), ("late", 2)):
+			out = tmp_path / ("%s%d.bgzf" % (mode, slots))
+			subprocess.run([tool, str(out), mode, str(slots)], input=data, check=True, timeout=120)
+			raw = out.read_bytes()
+			assert gzip.decompress(raw) == data
+			assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+			sizes, pos = [], 0
+			while pos < len(raw):
+				(bsize,) = struct.unpack_from("<H", raw, pos + 16)
+				sizes.append(struct.unpack_from("<I", raw, pos + bsize + 1 - 4)[0])
+				pos += bsize + 1
+			cuts[(mode, slots)] = sizes
+		assert len(set(map(tuple, cuts.values()))) == 1

@@ -370,6 +370,21 @@ def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_m
 	_run([tools["panvc3_project_alignments"], "-a", "alignments.sam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-u", "order.txt", "--record-index-tag=XI", "-t", "XS", "-t", "YS", "-b", "-o", "out.bam"], cwd=tmp_path)
 	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "out.bam", "-o", "out.sam"], cwd=tmp_path)
 	assert [l for l in open(tmp_path / "out.sam").read().split("\n") if l and not l.startswith("@")] == expect
+	# out.bam's blocks were compressed on the GPU (the default for BAM output).  The same with groups of two blocks (many groups,
+	# both slots in use), on the host's threads, and by zlib: the same records (that the blocks are cut at the same bytes
+	# whoever compresses them is tests/test_host_io_cpu.py's).
+	import gzip
+	to_bam = [tools["panvc3_project_alignments"], "-a", "alignments.sam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-u", "order.txt",
+			  "--record-index-tag=XI", "-t", "XS", "-t", "YS", "-b", "--debugging-output"]
+	base = (tmp_path / "out.bam").read_bytes()
+	for name, extra, env in (("groups.bam", [], {"PVC3_BGZF_GROUP_BLOCKS": "2"}), ("host.bam", ["--bgzf-deflate=host"], None), ("zlib.bam", ["--compression-level=6"], None)):
+		pg = _run(to_bam + ["-o", name] + extra, cwd=tmp_path, env=env)
+		raw = (tmp_path / name).read_bytes()
+		# (the @PG line holds the command line: compare behind the header)
+		assert gzip.decompress(raw)[-200000:] == gzip.decompress(base)[-200000:], name
+		assert (b"BGZF on the GPU" in pg.stderr) == (name == "groups.bam"), name
+		if name == "groups.bam":
+			assert b" groups" in pg.stderr and int(pg.stderr.split(b"blocks in ")[1].split()[0]) >= 2
 	# BAM in (the records are framed in place inside the inflated pieces of the file; pieces of 3 000 compressed bytes make
 	# them straddle), small batches, SAM out: the same records again
 	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "alignments.sam", "-b", "-o", "alignments.bam"], cwd=tmp_path)

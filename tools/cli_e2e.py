@@ -90,7 +90,21 @@ def prepare(workdir, scale=0.2, repeat=1):
 	with open("empty.bam", "wb") as f:		# the same header, no records: what the fixed part of a run costs
 		f.write(head_blocks)
 		f.write(bamio._bgzf_block(b""))
-	return dict(project=project, index_msa=index_msa, n=n, lens=lens, n_entries=genome.n_entries, t_index=t_index, in_size=os.path.getsize("in.bam"), workdir=workdir)
+	return dict(project=project, index_msa=index_msa, n=n, lens=lens, n_entries=genome.n_entries, t_index=t_index, in_size=os.path.getsize("in.bam"), workdir=workdir,
+				head_bytes=len(head_blocks), body_bytes=len(body_blocks), n_unique=n // repeat)
+
+
+def write_repeated(P, path, repeat):
+	"""A BAM file with in.bam's header and its records `repeat` times (in.bam's own blocks, copied); returns the number of records."""
+	with open(os.path.join(P["workdir"], "in.bam"), "rb") as f:
+		head = f.read(P["head_bytes"])
+		body = f.read(P["body_bytes"])
+	with open(path, "wb") as f:
+		f.write(head)
+		for _ in range(repeat):
+			f.write(body)
+		f.write(bamio._bgzf_block(b""))
+	return P["n_unique"] * repeat
 
 
 def project_command(P, alignments="in.bam", output="out.bam", bam=True):
@@ -126,7 +140,7 @@ def main():
 			raise SystemExit("command failed: " + " ".join(cmd))
 		dt = time.perf_counter() - t
 		for line in p.stderr.decode().split("\n"):
-			if "Stages" in line:
+			if "Stages" in line or "Timeline" in line or "BGZF on the GPU" in line:
 				print("   ", " ".join(cmd[-3:]), "|", line.strip())
 		return dt
 
@@ -134,6 +148,7 @@ def main():
 	full = [project, "-a", "in.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-b", "-o", "out.bam", "--debugging-output"]
 	run(full)		# first run pays the page cache and the GPU start-up
 	t_full = run(full)
+	t_host = run(full + ["--bgzf-deflate=host"])
 	t_small = run(full + ["--batch-size=131072"])
 	t_sam = run([project, "-a", "in.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-o", "out.sam"])
 	t_thr = {}
@@ -150,6 +165,7 @@ def main():
 	print("index_msa --build-index: %.2f s" % t_index)
 	print("project_alignments --io-only BAM->BAM: %.2f s = %.2f M records/s" % (t_io, n / t_io / 1e6))
 	print("project_alignments BAM->BAM: %.2f s = %.2f M records/s" % (t_full, n / t_full / 1e6))
+	print("project_alignments BAM->BAM, BGZF blocks compressed by the host threads (--bgzf-deflate=host): %.2f s = %.2f M records/s" % (t_host, n / t_host / 1e6))
 	print("project_alignments BAM->BAM, batches of 131072 (reading overlaps the GPU and the writing): %.2f s = %.2f M records/s" % (t_small, n / t_small / 1e6))
 	print("project_alignments BAM->SAM: %.2f s = %.2f M records/s" % (t_sam, n / t_sam / 1e6))
 	for thr, t in t_thr.items():

@@ -121,6 +121,13 @@ double peak_rss_mb()
 	return (double) ru.ru_maxrss / 1024.0;
 }
 
+double cpu_seconds()		// user + system time of the whole process so far
+{
+	struct rusage ru{};
+	getrusage(RUSAGE_SELF, &ru);
+	return (double) ru.ru_utime.tv_sec + (double) ru.ru_stime.tv_sec + 1e-6 * ((double) ru.ru_utime.tv_usec + (double) ru.ru_stime.tv_usec);
+}
+
 double rss_mb()		// resident now (/proc/self/statm, pages)
 {
 	double mb = 0.0;
@@ -1109,7 +1116,7 @@ int main(int argc, char **argv)
 					  << ", output closed " << t_closed << "; wall clock at the start " << std::fixed << epoch_start << ", now "
 					  << std::chrono::duration <double>(std::chrono::system_clock::now().time_since_epoch()).count() << std::defaultfloat
 					  << "; resident set (MB): contexts up " << rss_prepared << ", index uploaded " << rss_startup << ", last batch rewritten " << rss_batches_done
-					  << ", peak " << peak_rss_mb() << '\n';
+					  << ", peak " << peak_rss_mb() << "; CPU time (s): " << cpu_seconds() << '\n';
 		if (opt.debugging_output && block_deflater)
 			std::cerr << "\tBGZF on the GPU: " << block_deflater->blocks() << " blocks in " << block_deflater->groups() << " groups, kernel " << block_deflater->kernel_seconds() << " s\n";
 		if (!removed_tag_counts.empty())

@@ -147,3 +147,48 @@ def test_slots_are_independent(gpu):
 		got = b"".join(_inflate(o[i * bgzf.OUT_STRIDE:i * bgzf.OUT_STRIDE + int(ol[i])].tobytes()) for i in range(counts[slot]))
 		assert got == data
 		assert ms.value > 0
+
+
+@pytest.mark.gpu
+def test_random_structures(gpu):
+	"""Blocks of many shapes — alphabets of 1 to 256 symbols, copies at every distance class up to and beyond 32 768, matches of
+	every length up to and beyond 258, lengths that end a window anywhere — each stream inflated by zlib."""
+	rng = np.random.default_rng(23)
+	blocks = []
+	for k in range(160):
+		n = int(rng.integers(1, 65281))
+		kind = k % 8
+		if kind == 0:		# few symbols, long runs
+			data = np.repeat(rng.integers(0, int(rng.integers(1, 5)), size=n // 3 + 2, dtype=np.uint8), rng.integers(1, 9, size=n // 3 + 2))[:n]
+		elif kind == 1:		# uniform over a small alphabet
+			data = rng.integers(0, int(rng.integers(2, 257)), size=n, dtype=np.uint8)
+		elif kind == 2:		# a phrase book: copies at all distances
+			words = [rng.integers(0, 256, size=int(rng.integers(3, 400)), dtype=np.uint8) for _ in range(int(rng.integers(2, 60)))]
+			out, total = [], 0
+			while total < n:
+				w = words[int(rng.integers(0, len(words)))]
+				out.append(w); total += len(w)
+			data = np.concatenate(out)[:n]
+		elif kind == 3:		# one period, any length
+			period = rng.integers(0, 256, size=int(rng.integers(1, 40000)), dtype=np.uint8)
+			data = np.tile(period, n // len(period) + 1)[:n]
+		elif kind == 4:		# random bytes with a copy of the beginning exactly `d` back, d around the window limit
+			data = rng.integers(0, 256, size=n, dtype=np.uint8)
+			d = int(rng.choice([32766, 32767, 32768, 32769, 32770, 40000]))
+			if n > d + 600:
+				data[d:d + 600] = data[:600]
+		elif kind == 5:		# matches of chosen lengths separated by fresh bytes
+			piece = rng.integers(0, 256, size=300, dtype=np.uint8)
+			out = [piece]
+			for length in (3, 4, 5, 8, 9, 10, 11, 12, 130, 131, 226, 227, 257, 258, 259, 260, 300):
+				out += [rng.integers(0, 256, size=7, dtype=np.uint8), piece[:length]]
+			data = np.concatenate(out)[:n]
+		elif kind == 6:		# skewed: geometric symbol frequencies
+			data = np.minimum(rng.geometric(0.3, size=n), 255).astype(np.uint8)
+		else:				# text-like
+			data = rng.choice(np.frombuffer(b"etaoin shrdlu\n", dtype=np.uint8), size=n)
+		blocks.append(np.ascontiguousarray(data, dtype=np.uint8).tobytes())
+	for data in blocks:
+		(s,) = gpu.deflate(data)
+		assert _inflate(s) == data
+		assert len(s) <= len(data) + 5

@@ -31,6 +31,7 @@ for _ in range(args.runs):
 		if "wall clock at the start" in line:
 			a = float(line.split("wall clock at the start ")[1].split(",")[0])
 			b = float(line.split(", now ")[1].split(";")[0])
-			print("    before main's clock starts %.3f s, main %.3f s, after its last line %.3f s" % (a - e0, b - a, e1 - b))
+			cpu = float(line.split("CPU time (s): ")[1]) if "CPU time (s): " in line else 0.0
+			print("    before main's clock starts %.3f s, main %.3f s, after its last line %.3f s; CPU time %.2f s = %.1f cores busy" % (a - e0, b - a, e1 - b, cpu, cpu / (b - a)))
 		if "Stages" in line or "Timeline" in line or "BGZF on" in line or "teardown" in line:
 			print("   ", line.strip())

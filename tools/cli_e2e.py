@@ -123,6 +123,54 @@ def timed(cmd, cwd=None):
 	return dt, (stages[0] if stages else None)
 
 
+def records_digest(path):
+	"""(number of records, SHA-256 of the uncompressed records) of a BAM file: everything behind the header, which holds the
+	command line.  Inflated block by block with zlib, CRC32 and ISIZE checked."""
+	import hashlib
+	h = hashlib.sha256()
+	raw = open(path, "rb").read()
+	pos, out, header_left, n_records, carry = 0, [], None, 0, b""
+	while pos < len(raw):
+		(bsize,) = struct.unpack_from("<H", raw, pos + 16)
+		d = zlib.decompressobj(-15)
+		piece = d.decompress(raw[pos + 18:pos + bsize + 1 - 8]) + d.flush()
+		crc, isize = struct.unpack_from("<II", raw, pos + bsize + 1 - 8)
+		if not d.eof or len(piece) != isize or (zlib.crc32(piece) & 0xffffffff) != crc:
+			raise RuntimeError("%s: bad BGZF block at %d" % (path, pos))
+		pos += bsize + 1
+		carry += piece
+		if header_left is None:		# magic, l_text, text, n_ref, (l_name, name, l_ref) *
+			if len(carry) < 12:
+				continue
+			(l_text,) = struct.unpack_from("<i", carry, 4)
+			if len(carry) < 12 + l_text:
+				continue
+			(n_ref,) = struct.unpack_from("<i", carry, 8 + l_text)
+			q, ok = 12 + l_text, True
+			for _ in range(n_ref):
+				if len(carry) < q + 4:
+					ok = False; break
+				(l_name,) = struct.unpack_from("<i", carry, q)
+				q += 4 + l_name + 4
+			if not ok or len(carry) < q:
+				continue
+			carry = carry[q:]
+			header_left = 0
+		# whole records of what is at hand
+		q = 0
+		while len(carry) - q >= 4:
+			(bs,) = struct.unpack_from("<i", carry, q)
+			if len(carry) - q < 4 + bs:
+				break
+			q += 4 + bs
+			n_records += 1
+		h.update(carry[:q])
+		carry = carry[q:]
+	if carry:
+		raise RuntimeError("%s: %d bytes behind the last record" % (path, len(carry)))
+	return n_records, h.hexdigest()
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--scale", type=float, default=0.2)
@@ -148,7 +196,15 @@ def main():
 	full = [project, "-a", "in.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-b", "-o", "out.bam", "--debugging-output"]
 	run(full)		# first run pays the page cache and the GPU start-up
 	t_full = run(full)
-	t_host = run(full + ["--bgzf-deflate=host"])
+	gpu_size = os.path.getsize("out.bam")
+	digest_gpu = records_digest("out.bam")
+	t_host = run([c if c != "out.bam" else "out_host.bam" for c in full] + ["--bgzf-deflate=host"])
+	digest_host = records_digest("out_host.bam")
+	print("records of out.bam (blocks compressed on the GPU, %.1f MB) and of out_host.bam (host threads, %.1f MB): %d and %d, %s"
+		  % (gpu_size / 1e6, os.path.getsize("out_host.bam") / 1e6, digest_gpu[0], digest_host[0], "identical" if digest_gpu == digest_host else "DIFFERENT"))
+	if digest_gpu != digest_host or digest_gpu[0] != n:
+		raise SystemExit("the two outputs differ")
+	os.remove("out_host.bam")
 	t_small = run(full + ["--batch-size=131072"])
 	t_sam = run([project, "-a", "in.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-o", "out.sam"])
 	t_thr = {}

@@ -55,6 +55,30 @@ PVC3_BGZF_API int pvc3_bgzf_wait(pvc3_bgzf *h, uint32_t slot, uint8_t const **ou
  * ceil(n / piece) * PVC3_BGZF_OUT_STRIDE bytes. */
 PVC3_BGZF_API int pvc3_bgzf_deflate(pvc3_bgzf *h, uint8_t const *src, size_t n, uint32_t piece, uint8_t *dst, uint32_t *dst_len);
 
+/* ---- the other direction: the blocks of a BGZF file inflated, one wave per block (panvc3_amd/bgzf/inflate.hip) --------------------
+ * Replaces, like the compressor, nothing of panvc3's own: the reference reads BAM through seqan3 / zlib.  The caller reads a
+ * piece of the file into the slot's page-locked input, lists its blocks (where the DEFLATE data of each begin and how long they
+ * are, ISIZE, and where its bytes are to go in the slot's output: usually one behind the other), submits, and finds the inflated
+ * bytes in the slot's page-locked output.  status[i] != 0: the kernel did not accept block i (its bytes in the output are
+ * undefined) and the caller inflates it itself; the caller also verifies the CRC-32 of every block. */
+typedef struct pvc3_bgzf_inflater pvc3_bgzf_inflater;
+typedef struct pvc3_bgzf_block
+{
+	uint64_t in_off;		/* DEFLATE data of the block in the slot's input */
+	uint32_t in_len;
+	uint32_t out_len;		/* ISIZE, at most 65536 */
+	uint64_t out_off;		/* where its bytes go in the slot's output */
+} pvc3_bgzf_block;
+
+PVC3_BGZF_API int pvc3_bgzf_inflater_create(int device, size_t max_in_bytes, size_t max_out_bytes, uint32_t max_blocks, uint32_t n_slots, pvc3_bgzf_inflater **out);
+PVC3_BGZF_API void pvc3_bgzf_inflater_destroy(pvc3_bgzf_inflater *h);
+PVC3_BGZF_API uint8_t *pvc3_bgzf_inflater_input(pvc3_bgzf_inflater *h, uint32_t slot);
+PVC3_BGZF_API uint8_t *pvc3_bgzf_inflater_output(pvc3_bgzf_inflater *h, uint32_t slot);
+PVC3_BGZF_API pvc3_bgzf_block *pvc3_bgzf_inflater_blocks(pvc3_bgzf_inflater *h, uint32_t slot);
+/* in_bytes / out_bytes: how much of the slot's input is uploaded and how much of its output comes back. */
+PVC3_BGZF_API int pvc3_bgzf_inflater_submit(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t n_blocks, size_t in_bytes, size_t out_bytes);
+PVC3_BGZF_API int pvc3_bgzf_inflater_wait(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t const **status, float *kernel_ms);
+
 PVC3_BGZF_API char const *pvc3_bgzf_last_error(void);
 
 #ifdef __cplusplus

@@ -13,7 +13,10 @@ IN_PAD = 64
 IN_STRIDE = 65536
 OUT_STRIDE = 65536
 SYMBOLS = ("pvc3_bgzf_create", "pvc3_bgzf_destroy", "pvc3_bgzf_max_blocks", "pvc3_bgzf_slot_input", "pvc3_bgzf_slot_lengths", "pvc3_bgzf_submit",
-		   "pvc3_bgzf_wait", "pvc3_bgzf_deflate", "pvc3_bgzf_last_error")
+		   "pvc3_bgzf_wait", "pvc3_bgzf_deflate", "pvc3_bgzf_last_error",
+		   "pvc3_bgzf_inflater_create", "pvc3_bgzf_inflater_destroy", "pvc3_bgzf_inflater_input", "pvc3_bgzf_inflater_output", "pvc3_bgzf_inflater_blocks",
+		   "pvc3_bgzf_inflater_submit", "pvc3_bgzf_inflater_wait")
+BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8")])
 _L = None
 
 
@@ -38,6 +41,14 @@ def lib():
 		L.pvc3_bgzf_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float)]
 		L.pvc3_bgzf_deflate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]
 		L.pvc3_bgzf_last_error.restype = C.c_char_p
+		L.pvc3_bgzf_inflater_create.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+		L.pvc3_bgzf_inflater_destroy.argtypes = [C.c_void_p]
+		L.pvc3_bgzf_inflater_destroy.restype = None
+		for name in ("pvc3_bgzf_inflater_input", "pvc3_bgzf_inflater_output", "pvc3_bgzf_inflater_blocks"):
+			getattr(L, name).argtypes = [C.c_void_p, C.c_uint32]
+			getattr(L, name).restype = C.c_void_p
+		L.pvc3_bgzf_inflater_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t]
+		L.pvc3_bgzf_inflater_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_float)]
 		_L = L
 	return _L
 
@@ -94,6 +105,55 @@ class BlockCompressor:
 			size = int(ol.sum())
 			best = ms.value if best is None else min(best, ms.value)
 		return best, size, int(lens[:n_blocks].sum())
+
+
+class BlockInflater:
+	"""Raw DEFLATE streams inflated on the GPU (pvc3_bgzf_inflater_*)."""
+
+	def __init__(self, device=0, max_in=8 << 20, max_out=32 << 20, max_blocks=4096, n_slots=2):
+		self._L = lib()
+		h = C.c_void_p()
+		_check(self._L.pvc3_bgzf_inflater_create(device, max_in, max_out, max_blocks, n_slots, C.byref(h)))
+		self._h = h
+		self.max_in, self.max_out, self.max_blocks, self.n_slots = max_in, max_out, max_blocks, n_slots
+
+	def close(self):
+		if self._h:
+			self._L.pvc3_bgzf_inflater_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		self.close()
+
+	def _views(self, slot):
+		inp = np.ctypeslib.as_array(C.cast(self._L.pvc3_bgzf_inflater_input(self._h, slot), C.POINTER(C.c_uint8)), shape=(self.max_in,))
+		out = np.ctypeslib.as_array(C.cast(self._L.pvc3_bgzf_inflater_output(self._h, slot), C.POINTER(C.c_uint8)), shape=(self.max_out,))
+		raw = np.ctypeslib.as_array(C.cast(self._L.pvc3_bgzf_inflater_blocks(self._h, slot), C.POINTER(C.c_uint8)), shape=(self.max_blocks * BLOCK_DTYPE.itemsize,))
+		return inp, out, raw.view(BLOCK_DTYPE)
+
+	def inflate(self, streams, sizes, gap=0, slot=0, repeats=1):
+		"""streams[i] inflated to sizes[i] bytes; the streams lie `gap` bytes apart in the input (any alignment), the outputs one
+		behind the other.  Returns (list of bytes or None per stream, statuses, kernel ms)."""
+		inp, out, blocks = self._views(slot)
+		pos, opos = 1, 0		# the first stream at an odd address
+		for i, (s, n) in enumerate(zip(streams, sizes)):
+			inp[pos:pos + len(s)] = np.frombuffer(s, dtype=np.uint8)
+			blocks[i] = (pos, len(s), n, opos)
+			pos += len(s) + gap
+			opos += n
+		out[:opos] = 0xAB
+		best = None
+		for _ in range(repeats):
+			_check(self._L.pvc3_bgzf_inflater_submit(self._h, slot, len(streams), pos, opos))
+			st, ms = C.c_void_p(), C.c_float()
+			_check(self._L.pvc3_bgzf_inflater_wait(self._h, slot, C.byref(st), C.byref(ms)))
+			best = ms.value if best is None else min(best, ms.value)
+		status = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint32)), shape=(len(streams),)).copy()
+		got, o = [], 0
+		for i, n in enumerate(sizes):
+			got.append(out[o:o + n].tobytes() if 0 == status[i] else None)
+			o += n
+		return got, status, best
 
 
 def bgzf_member(stream, data):

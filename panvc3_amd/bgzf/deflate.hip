@@ -32,6 +32,8 @@
 
 #include "../../include/pvc3_bgzf.h"
 
+thread_local char g_bgzf_error[256];		// the message of the calling thread's last failure (both files of the library)
+
 namespace {
 
 constexpr unsigned HASH_BITS = 12;
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(WAVE) void k_deflate_blocks(
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 
-thread_local char g_error[256];
+#define g_error g_bgzf_error
 
 int fail(int code, char const *what, hipError_t e = hipSuccess)
 {

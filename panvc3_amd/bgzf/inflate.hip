@@ -1,0 +1,522 @@
+// inflate.hip — BGZF blocks inflated on the GPU, one wavefront per block (libpvc3_bgzf.so; C ABI in include/pvc3_bgzf.h).
+//
+// No reference code corresponds to this file: the reference reads BAM through seqan3 / zlib.  The BGZF reader of
+// panvc3_project_alignments inflates every block of its input; with the output's blocks compressed on the GPU (deflate.hip)
+// that was the largest share of the host's CPU time that was left.
+//
+// DEFLATE is decoded one symbol after the other, so a block is one wave's work and the wave runs it like a scalar program:
+// the decoder's state (bit buffer, positions) is the same in every lane, every table look-up is one LDS address read by all
+// lanes and brought back with v_readfirstlane, every branch is uniform.  What the 64 lanes add is the copying: the block's
+// output lives in LDS (64 KB: a match is `length` bytes copied by `length` lanes from wherever the distance points, overlapping
+// copies included, src = (j mod distance)), the compressed input is staged through a 4 KB ring in LDS by all lanes, the tables
+// are built by all lanes (canonical codes from the code lengths: an 11-bit table for literals / lengths, 9 bits for
+// distances; the few longer codes are found by their length, first code and rank — no second-level tables), and the finished
+// block goes to global memory in whole dwords.  Two waves per CU (76 KB of LDS each), 512 blocks in flight.
+//
+// Whatever the kernel does not accept (a code that does not exist, a distance before the block, an output longer than the
+// ISIZE says, input that ends early) gets a status, and the caller inflates that block itself; the caller also checks every
+// block's CRC-32.  So a flaw here costs time, not data.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/pvc3_bgzf.h"
+
+extern thread_local char g_bgzf_error[256];		// deflate.hip
+
+namespace {
+
+constexpr unsigned WAVE = 64;
+constexpr unsigned LL_BITS = 11, D_BITS = 9, CL_BITS = 7;
+constexpr unsigned RING_WORDS = 1024;		// two halves of 512 dwords
+constexpr unsigned OUT_CAP = 65536;
+
+enum : uint32_t
+{
+	ST_OK = 0, ST_BAD_BLOCK_TYPE = 1, ST_BAD_STORED = 2, ST_BAD_CODE_LENGTHS = 3, ST_BAD_SYMBOL = 4, ST_BAD_DISTANCE = 5, ST_OUTPUT_OVERFLOW = 6,
+	ST_INPUT_OVERRUN = 7, ST_LENGTH_MISMATCH = 8, ST_TOO_LARGE = 9
+};
+
+struct code_info		// canonical decoding of the codes longer than the table's index
+{
+	uint32_t count[16], first[16], offset[16];
+};
+
+struct lds_t
+{
+	uint8_t out[OUT_CAP];
+	uint32_t ring[RING_WORDS];
+	uint16_t t_ll[1u << LL_BITS];		// symbol | length << 12; length 0: not in the table
+	uint16_t t_d[1u << D_BITS];
+	uint16_t t_cl[1u << CL_BITS];
+	uint16_t sorted_ll[288], sorted_d[32];
+	uint8_t lens[320];					// code lengths of the literal / length codes, then of the distance codes
+	code_info ll, d;
+	uint32_t flag;
+};
+
+__constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+
+// The compressed bytes as a stream of bits, least significant first.  The same state in every lane.
+struct bit_reader
+{
+	uint32_t *ring;
+	uint32_t const *src;		// the dword that holds the block's first byte
+	uint32_t n_words;			// dwords that hold bytes of the block
+	uint32_t next_word{};		// the next dword for the bit buffer
+	uint64_t buf{};
+	uint32_t cnt{};
+	uint32_t lead_bits{};
+
+	__device__ __forceinline__ void stage(uint32_t first_word)		// 512 dwords from first_word on into their half of the ring
+	{
+		for (uint32_t i = threadIdx.x; i < RING_WORDS / 2; i += WAVE)
+		{
+			uint32_t const w = first_word + i;
+			ring[w & (RING_WORDS - 1)] = (w < n_words) ? src[w] : 0;
+		}
+		__syncthreads();
+	}
+
+	__device__ void start(uint8_t const *data, uint32_t n_bytes, uint32_t *ring_)
+	{
+		ring = ring_;
+		uintptr_t const a = reinterpret_cast <uintptr_t>(data);
+		src = reinterpret_cast <uint32_t const *>(a & ~uintptr_t(3));
+		uint32_t const lead = (uint32_t) (a & 3);
+		n_words = (lead + n_bytes + 3) / 4;
+		next_word = 0; buf = 0; cnt = 0; lead_bits = 8 * lead;
+		__syncthreads();
+		stage(0);
+		stage(RING_WORDS / 2);
+		refill();
+		buf >>= lead_bits; cnt -= lead_bits;
+		refill();
+	}
+
+	// At least 33 bits in the buffer afterwards (zeros behind the end of the input: consumed_bits() tells).
+	__device__ __forceinline__ void refill()
+	{
+		while (cnt <= 32)
+		{
+			uint32_t const w = uni(ring[next_word & (RING_WORDS - 1)]);
+			buf |= uint64_t(w) << cnt;
+			cnt += 32;
+			++next_word;
+			if (0 == (next_word & (RING_WORDS / 2 - 1)))		// entered a half: the one behind it is free for what follows this one
+				stage(next_word + RING_WORDS / 2);
+		}
+	}
+
+	__device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t) buf & ((1u << n) - 1); }
+	__device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; }
+	__device__ __forceinline__ uint32_t take(uint32_t n) { uint32_t const v = peek(n); drop(n); return v; }
+	__device__ __forceinline__ uint64_t consumed_bits() const { return uint64_t(32) * next_word - cnt - lead_bits; }
+};
+
+// Canonical codes of lens[0 .. n) (RFC 1951 3.2.2) into a look-up table indexed by the next `bits` bits of the stream
+// (entry = symbol | length << 12) and, for longer codes, the symbols sorted by (length, symbol) with the first code and the
+// count of every length.  Returns false for an over-subscribed code.  Called by the whole wave.
+__device__ bool build_table(uint8_t const *lens, uint32_t n, uint32_t bits, uint16_t *table, uint16_t *sorted, code_info &ci, uint32_t *flag)
+{
+	unsigned const lane = threadIdx.x;
+	for (uint32_t i = lane; i < (1u << bits); i += WAVE) table[i] = 0;
+	if (lane < 16) ci.count[lane] = 0;
+	__syncthreads();
+	for (uint32_t s = lane; s < n; s += WAVE) if (lens[s]) atomicAdd(&ci.count[lens[s]], 1u);
+	__syncthreads();
+	if (0 == lane)
+	{
+		uint32_t code = 0, off = 0, left = 1;
+		bool ok = true;
+		for (uint32_t l = 1; l < 16; ++l)
+		{
+			left <<= 1;
+			uint32_t const c = ci.count[l];
+			if (c > left) ok = false;
+			left -= (c > left) ? left : c;
+			ci.first[l] = code; ci.offset[l] = off;
+			code = (code + c) << 1;
+			off += c;
+		}
+		ci.first[0] = 0; ci.offset[0] = 0;
+		*flag = ok ? 1u : 0u;
+	}
+	__syncthreads();
+	if (0 == *flag) return false;
+	for (uint32_t s = lane; s < n; s += WAVE)
+	{
+		uint32_t const l = lens[s];
+		if (0 == l) continue;
+		uint32_t k = 0;
+		for (uint32_t t = 0; t < s; ++t) k += (lens[t] == l);
+		uint32_t const code = ci.first[l] + k;
+		sorted[ci.offset[l] + k] = (uint16_t) s;
+		if (l <= bits)
+		{
+			uint32_t const r = __brev(code) >> (32 - l);
+			uint16_t const e = (uint16_t) (s | (l << 12));
+			for (uint32_t j = r; j < (1u << bits); j += (1u << l)) table[j] = e;
+		}
+	}
+	__syncthreads();
+	return true;
+}
+
+// The symbol whose code (longer than the table's index) begins the bit buffer, by length; false if there is none.
+__device__ __forceinline__ bool long_code(uint32_t low_bits, uint32_t from_len, uint16_t const *sorted, code_info const &ci, uint32_t &sym, uint32_t &len)
+{
+	for (uint32_t l = from_len; l < 16; ++l)
+	{
+		uint32_t const code = __brev(low_bits) >> (32 - l);		// the first l bits of the stream, most significant first
+		uint32_t const k = code - uni(ci.first[l]);
+		if (code >= uni(ci.first[l]) && k < uni(ci.count[l]))
+		{
+			sym = uni(sorted[uni(ci.offset[l]) + k]);
+			len = l;
+			return true;
+		}
+	}
+	return false;
+}
+
+__global__ __launch_bounds__(WAVE) void k_inflate_blocks(
+	uint8_t const *__restrict__ in, pvc3_bgzf_block const *__restrict__ blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t n_blocks)
+{
+	__shared__ lds_t L;
+	unsigned const lane = threadIdx.x;
+
+	for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x)
+	{
+		pvc3_bgzf_block const blk = blocks[b];
+		uint32_t const want = blk.out_len;
+		__syncthreads();		// the previous block's output has left LDS
+		if (want > OUT_CAP) { if (0 == lane) status[b] = ST_TOO_LARGE; continue; }
+		bit_reader br;
+		br.start(in + blk.in_off, blk.in_len, L.ring);
+		uint32_t pos = 0, st = ST_OK;
+
+		for (bool last = false; !last && ST_OK == st; )
+		{
+			br.refill();
+			last = 0 != br.take(1);
+			uint32_t const type = br.take(2);
+			if (0 == type)
+			{
+				// stored (RFC 1951 3.2.4): to the next byte boundary, LEN, NLEN, the bytes
+				br.drop((uint32_t) ((0 - br.consumed_bits()) & 7));
+				br.refill();
+				uint32_t const len = br.take(16), nlen = br.take(16);
+				if ((len ^ nlen) != 0xffff) { st = ST_BAD_STORED; break; }
+				if (pos + len > want) { st = ST_OUTPUT_OVERFLOW; break; }
+				for (uint32_t i = 0; i < len; ++i)
+				{
+					br.refill();
+					uint32_t const v = br.take(8);
+					if (0 == lane) L.out[pos + i] = (uint8_t) v;
+				}
+				pos += len;
+				continue;
+			}
+			if (3 == type) { st = ST_BAD_BLOCK_TYPE; break; }
+			uint32_t n_ll, n_d;
+			if (1 == type)
+			{
+				// fixed codes (3.2.6)
+				n_ll = 288; n_d = 30;
+				for (uint32_t s = lane; s < 288; s += WAVE) L.lens[s] = (uint8_t) ((s < 144) ? 8 : (s < 256) ? 9 : (s < 280) ? 7 : 8);
+				if (lane < 30) L.lens[288 + lane] = 5;
+				__syncthreads();
+			}
+			else
+			{
+				// dynamic codes (3.2.7)
+				br.refill();
+				n_ll = br.take(5) + 257; n_d = br.take(5) + 1;
+				uint32_t const n_cl = br.take(4) + 4;
+				uint64_t cl_lens = 0;		// three bits per symbol of the code length alphabet
+				for (uint32_t i = 0; i < n_cl; ++i)
+				{
+					br.refill();
+					cl_lens |= uint64_t(br.take(3)) << (3 * c_cl_order[i]);
+				}
+				if (n_ll > 286 || n_d > 30) { st = ST_BAD_CODE_LENGTHS; break; }
+				{
+					// the code length code: 19 symbols, one per lane
+					uint32_t const l = (lane < 19) ? (uint32_t) ((cl_lens >> (3 * lane)) & 7) : 0;
+					for (uint32_t i = lane; i < (1u << CL_BITS); i += WAVE) L.t_cl[i] = 0;
+					__syncthreads();
+					uint32_t code = 0, left = 1, mine = 0;
+					bool ok = true;
+					for (uint32_t k = 1; k < 8; ++k)
+					{
+						uint64_t const same = __ballot(l == k);
+						uint32_t const c = (uint32_t) __popcll(same);
+						left <<= 1;
+						if (c > left) ok = false;
+						left -= (c > left) ? left : c;
+						if (l == k) mine = code + (uint32_t) __popcll(same & ((uint64_t(1) << lane) - 1));
+						code = (code + c) << 1;
+					}
+					if (!ok) { st = ST_BAD_CODE_LENGTHS; break; }
+					if (l)
+					{
+						uint32_t const r = __brev(mine) >> (32 - l);
+						uint16_t const e = (uint16_t) (lane | (l << 12));
+						for (uint32_t j = r; j < (1u << CL_BITS); j += (1u << l)) L.t_cl[j] = e;
+					}
+					__syncthreads();
+				}
+				uint32_t const n = n_ll + n_d;
+				uint32_t i = 0, prev = 0;
+				while (i < n && ST_OK == st)
+				{
+					br.refill();
+					uint32_t const e = uni(L.t_cl[br.peek(CL_BITS)]);
+					uint32_t const l = e >> 12, sym = e & 0xfff;
+					if (0 == l) { st = ST_BAD_CODE_LENGTHS; break; }
+					br.drop(l);
+					uint32_t rep = 1, v = sym;
+					if (16 == sym) { if (0 == i) { st = ST_BAD_CODE_LENGTHS; break; } rep = 3 + br.take(2); v = prev; }
+					else if (17 == sym) { rep = 3 + br.take(3); v = 0; }
+					else if (18 == sym) { rep = 11 + br.take(7); v = 0; }
+					if (i + rep > n) { st = ST_BAD_CODE_LENGTHS; break; }
+					for (uint32_t r = lane; r < rep; r += WAVE) L.lens[i + r] = (uint8_t) v;
+					i += rep; prev = v;
+				}
+				if (ST_OK != st) break;
+				__syncthreads();
+				if (0 == L.lens[256]) { st = ST_BAD_CODE_LENGTHS; break; }		// no end-of-block code
+			}
+			uint8_t const *lens_d = L.lens + ((1 == type) ? 288 : n_ll);
+			if (!build_table(L.lens, n_ll, LL_BITS, L.t_ll, L.sorted_ll, L.ll, &L.flag) || !build_table(lens_d, n_d, D_BITS, L.t_d, L.sorted_d, L.d, &L.flag))
+			{ st = ST_BAD_CODE_LENGTHS; break; }
+
+			// ---- the symbols -----------------------------------------------------------------------------------------------------------
+			for (;;)
+			{
+				br.refill();
+				uint32_t e = uni(L.t_ll[br.peek(LL_BITS)]);
+				uint32_t l = e >> 12, sym = e & 0xfff;
+				if (0 == l && !long_code((uint32_t) br.buf, LL_BITS + 1, L.sorted_ll, L.ll, sym, l)) { st = ST_BAD_SYMBOL; break; }
+				br.drop(l);
+				if (sym < 256)
+				{
+					if (pos >= want) { st = ST_OUTPUT_OVERFLOW; break; }
+					if (0 == lane) L.out[pos] = (uint8_t) sym;
+					++pos;
+					continue;
+				}
+				if (256 == sym) break;
+				if (sym > 285) { st = ST_BAD_SYMBOL; break; }
+				uint32_t const ls = sym - 257;
+				uint32_t length;
+				if (ls < 8) length = 3 + ls;
+				else if (28 == ls) length = 258;
+				else { uint32_t const x = (ls - 4) >> 2; length = 3 + ((4 + ((ls - 4) & 3)) << x) + br.take(x); }
+				br.refill();
+				e = uni(L.t_d[br.peek(D_BITS)]);
+				l = e >> 12; uint32_t ds = e & 0xfff;
+				if (0 == l && !long_code((uint32_t) br.buf, D_BITS + 1, L.sorted_d, L.d, ds, l)) { st = ST_BAD_SYMBOL; break; }
+				br.drop(l);
+				if (ds > 29) { st = ST_BAD_SYMBOL; break; }
+				uint32_t dist;
+				if (ds < 4) dist = 1 + ds;
+				else { uint32_t const x = (ds >> 1) - 1; dist = 1 + ((2 + (ds & 1)) << x) + br.take(x); }
+				if (dist > pos) { st = ST_BAD_DISTANCE; break; }
+				if (pos + length > want) { st = ST_OUTPUT_OVERFLOW; break; }
+				// `length` bytes from `dist` back; a copy that overlaps itself repeats its first `dist` bytes
+				uint32_t const from = pos - dist;
+				if (dist >= length)
+					for (uint32_t j = lane; j < length; j += WAVE) L.out[pos + j] = L.out[from + j];
+				else if (1 == dist)
+				{
+					uint8_t const v = L.out[from];
+					for (uint32_t j = lane; j < length; j += WAVE) L.out[pos + j] = v;
+				}
+				else
+					for (uint32_t j = lane; j < length; j += WAVE) L.out[pos + j] = L.out[from + j % dist];
+				pos += length;
+			}
+		}
+		if (ST_OK == st && br.consumed_bits() > uint64_t(8) * blk.in_len) st = ST_INPUT_OVERRUN;
+		if (ST_OK == st && pos != want) st = ST_LENGTH_MISMATCH;
+		__syncthreads();
+		if (ST_OK == st)
+		{
+			// LDS -> global: bytes up to the first dword boundary of the destination, whole dwords, the bytes that are left
+			uint8_t *dst = out + blk.out_off;
+			uint32_t const head = (uint32_t) ((4 - (reinterpret_cast <uintptr_t>(dst) & 3)) & 3);
+			uint32_t const h = (head < want) ? head : want;
+			if (lane < h) dst[lane] = L.out[lane];
+			uint32_t const n_dw = (want - h) / 4;
+			uint32_t *dst32 = reinterpret_cast <uint32_t *>(dst + h);
+			uint32_t const *lds32 = reinterpret_cast <uint32_t const *>(L.out);
+			for (uint32_t i = lane; i < n_dw; i += WAVE)
+			{
+				uint32_t const o = h + 4 * i;		// byte offset in LDS; h is 0 .. 3
+				uint32_t const w0 = lds32[o >> 2], w1 = lds32[(o >> 2) + 1 < OUT_CAP / 4 ? (o >> 2) + 1 : (o >> 2)];
+				dst32[i] = __builtin_amdgcn_alignbyte(w1, w0, o & 3);
+			}
+			uint32_t const tail = h + 4 * n_dw;
+			if (tail + lane < want) dst[tail + lane] = L.out[tail + lane];
+		}
+		if (0 == lane) status[b] = st;
+	}
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------------
+
+int fail(int code, char const *what, hipError_t e = hipSuccess)
+{
+	if (hipSuccess != e) std::snprintf(g_bgzf_error, sizeof(g_bgzf_error), "%s: %s", what, hipGetErrorString(e));
+	else std::snprintf(g_bgzf_error, sizeof(g_bgzf_error), "%s", what);
+	return code;
+}
+
+enum { E_INVALID = -1, E_NOMEM = -2, E_HIP = -3, E_NO_DEVICE = -4, E_STATE = -6 };
+
+#define HIP_TRY(expr, what) do { hipError_t const e_ = (expr); if (hipSuccess != e_) return fail(E_HIP, what, e_); } while (0)
+
+constexpr size_t IN_SLACK = 4096;		// behind a slot's input: the kernel reads whole dwords
+
+}
+
+struct pvc3_bgzf_inflater
+{
+	int device{};
+	size_t max_in{}, max_out{};
+	uint32_t max_blocks{}, n_slots{}, grid_max{};
+	hipStream_t stream{};
+	uint8_t *d_in{}, *d_out{};
+	pvc3_bgzf_block *d_blocks{};
+	uint32_t *d_status{};
+	struct slot
+	{
+		uint8_t *h_in{}, *h_out{};
+		pvc3_bgzf_block *h_blocks{};
+		uint32_t *h_status{};
+		hipEvent_t start{}, stop{}, done{};
+		uint32_t n{};
+		bool busy{};
+	} slots[4];
+};
+
+extern "C" {
+
+void pvc3_bgzf_inflater_destroy(pvc3_bgzf_inflater *h)
+{
+	if (!h) return;
+	(void) hipSetDevice(h->device);
+	if (h->stream) (void) hipStreamSynchronize(h->stream);
+	for (auto &s : h->slots)
+	{
+		if (s.h_in) (void) hipHostFree(s.h_in);
+		if (s.h_out) (void) hipHostFree(s.h_out);
+		if (s.h_blocks) (void) hipHostFree(s.h_blocks);
+		if (s.h_status) (void) hipHostFree(s.h_status);
+		if (s.start) (void) hipEventDestroy(s.start);
+		if (s.stop) (void) hipEventDestroy(s.stop);
+		if (s.done) (void) hipEventDestroy(s.done);
+	}
+	if (h->d_in) (void) hipFree(h->d_in);
+	if (h->d_out) (void) hipFree(h->d_out);
+	if (h->d_blocks) (void) hipFree(h->d_blocks);
+	if (h->d_status) (void) hipFree(h->d_status);
+	if (h->stream) (void) hipStreamDestroy(h->stream);
+	delete h;
+}
+
+int pvc3_bgzf_inflater_create(int device, size_t max_in_bytes, size_t max_out_bytes, uint32_t max_blocks, uint32_t n_slots, pvc3_bgzf_inflater **out)
+{
+	if (!out || 0 == max_in_bytes || 0 == max_out_bytes || 0 == max_blocks || 0 == n_slots || n_slots > 4)
+		return fail(E_INVALID, "pvc3_bgzf_inflater_create: bad argument");
+	*out = nullptr;
+	int count = 0;
+	if (hipSuccess != hipGetDeviceCount(&count) || device < 0 || device >= count) return fail(E_NO_DEVICE, "pvc3_bgzf_inflater_create: no such GPU");
+	HIP_TRY(hipSetDevice(device), "hipSetDevice");
+	pvc3_bgzf_inflater *h = new (std::nothrow) pvc3_bgzf_inflater;
+	if (!h) return fail(E_NOMEM, "out of memory");
+	h->device = device; h->max_in = max_in_bytes; h->max_out = max_out_bytes; h->max_blocks = max_blocks; h->n_slots = n_slots;
+	int rc = 0;
+	auto check = [&](hipError_t e, char const *what) { if (0 == rc && hipSuccess != e) rc = fail((hipErrorOutOfMemory == e) ? E_NOMEM : E_HIP, what, e); };
+	hipDeviceProp_t prop;
+	check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+	if (0 == rc)
+	{
+		int per_cu = 0;
+		check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_blocks, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+		if (per_cu < 1) per_cu = 1;
+		h->grid_max = (uint32_t) prop.multiProcessorCount * (uint32_t) per_cu;
+	}
+	check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
+	if (0 == rc) check(hipMalloc((void **) &h->d_in, max_in_bytes + IN_SLACK), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_out, max_out_bytes), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_blocks, max_blocks * sizeof(pvc3_bgzf_block)), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_status, max_blocks * sizeof(uint32_t)), "hipMalloc");
+	for (uint32_t i = 0; i < n_slots && 0 == rc; ++i)
+	{
+		auto &s = h->slots[i];
+		check(hipHostMalloc((void **) &s.h_in, max_in_bytes + IN_SLACK, hipHostMallocDefault), "hipHostMalloc");
+		if (0 == rc) check(hipHostMalloc((void **) &s.h_out, max_out_bytes, hipHostMallocDefault), "hipHostMalloc");
+		if (0 == rc) check(hipHostMalloc((void **) &s.h_blocks, max_blocks * sizeof(pvc3_bgzf_block), hipHostMallocDefault), "hipHostMalloc");
+		if (0 == rc) check(hipHostMalloc((void **) &s.h_status, max_blocks * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+		if (0 == rc) check(hipEventCreate(&s.start), "hipEventCreate");
+		if (0 == rc) check(hipEventCreate(&s.stop), "hipEventCreate");
+		if (0 == rc) check(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
+	}
+	if (rc) { char keep[sizeof(g_bgzf_error)]; std::memcpy(keep, g_bgzf_error, sizeof(keep)); pvc3_bgzf_inflater_destroy(h); std::memcpy(g_bgzf_error, keep, sizeof(keep)); return rc; }
+	*out = h;
+	return 0;
+}
+
+uint8_t *pvc3_bgzf_inflater_input(pvc3_bgzf_inflater *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].h_in : nullptr; }
+uint8_t *pvc3_bgzf_inflater_output(pvc3_bgzf_inflater *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].h_out : nullptr; }
+pvc3_bgzf_block *pvc3_bgzf_inflater_blocks(pvc3_bgzf_inflater *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].h_blocks : nullptr; }
+
+int pvc3_bgzf_inflater_submit(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t n_blocks, size_t in_bytes, size_t out_bytes)
+{
+	if (!h || slot >= h->n_slots || 0 == n_blocks || n_blocks > h->max_blocks || in_bytes > h->max_in || out_bytes > h->max_out)
+		return fail(E_INVALID, "pvc3_bgzf_inflater_submit: bad argument");
+	auto &s = h->slots[slot];
+	if (s.busy) return fail(E_STATE, "pvc3_bgzf_inflater_submit: the slot has not been waited for");
+	for (uint32_t i = 0; i < n_blocks; ++i)
+	{
+		pvc3_bgzf_block const &b = s.h_blocks[i];
+		if (b.in_off > in_bytes || b.in_len > in_bytes - b.in_off || b.out_off > out_bytes || b.out_len > out_bytes - b.out_off)
+			return fail(E_INVALID, "pvc3_bgzf_inflater_submit: a block outside the slot's input or output");
+	}
+	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+	HIP_TRY(hipMemcpyAsync(h->d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(h->d_blocks, s.h_blocks, n_blocks * sizeof(pvc3_bgzf_block), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
+	uint32_t const grid = (n_blocks < h->grid_max) ? n_blocks : h->grid_max;
+	HIP_TRY(hipEventRecord(s.start, h->stream), "hipEventRecord");
+	hipLaunchKernelGGL(k_inflate_blocks, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, h->d_out, h->d_status, n_blocks);
+	HIP_TRY(hipGetLastError(), "k_inflate_blocks");
+	HIP_TRY(hipEventRecord(s.stop, h->stream), "hipEventRecord");
+	HIP_TRY(hipMemcpyAsync(s.h_status, h->d_status, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
+	if (out_bytes) HIP_TRY(hipMemcpyAsync(s.h_out, h->d_out, out_bytes, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
+	s.n = n_blocks; s.busy = true;
+	return 0;
+}
+
+int pvc3_bgzf_inflater_wait(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t const **status, float *kernel_ms)
+{
+	if (!h || slot >= h->n_slots) return fail(E_INVALID, "pvc3_bgzf_inflater_wait: bad argument");
+	auto &s = h->slots[slot];
+	if (!s.busy) return fail(E_STATE, "pvc3_bgzf_inflater_wait: nothing was submitted");
+	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+	s.busy = false;
+	HIP_TRY(hipEventSynchronize(s.done), "hipEventSynchronize");
+	if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, s.start, s.stop), "hipEventElapsedTime");
+	if (status) *status = s.h_status;
+	return 0;
+}
+
+}

@@ -101,16 +101,16 @@ def build(force=False, verbose=False):
 	return LIB
 
 
-BGZF_SRC = os.path.join(HERE, "bgzf", "deflate.hip")
+BGZF_SRC = [os.path.join(HERE, "bgzf", "deflate.hip"), os.path.join(HERE, "bgzf", "inflate.hip")]
 BGZF_LIB = os.path.join(HERE, "libpvc3_bgzf.so")
 
 
 def build_bgzf(force=False, verbose=False):
-	"""libpvc3_bgzf.so: the BGZF block compressor (panvc3_amd/bgzf/deflate.hip, C ABI include/pvc3_bgzf.h).  A library of its own:
+	"""libpvc3_bgzf.so: the BGZF block compressor (panvc3_amd/bgzf/deflate.hip and inflate.hip, C ABI include/pvc3_bgzf.h).  A library of its own:
 	the BAM writer's, not the projection's, and kernel_key() above stays the key of the projection kernels alone."""
 	os.makedirs(OBJ, exist_ok=True)
-	cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden", "-Wall", "-Wextra", "-shared", "-o", BGZF_LIB, BGZF_SRC]
-	key = _key([BGZF_SRC, os.path.join(HERE, "..", "include", "pvc3_bgzf.h")], cmd[1:])
+	cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden", "-Wall", "-Wextra", "-shared", "-o", BGZF_LIB] + BGZF_SRC
+	key = _key(BGZF_SRC + [os.path.join(HERE, "..", "include", "pvc3_bgzf.h")], cmd[1:])
 	marker = os.path.join(OBJ, "libpvc3_bgzf.so")
 	if force or not os.path.exists(BGZF_LIB) or _stale(marker, key):
 		if verbose:

@@ -192,3 +192,100 @@ def test_random_structures(gpu):
 		(s,) = gpu.deflate(data)
 		assert _inflate(s) == data
 		assert len(s) <= len(data) + 5
+
+
+# ---- the other direction: pvc3_bgzf_inflater_* (panvc3_amd/bgzf/inflate.hip) against zlib-made streams -------------------------------
+
+def _raw_deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+	c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+	return c.compress(data) + c.flush()
+
+
+@pytest.fixture(scope="module")
+def gpu_inflater():
+	from panvc3_amd import bgzf, build
+	build.build_bgzf()
+	c = bgzf.BlockInflater(0, max_in=24 << 20, max_out=48 << 20, max_blocks=2048, n_slots=2)
+	yield c
+	c.close()
+
+
+def _inflate_cases():
+	rng = np.random.default_rng(29)
+	text = bytes(rng.choice(np.frombuffer(b"etaoin shrdlu\n", dtype=np.uint8), size=65536))
+	cases = [b"", b"a", b"ab", b"abc" * 5, b"x" * 65536, bytes(range(256)) * 256, text, bytes(rng.integers(0, 256, size=65536, dtype=np.uint8)),
+			 bytes(rng.integers(0, 4, size=40000, dtype=np.uint8)), _bam_like(rng, 200)[:65280], b"ab" * 129 + b"c", b"q" * 257, b"q" * 258, b"q" * 259]
+	for size in (1, 2, 7, 8, 9, 100, 257, 258, 259, 273, 1000, 32768, 32769, 65280):
+		cases.append(bytes(rng.integers(0, 256, size=size, dtype=np.uint8)))
+		cases.append(bytes(rng.integers(97, 101, size=size, dtype=np.uint8)))
+	# copies at the distance limit, lengths around every code boundary
+	far = bytearray(rng.integers(0, 256, size=65536, dtype=np.uint8))
+	far[32768:33400] = far[:632]
+	far[40000:40258] = far[40000 - 32768:40000 - 32768 + 258]
+	cases.append(bytes(far))
+	return cases
+
+
+@pytest.mark.gpu
+def test_inflate_zlib_streams(gpu_inflater):
+	"""Streams of every block type (stored, fixed, dynamic; several blocks per stream), made by zlib at levels 0, 1, 6, 9 with the
+	default, fixed, Huffman-only and run-length strategies, at any alignment in the input."""
+	streams, datas = [], []
+	for data in _inflate_cases():
+		for level in (0, 1, 6, 9):
+			for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+				streams.append(_raw_deflate(data, level, strategy))
+				datas.append(data)
+	for gap in (0, 1, 2, 3, 5):
+		for first in range(0, len(streams), 1024):
+			part, want = streams[first:first + 1024], datas[first:first + 1024]
+			got, status, _ = gpu_inflater.inflate(part, [len(d) for d in want], gap=gap)
+			bad = [i for i in range(len(part)) if status[i] != 0 or got[i] != want[i]]
+			assert not bad, (gap, first, bad[:5], [int(status[i]) for i in bad[:5]])
+
+
+@pytest.mark.gpu
+def test_inflate_what_the_gpu_deflated(gpu, gpu_inflater):
+	rng = np.random.default_rng(31)
+	data = _bam_like(rng, 6000)
+	streams = gpu.deflate(data)
+	pieces = [data[i * 65280:(i + 1) * 65280] for i in range(len(streams))]
+	got, status, ms = gpu_inflater.inflate(streams, [len(p) for p in pieces], slot=1)
+	assert not status.any() and got == pieces and ms > 0
+
+
+@pytest.mark.gpu
+def test_inflate_refuses_what_is_wrong(gpu_inflater):
+	"""A damaged stream gets a status (or inflates to different bytes, which the caller's CRC check finds); its neighbours are not
+	touched.  Truncated input, a wrong ISIZE in either direction, flipped bytes, garbage."""
+	rng = np.random.default_rng(37)
+	data = _bam_like(rng, 200)[:60000]
+	good = _raw_deflate(data, 6)
+	damaged = [(good[:len(good) // 2], len(data)), (good[:-3], len(data)), (good, len(data) - 1), (good, len(data) + 1),
+			   (bytes(rng.integers(0, 256, size=5000, dtype=np.uint8)), 20000), (b"\x07" + good[1:], len(data)), (b"", 10)]
+	for k in range(20):
+		b = bytearray(good)
+		for _ in range(3):
+			b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+		damaged.append((bytes(b), len(data)))
+	streams, sizes = [], []
+	for s, n in damaged:
+		streams += [good, s]
+		sizes += [len(data), n]
+	streams.append(good); sizes.append(len(data))
+	got, status, _ = gpu_inflater.inflate(streams, sizes, gap=3)
+	for i in range(0, len(streams), 2):
+		assert status[i] == 0 and got[i] == data
+	for i, (s, n) in enumerate(damaged):
+		j = 2 * i + 1
+		try:
+			d = zlib.decompressobj(-15)
+			ref = d.decompress(s) + d.flush()
+			ok = d.eof and len(ref) == n and not d.unused_data
+		except zlib.error:
+			ok = False
+		if ok:
+			assert status[j] == 0 and got[j] == ref		# (a flipped bit may leave a valid stream of the same length)
+		else:
+			assert status[j] != 0 or got[j] != data[:n] or n != len(data)
+	assert status[1] != 0 and status[3] != 0 and status[5] != 0 and status[7] != 0

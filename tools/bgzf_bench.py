@@ -39,7 +39,32 @@ def main():
 	dt = time.perf_counter() - t
 	ok = all(zlib.decompress(s, -15) == data[i * bgzf.BLOCK:(i + 1) * bgzf.BLOCK] for i, s in enumerate(streams))
 	print("round trip of 256 blocks through zlib's inflate: %s (host buffers in and out: %.1f ms)" % ("ok" if ok else "MISMATCH", 1e3 * dt))
+	# the other direction: the same blocks inflated on the GPU, from zlib's streams (what samtools writes) and from the GPU's own
+	n_inf = min(args.blocks, 2048)
+	pieces = [data[i * bgzf.BLOCK:(i + 1) * bgzf.BLOCK] for i in range(n_inf)]
+	unique = {}
+	def level6(p):
+		if p not in unique:
+			c = zlib.compressobj(6, zlib.DEFLATED, -15)
+			unique[p] = c.compress(p) + c.flush()
+		return unique[p]
+	z_streams = [level6(p) for p in pieces]
+	own = comp.deflate(data[:n_inf * bgzf.BLOCK])
+	inf = bgzf.BlockInflater(0, max_in=n_inf * 66000, max_out=n_inf * bgzf.BLOCK, max_blocks=n_inf, n_slots=1)
+	for name, streams in (("zlib level 6", z_streams), ("the GPU's encoder", own)):
+		for count in (n_inf, 512, 128):
+			got, status, ms = inf.inflate(streams[:count], [len(p) for p in pieces[:count]], repeats=3)
+			good = (not status.any()) and got == pieces[:count]
+			n_out = sum(len(p) for p in pieces[:count])
+			print("GPU inflate, streams of %s: %d blocks, %.1f MB out of %.1f MB in %.3f ms = %.1f GB/s %s"
+				  % (name, count, n_out / 1e6, sum(len(x) for x in streams[:count]) / 1e6, ms, n_out / ms / 1e6, "ok" if good else "MISMATCH"))
+			ok = ok and good
+	inf.close()
 	sample = data[:64 * bgzf.BLOCK]
+	t = time.perf_counter()
+	for x in z_streams[:64]:
+		zlib.decompress(x, -15)
+	print("zlib inflate, one core: %.1f MB/s" % (len(sample) / (time.perf_counter() - t) / 1e6))
 	for level in (1, 6):
 		t = time.perf_counter()
 		n = sum(len(zlib.compress(sample[o:o + bgzf.BLOCK], level)) - 6 for o in range(0, len(sample), bgzf.BLOCK))

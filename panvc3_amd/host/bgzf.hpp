@@ -150,6 +150,25 @@ inline unsigned default_io_threads()
 	return std::min(hc, 32u);
 }
 
+// An inflater of whole groups of BGZF blocks that lives elsewhere (the GPU: gpu_deflate.hpp over include/pvc3_bgzf.h).  The reader
+// reads a piece of the file into input(), lists the piece's blocks (block: the layout of pvc3_bgzf_block), and finds their
+// bytes in output(slot) after wait(); a block whose status is not 0 it inflates itself.  Both calls throw io_error.
+class group_inflater
+{
+public:
+	struct block { uint64_t in_off; uint32_t in_len; uint32_t out_len; uint64_t out_off; };
+	virtual ~group_inflater() = default;
+	virtual unsigned slots() const = 0;					// at least 2: a piece is consumed while the next one is made
+	virtual std::size_t max_in() const = 0;
+	virtual std::size_t max_out() const = 0;
+	virtual std::size_t max_blocks() const = 0;
+	virtual uint8_t *input(unsigned slot) = 0;
+	virtual uint8_t *output(unsigned slot) = 0;
+	virtual block *blocks(unsigned slot) = 0;
+	virtual void submit(unsigned slot, std::size_t n_blocks, std::size_t in_bytes, std::size_t out_bytes) = 0;
+	virtual uint32_t const *wait(unsigned slot) = 0;
+};
+
 // Sequential byte source: a file or stdin.  BGZF input (BAM, bgzip'ed SAM) is inflated block-parallel; plain gzip and
 // uncompressed input go through zlib's gz* interface.
 class byte_reader
@@ -161,15 +180,20 @@ class byte_reader
 	std::vector <uint8_t> m_cbuf;		// compressed bytes not yet inflated (whole blocks + a partial tail)
 	std::size_t m_clen{};
 	// Inflated bytes: the piece being consumed and the next one, which a second thread reads and inflates meanwhile.
-	struct piece { std::vector <uint8_t> data; std::size_t len{}; };
+	// (ptr: data.data(), or the page-locked output of the group_inflater's slot `slot` when that made the piece)
+	struct piece { std::vector <uint8_t> data; uint8_t *ptr{}; std::size_t len{}; unsigned slot{}; };
 	piece m_cur, m_next;
+	std::atomic <group_inflater *> m_group{nullptr};		// attach(): pieces are inflated there from the next one on
+	group_inflater *m_group_in_use{};						// the producing thread's: the compressed bytes lie in its input(m_in_slot)
+	unsigned m_in_slot{};
+	uint64_t m_group_blocks{}, m_group_refused{};
 	std::size_t m_dpos{};
 	bool m_eof{};
 	bool m_started{};
 	std::future <bool> m_ahead;
 
 	// Compressed bytes read (and inflated) per piece; PVC3_BGZF_CHUNK overrides it so that a test can make records straddle pieces.
-	std::size_t const CHUNK = []() -> std::size_t {
+	std::size_t CHUNK = []() -> std::size_t {
 		char const *e = std::getenv("PVC3_BGZF_CHUNK");
 		std::size_t const v = e ? (std::size_t) std::strtoull(e, nullptr, 10) : 0;
 		return v ? v : (std::size_t) (32u << 20);
@@ -197,16 +221,55 @@ class byte_reader
 		throw io_error("corrupt BGZF stream (no BC field)");
 	}
 
-	// The next piece of the file into `dst` (false at the end); touches only m_raw, m_cbuf, m_clen and m_eof.
+	// One block on this thread: the block's own decoder first (fast_inflate.hpp); whatever it does not accept, or whose checksum
+	// does not come out, goes through zlib, which then decides what is corrupt.
+	static void inflate_block(uint8_t const *src, std::size_t in_len, uint8_t *dst, std::size_t out_len, uint32_t crc)
+	{
+		if (0 == out_len) return;
+		static thread_local fast_inflater quick;
+		if (quick.inflate(src, in_len, dst, out_len) && fast_crc32(0, dst, out_len) == crc)
+			return;
+		z_stream zs{};
+		if (Z_OK != inflateInit2(&zs, -15)) throw io_error("inflateInit2 failed");
+		zs.next_in = const_cast <uint8_t *>(src); zs.avail_in = (uInt) in_len;
+		zs.next_out = dst; zs.avail_out = (uInt) out_len;
+		int const rc = inflate(&zs, Z_FINISH);
+		inflateEnd(&zs);
+		if (Z_STREAM_END != rc || zs.total_out != out_len) throw io_error("corrupt BGZF block");
+		if (fast_crc32(0, dst, out_len) != crc) throw io_error("BGZF block checksum mismatch");
+	}
+
+	// The next piece of the file into `dst` (false at the end); touches only m_raw, m_cbuf, m_clen, m_eof and m_group_in_use.
 	bool produce(piece &dst)
 	{
 		dst.len = 0;
+		// A group_inflater attached since the last piece: the compressed bytes at hand move to its page-locked input, where
+		// the file is read to from now on.
+		if (group_inflater *g = m_group.load(std::memory_order_acquire); g && g != m_group_in_use)
+		{
+			// (pieces of at most half the inflater's input from here on: the page-locked output is sized for them)
+			CHUNK = std::min(CHUNK, g->max_in() / 2);
+			if (CHUNK >= (1u << 16) && m_clen + CHUNK + (1u << 17) <= g->max_in())
+			{
+				std::memcpy(g->input(dst.slot), m_cbuf.data(), m_clen);
+				m_group_in_use = g; m_in_slot = dst.slot;
+			}
+			else
+				m_group.store(nullptr);		// (a piece would not fit: PVC3_BGZF_CHUNK larger than the inflater was made for)
+		}
 		while (0 == dst.len)
 		{
+			group_inflater *g = m_group_in_use;
+			if (!g) m_cbuf.resize(std::max(m_cbuf.size(), m_clen + CHUNK));
+			if (g && m_in_slot != dst.slot)		// the input of a slot goes with its output: what the last piece left over moves along
+			{
+				std::memcpy(g->input(dst.slot), g->input(m_in_slot), m_clen);
+				m_in_slot = dst.slot;
+			}
+			uint8_t *cbuf = g ? g->input(m_in_slot) : m_cbuf.data();
 			if (!m_eof)
 			{
-				m_cbuf.resize(std::max(m_cbuf.size(), m_clen + CHUNK));
-				std::size_t const got = std::fread(m_cbuf.data() + m_clen, 1, CHUNK, m_raw);
+				std::size_t const got = std::fread(cbuf + m_clen, 1, CHUNK, m_raw);
 				if (got < CHUNK) { if (std::ferror(m_raw)) throw io_error("read error"); m_eof = true; }
 				m_clen += got;
 			}
@@ -215,12 +278,12 @@ class byte_reader
 			for (;;)
 			{
 				std::size_t data_off = 0;
-				std::size_t const bs = block_size(m_cbuf.data() + off, m_clen - off, data_off);
+				std::size_t const bs = block_size(cbuf + off, m_clen - off, data_off);
 				if (0 == bs || off + bs > m_clen) break;
 				if (bs < data_off + 8) throw io_error("corrupt BGZF stream (short block)");
 				uint32_t crc, isize;
-				std::memcpy(&crc, m_cbuf.data() + off + bs - 8, 4);
-				std::memcpy(&isize, m_cbuf.data() + off + bs - 4, 4);
+				std::memcpy(&crc, cbuf + off + bs - 8, 4);
+				std::memcpy(&isize, cbuf + off + bs - 4, 4);
 				blocks.push_back(block{off + data_off, bs - data_off - 8, out, isize, crc});
 				out += isize; off += bs;
 			}
@@ -229,27 +292,43 @@ class byte_reader
 				if (m_eof) { if (m_clen) throw io_error("truncated BGZF stream"); return false; }
 				continue;
 			}
-			if (dst.data.size() < out) dst.data.resize(out);		// grows only: no zero-fill per piece
 			dst.len = out;
-			uint8_t *dbuf = dst.data.data();
-			parallel_for(blocks.size(), m_threads, [&](std::size_t i) {
-				block const &b = blocks[i];
-				if (0 == b.out_len) return;
-				// The block's own decoder first (fast_inflate.hpp); whatever it does not accept, or whose checksum does not come
-				// out, goes through zlib, which then decides what is corrupt.
-				static thread_local fast_inflater quick;
-				if (quick.inflate(m_cbuf.data() + b.in_off, b.in_len, dbuf + b.out_off, b.out_len) && fast_crc32(0, dbuf + b.out_off, b.out_len) == b.crc)
-					return;
-				z_stream zs{};
-				if (Z_OK != inflateInit2(&zs, -15)) throw io_error("inflateInit2 failed");
-				zs.next_in = m_cbuf.data() + b.in_off; zs.avail_in = (uInt) b.in_len;
-				zs.next_out = dbuf + b.out_off; zs.avail_out = (uInt) b.out_len;
-				int const rc = inflate(&zs, Z_FINISH);
-				inflateEnd(&zs);
-				if (Z_STREAM_END != rc || zs.total_out != b.out_len) throw io_error("corrupt BGZF block");
-				if (fast_crc32(0, dbuf + b.out_off, b.out_len) != b.crc) throw io_error("BGZF block checksum mismatch");
-			});
-			std::memmove(m_cbuf.data(), m_cbuf.data() + off, m_clen - off);
+			if (g && out <= g->max_out() && blocks.size() <= g->max_blocks())
+			{
+				// The piece's blocks on the GPU, their bytes in the page-locked output of this piece's slot; what the GPU refuses
+				// is inflated here, and every block's checksum is verified here.
+				group_inflater::block *gb = g->blocks(dst.slot);
+				for (std::size_t i = 0; i < blocks.size(); ++i)
+					gb[i] = group_inflater::block{blocks[i].in_off, (uint32_t) blocks[i].in_len, (uint32_t) blocks[i].out_len, blocks[i].out_off};
+				g->submit(dst.slot, blocks.size(), off, out);
+				uint32_t const *status = g->wait(dst.slot);
+				uint8_t *dbuf = g->output(dst.slot);
+				dst.ptr = dbuf;
+				std::atomic <uint64_t> refused{0};
+				std::size_t const n_tasks = std::min <std::size_t>(blocks.size(), 8 * (std::size_t) m_threads);
+				parallel_for(n_tasks, m_threads, [&](std::size_t t) {
+					for (std::size_t i = blocks.size() * t / n_tasks; i < blocks.size() * (t + 1) / n_tasks; ++i)
+					{
+						block const &b = blocks[i];
+						if (0 == b.out_len) continue;
+						if (0 == status[i] && fast_crc32(0, dbuf + b.out_off, b.out_len) == b.crc) continue;
+						++refused;
+						inflate_block(cbuf + b.in_off, b.in_len, dbuf + b.out_off, b.out_len, b.crc);
+					}
+				});
+				m_group_blocks += blocks.size(); m_group_refused += refused.load();
+			}
+			else
+			{
+				if (dst.data.size() < out) dst.data.resize(out);		// grows only: no zero-fill per piece
+				uint8_t *dbuf = dst.data.data();
+				dst.ptr = dbuf;
+				parallel_for(blocks.size(), m_threads, [&](std::size_t i) {
+					block const &b = blocks[i];
+					inflate_block(cbuf + b.in_off, b.in_len, dbuf + b.out_off, b.out_len, b.crc);
+				});
+			}
+			std::memmove(cbuf, cbuf + off, m_clen - off);
 			m_clen -= off;
 			if (0 == dst.len && m_eof && 0 == m_clen) return false;		// only the EOF marker was left
 		}
@@ -284,6 +363,12 @@ public:
 
 	void set_threads(unsigned n) { m_threads = n ? n : 1; }
 
+	// From the next piece on the blocks of BGZF input are inflated by `g` (which must outlive this reader's use).  May be called
+	// from another thread than the one that reads.
+	void attach(group_inflater *g) { m_group.store(g, std::memory_order_release); }
+	uint64_t group_blocks() const { return m_group_blocks; }
+	uint64_t group_refused() const { return m_group_refused; }
+
 	void open(char const *path)		// nullptr or "-" = stdin
 	{
 		close();
@@ -302,6 +387,7 @@ public:
 			{
 				std::rewind(f);
 				m_raw = f; m_clen = 0; m_eof = false; m_cur.len = 0; m_dpos = 0; m_started = false;
+				m_cur.slot = 0; m_next.slot = 1; m_group_in_use = nullptr;
 				return;
 			}
 			std::fclose(f);
@@ -329,7 +415,7 @@ public:
 			{
 				if (m_dpos == m_cur.len && !refill()) break;
 				std::size_t const take = std::min(n - got, m_cur.len - m_dpos);
-				std::memcpy((char *) dst + got, m_cur.data.data() + m_dpos, take);
+				std::memcpy((char *) dst + got, m_cur.ptr + m_dpos, take);
 				m_dpos += take; got += take;
 			}
 			return got;
@@ -351,7 +437,7 @@ public:
 	{
 		if (!m_raw) return false;
 		if (m_dpos == m_cur.len && !refill()) return false;
-		p = m_cur.data.data() + m_dpos;
+		p = m_cur.ptr + m_dpos;
 		n = m_cur.len - m_dpos;
 		return true;
 	}
@@ -375,7 +461,7 @@ public:
 		{
 			if (m_dpos == m_cur.len && !refill()) break;
 			std::size_t const take = std::min(n - got, m_cur.len - m_dpos);
-			uint8_t const *p = m_cur.data.data() + m_dpos;
+			uint8_t const *p = m_cur.ptr + m_dpos;
 			dst.insert(dst.end(), p, p + take);
 			m_dpos += take; got += take;
 		}
@@ -393,7 +479,7 @@ public:
 			{
 				if (m_dpos == m_cur.len && !refill()) break;
 				any = true;
-				uint8_t const *b = m_cur.data.data() + m_dpos;
+				uint8_t const *b = m_cur.ptr + m_dpos;
 				std::size_t const left = m_cur.len - m_dpos;
 				uint8_t const *nl = (uint8_t const *) std::memchr(b, '\n', left);
 				if (nl)
@@ -429,7 +515,7 @@ public:
 		if (m_raw)
 		{
 			if (m_dpos == m_cur.len && !refill()) return -1;
-			return m_cur.data[m_dpos];
+			return m_cur.ptr[m_dpos];
 		}
 		int const c = gzgetc(m_file);
 		if (c >= 0) gzungetc(c, m_file);

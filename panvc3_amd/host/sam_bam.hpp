@@ -540,6 +540,9 @@ public:
 	sam_header header;
 
 	void set_threads(unsigned n) { m_in.set_threads(n); }
+	void attach(group_inflater *g) { m_in.attach(g); }		// BGZF input inflated elsewhere from the next piece on (byte_reader::attach)
+	uint64_t group_blocks() const { return m_in.group_blocks(); }
+	uint64_t group_refused() const { return m_in.group_refused(); }
 
 	void open(char const *path, bool bam)
 	{

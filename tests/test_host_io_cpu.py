@@ -117,3 +117,50 @@ def test_writer_with_a_group_deflater(tmp_path):
 				pos += bsize + 1
 			cuts[(mode, slots)] = sizes
 		assert len(set(map(tuple, cuts.values()))) == 1
+
+
+def test_reader_with_a_group_inflater(tmp_path):
+	"""byte_reader's group path (the GPU inflater's slot interface) with a host stand-in: the same bytes whether the pieces are
+	inflated by the group from the start, from some point on, or not at all; blocks the group refuses are inflated by the
+	reader, blocks it returns wrong bytes for are found by their checksum and inflated again; small pieces make records and
+	blocks straddle them; a damaged block is an error whoever inflates."""
+	import re
+	import sys
+	import numpy as np
+	from panvc3_amd import build
+	build.build_cpp_tests()
+	tool = os.path.join(ROOT, "bin", "test_group_reader_test")
+	sys.path.insert(0, os.path.join(ROOT, "tests"))
+	import bamio
+	rng = np.random.default_rng(19)
+	data = bytes(np.repeat(rng.integers(0, 20, size=400000, dtype=np.uint8), rng.integers(1, 6, size=400000)))[:1_000_003]
+	blocks, pos = [], 0
+	while pos < len(data):
+		n = int(rng.integers(1, 65281))
+		blocks.append(bamio._bgzf_block(data[pos:pos + n]))
+		pos += n
+		if 0 == len(blocks) % 7:
+			blocks.append(bamio._bgzf_block(b""))		# empty blocks in the middle of the file are legal
+	path = tmp_path / "in.bgzf"
+	path.write_bytes(b"".join(blocks) + bamio._bgzf_block(b""))
+	for chunk in (None, "70000", "200000"):
+		env = dict(os.environ, PVC3_BGZF_CHUNK=chunk) if chunk else None
+		for mode in ("plain", "group", "late", "refuse", "garble"):
+			p = subprocess.run([tool, str(path), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+			assert 0 == p.returncode, p.stderr
+			assert p.stdout == data, (chunk, mode)
+			through, here = (int(x) for x in re.findall(r"(\d+)", p.stderr.decode())[:2])
+			if "plain" == mode:
+				assert 0 == through
+			elif chunk is None:
+				pass		# (pieces of 32 MB do not fit the stand-in's input: the reader keeps inflating itself)
+			elif "late" != mode:		# (attached late, the pieces read ahead by then may have been the whole file)
+				assert through > 0 and (here > 0) == (mode in ("refuse", "garble"))
+	# one flipped bit in the middle of a block's data: an error in every mode
+	raw = bytearray(path.read_bytes())
+	raw[len(blocks[0]) + len(blocks[1]) // 2] ^= 4
+	bad = tmp_path / "bad.bgzf"
+	bad.write_bytes(bytes(raw))
+	for mode in ("plain", "group", "refuse"):
+		p = subprocess.run([tool, str(bad), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, PVC3_BGZF_CHUNK="200000"), timeout=120)
+		assert 0 != p.returncode and (b"corrupt" in p.stderr or b"checksum" in p.stderr)

@@ -384,14 +384,15 @@ def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_m
 		assert gzip.decompress(raw)[-200000:] == gzip.decompress(base)[-200000:], name
 		assert (b"BGZF on the GPU" in pg.stderr) == (name == "groups.bam"), name
 		if name == "groups.bam":
-			assert b" groups" in pg.stderr and int(pg.stderr.split(b"blocks in ")[1].split()[0]) >= 2
+			assert b" groups" in pg.stderr and int(pg.stderr.split(b"BGZF on the GPU: ")[1].split(b"blocks in ")[1].split()[0]) >= 2
 	# BAM in (the records are framed in place inside the inflated pieces of the file; pieces of 3 000 compressed bytes make
 	# them straddle), small batches, SAM out: the same records again
 	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "alignments.sam", "-b", "-o", "alignments.bam"], cwd=tmp_path)
-	for env in (None, {"PVC3_BGZF_CHUNK": "3000"}):
+	for env, extra in ((None, []), ({"PVC3_BGZF_CHUNK": "3000"}, []), ({"PVC3_BGZF_CHUNK": "3000"}, ["--bgzf-inflate=gpu"]), ({"PVC3_BGZF_CHUNK": "70000"}, ["--debugging-output", "--bgzf-inflate=gpu"])):
 		p3 = _run([tools["panvc3_project_alignments"], "-a", "alignments.bam", "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-u", "order.txt",
-				   "--record-index-tag=XI", "-t", "XS", "-t", "YS", "--batch-size=64"], cwd=tmp_path, env=env)
+				   "--record-index-tag=XI", "-t", "XS", "-t", "YS", "--batch-size=64"] + extra, cwd=tmp_path, env=env)
 		assert [l for l in p3.stdout.decode().split("\n") if l and not l.startswith("@")] == expect
+		assert (b"BGZF input on the GPU" in p3.stderr) == bool(extra and extra[0] == "--debugging-output")
 	text, refs, got = bamio.read_bam(tmp_path / "out.bam")
 	assert refs == [("test", 10000)]
 	for g in got[:50]:

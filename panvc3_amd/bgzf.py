@@ -24,7 +24,7 @@ def lib():
 	global _L
 	if _L is None:
 		from . import build
-		path = build.BGZF_LIB
+		path = os.environ.get("PVC3_BGZF_LIB", build.BGZF_LIB)		# (an experimental build of the kernels: tools/calib)
 		if not os.path.exists(path):
 			raise RuntimeError("libpvc3_bgzf.so has not been built (python -m panvc3_amd.build)")
 		L = C.CDLL(path)

@@ -5,13 +5,19 @@
 // that was the largest share of the host's CPU time that was left.
 //
 // DEFLATE is decoded one symbol after the other, so a block is one wave's work and the wave runs it like a scalar program:
-// the decoder's state (bit buffer, positions) is the same in every lane, every table look-up is one LDS address read by all
-// lanes and brought back with v_readfirstlane, every branch is uniform.  What the 64 lanes add is the copying: the block's
-// output lives in LDS (64 KB: a match is `length` bytes copied by `length` lanes from wherever the distance points, overlapping
-// copies included, src = (j mod distance)), the compressed input is staged through a 4 KB ring in LDS by all lanes, the tables
-// are built by all lanes (canonical codes from the code lengths: an 11-bit table for literals / lengths, 9 bits for
-// distances; the few longer codes are found by their length, first code and rank — no second-level tables), and the finished
-// block goes to global memory in whole dwords.  Two waves per CU (76 KB of LDS each), 512 blocks in flight.
+// the decoder's state (a bit window of 97 .. 128 bits, positions) is the same in every lane and lives in scalar registers,
+// every branch is uniform.  What the 64 lanes add:
+//   look-ups   lane k looks up the literal / length code and the distance code that would begin at bit k of the window; a scalar
+//              walk then follows the codes that do begin somewhere (o, o + length of the code at o, ...) and takes the entries
+//              out of the lanes with v_readlane: a run of literals and the matches between them for one trip to LDS;
+//   copying    the last 32 KB of the output live in a ring in LDS (a match reaches no further back): a match is `length` bytes
+//              copied by `length` lanes, overlapping copies included (src = j mod distance); what lies behind the ring goes to
+//              global memory 16 KB at a time, in whole dwords;
+//   staging    the compressed input comes through a 2 KB ring in LDS, 64 dwords of it at a time through the lanes of a register;
+//   tables     canonical codes from the code lengths by all lanes: a 10-bit table for literals / lengths, 9 bits for distances;
+//              the few longer codes are found by their length, first code and rank — no second-level tables.
+// 39 KB of LDS per wave: four waves per CU, 1 024 blocks in flight.  The kernel is bound by the issue of its scalar
+// instructions (about 35 per symbol), which is why every wave more per SIMD counts.
 //
 // Whatever the kernel does not accept (a code that does not exist, a distance before the block, an output longer than the
 // ISIZE says, input that ends early) gets a status, and the caller inflates that block itself; the caller also checks every
@@ -30,9 +36,11 @@ extern thread_local char g_bgzf_error[256];		// deflate.hip
 namespace {
 
 constexpr unsigned WAVE = 64;
-constexpr unsigned LL_BITS = 11, D_BITS = 9, CL_BITS = 7;
-constexpr unsigned RING_WORDS = 1024;		// two halves of 512 dwords
-constexpr unsigned OUT_CAP = 65536;
+constexpr unsigned LL_BITS = 10, D_BITS = 9, CL_BITS = 7;
+constexpr unsigned RING_WORDS = 512;		// two halves of 256 dwords
+constexpr unsigned OUT_CAP = 65536;			// ISIZE at most
+constexpr unsigned OUT_RING = 32768;		// the last 32 KB of the output: as far back as a match can reach
+constexpr unsigned OUT_HALF = OUT_RING / 2;
 
 enum : uint32_t
 {
@@ -47,7 +55,7 @@ struct code_info		// canonical decoding of the codes longer than the table's ind
 
 struct lds_t
 {
-	uint8_t out[OUT_CAP];
+	uint8_t out[OUT_RING];
 	uint32_t ring[RING_WORDS];
 	uint16_t t_ll[1u << LL_BITS];		// symbol | length << 12; length 0: not in the table
 	uint16_t t_d[1u << D_BITS];
@@ -60,20 +68,26 @@ struct lds_t
 
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+#define OUTB(i) L.out[(i) & (OUT_RING - 1)]
+
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
 
-// The compressed bytes as a stream of bits, least significant first.  The same state in every lane.
+// The compressed bytes as a stream of bits, least significant first: a window of 97 .. 128 bits in two 64-bit halves, the same in
+// every lane (the compiler keeps it in scalar registers).  The ring's dwords are fetched 64 at a time, one per lane, and handed
+// to the window with v_readlane, so that a refill is not a trip to LDS.
 struct bit_reader
 {
 	uint32_t *ring;
 	uint32_t const *src;		// the dword that holds the block's first byte
 	uint32_t n_words;			// dwords that hold bytes of the block
-	uint32_t next_word{};		// the next dword for the bit buffer
-	uint64_t buf{};
-	uint32_t cnt{};
+	uint32_t next_word{};		// the next dword for the window
+	uint32_t batch_first{};		// lane j holds dword batch_first + j
+	uint32_t batch{};
+	uint64_t lo{}, hi{};		// bits 0 .. 63 and 64 .. 127 of the window
+	uint32_t valid{};
 	uint32_t lead_bits{};
 
-	__device__ __forceinline__ void stage(uint32_t first_word)		// 512 dwords from first_word on into their half of the ring
+	__device__ __forceinline__ void stage(uint32_t first_word)		// half a ring of dwords from first_word on
 	{
 		for (uint32_t i = threadIdx.x; i < RING_WORDS / 2; i += WAVE)
 		{
@@ -83,6 +97,12 @@ struct bit_reader
 		__syncthreads();
 	}
 
+	__device__ __forceinline__ void load_batch()
+	{
+		batch_first = next_word;
+		batch = ring[(next_word + threadIdx.x) & (RING_WORDS - 1)];		// staged: the ring holds 256 dwords from next_word on at least
+	}
+
 	__device__ void start(uint8_t const *data, uint32_t n_bytes, uint32_t *ring_)
 	{
 		ring = ring_;
@@ -90,33 +110,50 @@ struct bit_reader
 		src = reinterpret_cast <uint32_t const *>(a & ~uintptr_t(3));
 		uint32_t const lead = (uint32_t) (a & 3);
 		n_words = (lead + n_bytes + 3) / 4;
-		next_word = 0; buf = 0; cnt = 0; lead_bits = 8 * lead;
+		next_word = 0; lo = 0; hi = 0; valid = 0; lead_bits = 8 * lead;
 		__syncthreads();
 		stage(0);
 		stage(RING_WORDS / 2);
+		load_batch();
 		refill();
-		buf >>= lead_bits; cnt -= lead_bits;
+		drop(lead_bits);
 		refill();
 	}
 
-	// At least 33 bits in the buffer afterwards (zeros behind the end of the input: consumed_bits() tells).
+	// At least 97 bits in the window afterwards (zeros behind the end of the input: consumed_bits() tells).
 	__device__ __forceinline__ void refill()
 	{
-		while (cnt <= 32)
+		while (valid <= 96)
 		{
-			uint32_t const w = uni(ring[next_word & (RING_WORDS - 1)]);
-			buf |= uint64_t(w) << cnt;
-			cnt += 32;
+			if (next_word - batch_first >= WAVE) load_batch();
+			uint64_t const w = (uint32_t) __builtin_amdgcn_readlane((int) batch, (int) (next_word - batch_first));
+			if (valid >= 64) hi |= w << (valid - 64);
+			else { lo |= w << valid; if (valid > 32) hi |= w >> (64 - valid); }
+			valid += 32;
 			++next_word;
 			if (0 == (next_word & (RING_WORDS / 2 - 1)))		// entered a half: the one behind it is free for what follows this one
 				stage(next_word + RING_WORDS / 2);
 		}
 	}
 
-	__device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t) buf & ((1u << n) - 1); }
-	__device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; }
+	__device__ __forceinline__ uint32_t low32() const { return (uint32_t) lo; }
+	__device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t) lo & ((1u << n) - 1); }
+	// n (at most 13) bits from bit `at` (below 96) on
+	__device__ __forceinline__ uint32_t peek_at(uint32_t at, uint32_t n) const
+	{
+		uint64_t const v = (at >= 64) ? (hi >> (at - 64)) : (0 == at) ? lo : ((lo >> at) | (hi << (64 - at)));
+		return (uint32_t) v & ((1u << n) - 1);
+	}
+	__device__ __forceinline__ void drop(uint32_t n)		// n below 128
+	{
+		valid -= n;
+		if (n >= 64) { lo = hi; hi = 0; n -= 64; }
+		if (n) { lo = (lo >> n) | (hi << (64 - n)); hi >>= n; }
+	}
 	__device__ __forceinline__ uint32_t take(uint32_t n) { uint32_t const v = peek(n); drop(n); return v; }
-	__device__ __forceinline__ uint64_t consumed_bits() const { return uint64_t(32) * next_word - cnt - lead_bits; }
+	// the 64 bits that begin at bit `k` (below 64) of the window
+	__device__ __forceinline__ uint64_t from_bit(uint32_t k) const { return (0 == k) ? lo : ((lo >> k) | (hi << (64 - k))); }
+	__device__ __forceinline__ uint64_t consumed_bits() const { return uint64_t(32) * next_word - valid - lead_bits; }
 };
 
 // Canonical codes of lens[0 .. n) (RFC 1951 3.2.2) into a look-up table indexed by the next `bits` bits of the stream
@@ -200,6 +237,31 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 		bit_reader br;
 		br.start(in + blk.in_off, blk.in_len, L.ring);
 		uint32_t pos = 0, st = ST_OK;
+		// The output's last 32 KB live in LDS (a match reaches no further back); what lies behind goes to global memory half a
+		// ring at a time, before the bytes that will take its place are written.
+		uint32_t flushed = 0;
+		uint8_t *const dst = out + blk.out_off;
+		auto store_region = [&](uint32_t start, uint32_t n) {		// output bytes start .. start + n from the ring (they do not wrap)
+			uint8_t *g = dst + start;
+			uint32_t const ro = start & (OUT_RING - 1);
+			uint32_t const head = (uint32_t) ((4 - (reinterpret_cast <uintptr_t>(g) & 3)) & 3);
+			uint32_t const h = (head < n) ? head : n;
+			if (lane < h) g[lane] = L.out[ro + lane];
+			uint32_t const n_dw = (n - h) / 4;
+			uint32_t *g32 = reinterpret_cast <uint32_t *>(g + h);
+			uint32_t const *lds32 = reinterpret_cast <uint32_t const *>(L.out);
+			for (uint32_t i = lane; i < n_dw; i += WAVE)
+			{
+				uint32_t const x = ro + h + 4 * i;
+				uint32_t const w0 = lds32[x >> 2], w1 = lds32[((x >> 2) + 1) & (OUT_RING / 4 - 1)];
+				g32[i] = __builtin_amdgcn_alignbyte(w1, w0, x & 3);
+			}
+			uint32_t const tail = h + 4 * n_dw;
+			if (tail + lane < n) g[tail + lane] = L.out[ro + tail + lane];
+		};
+		auto make_room = [&]() {		// before up to 322 bytes are written at pos
+			if (pos + 322 > flushed + OUT_RING) { store_region(flushed, OUT_HALF); flushed += OUT_HALF; }
+		};
 
 		for (bool last = false; !last && ST_OK == st; )
 		{
@@ -218,9 +280,10 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 				{
 					br.refill();
 					uint32_t const v = br.take(8);
-					if (0 == lane) L.out[pos + i] = (uint8_t) v;
+					make_room();
+					if (0 == lane) OUTB(pos) = (uint8_t) v;
+					++pos;
 				}
-				pos += len;
 				continue;
 			}
 			if (3 == type) { st = ST_BAD_BLOCK_TYPE; break; }
@@ -298,21 +361,88 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 			{ st = ST_BAD_CODE_LENGTHS; break; }
 
 			// ---- the symbols -----------------------------------------------------------------------------------------------------------
-			for (;;)
+			// One pass = one trip to LDS: lane k looks up the literal / length code and the distance code that would begin at bit
+			// k of the window; then a scalar walk follows the codes that do begin somewhere — o, o + length of the code at o, ... —
+			// taking the entries out of the lanes with v_readlane: a run of literals (literal i kept by lane i, one LDS store) and
+			// the matches between them, until the offsets leave the lanes.  Codes longer than the tables' index (rare) and whatever
+			// is wrong go through the one-token path behind the walk.
+			for (bool end_of_block = false; !end_of_block && ST_OK == st; )
 			{
+				br.refill();
+				uint64_t const mine = br.from_bit(lane);
+				uint32_t const e_ll = L.t_ll[(uint32_t) mine & ((1u << LL_BITS) - 1)], e_d = L.t_d[(uint32_t) mine & ((1u << D_BITS) - 1)];
+				uint32_t o = 0, n_lit = 0;
+				int lits = 0;
+				bool slow = false;
+				auto flush_literals = [&]() {
+					if (pos + n_lit > want) { st = ST_OUTPUT_OVERFLOW; return; }
+					make_room();
+#ifndef PVC3_INF_SKIP_LIT
+					if (lane < n_lit) OUTB(pos + lane) = (uint8_t) lits;
+#endif
+					pos += n_lit; n_lit = 0;
+				};
+				while (o < WAVE)
+				{
+					uint32_t const e = (uint32_t) __builtin_amdgcn_readlane((int) e_ll, (int) o);
+					uint32_t const l = e >> 12, sym = e & 0xfff;
+					if (0 == l) { slow = true; break; }
+					if (sym < 256) { lits = (lane == n_lit) ? (int) sym : lits; ++n_lit; o += l; continue; }
+					if (256 == sym) { o += l; end_of_block = true; break; }
+					if (sym > 285) { st = ST_BAD_SYMBOL; break; }
+					uint32_t const ls = sym - 257;
+					uint32_t const x = (ls < 8 || 28 == ls) ? 0 : ((ls - 4) >> 2);
+					uint32_t const od = o + l + x;		// where the distance code begins
+					if (od >= WAVE) break;					// not in the lanes: the next pass begins with this match
+					uint32_t const ed = (uint32_t) __builtin_amdgcn_readlane((int) e_d, (int) od);
+					uint32_t const ld = ed >> 12, ds = ed & 0xfff;
+					if (0 == ld) { slow = true; break; }
+					if (ds > 29) { st = ST_BAD_SYMBOL; break; }
+					uint32_t const length = (ls < 8) ? (3 + ls) : (28 == ls) ? 258 : (3 + ((4 + ((ls - 4) & 3)) << x) + br.peek_at(o + l, x));
+					uint32_t const xd = (ds < 4) ? 0 : ((ds >> 1) - 1);
+					uint32_t const dist = (ds < 4) ? (1 + ds) : (1 + ((2 + (ds & 1)) << xd) + br.peek_at(od + ld, xd));
+					flush_literals();
+					if (ST_OK != st) break;
+					if (dist > pos) { st = ST_BAD_DISTANCE; break; }
+					if (pos + length > want) { st = ST_OUTPUT_OVERFLOW; break; }
+					// `length` bytes from `dist` back; a copy that overlaps itself repeats its first `dist` bytes
+					uint32_t const from = pos - dist;
+					make_room();
+#ifndef PVC3_INF_SKIP_COPY
+					if (dist >= length)
+						for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = OUTB(from + j);
+					else if (1 == dist)
+					{
+						uint8_t const v = OUTB(from);
+						for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = v;
+					}
+					else
+						for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = OUTB(from + j % dist);
+#else
+					(void) from;
+#endif
+					pos += length;
+					o = od + ld + xd;
+				}
+				if (ST_OK == st) flush_literals();
+				br.drop(o);
+				if (!slow || ST_OK != st) continue;
+
+				// one token the long way
 				br.refill();
 				uint32_t e = uni(L.t_ll[br.peek(LL_BITS)]);
 				uint32_t l = e >> 12, sym = e & 0xfff;
-				if (0 == l && !long_code((uint32_t) br.buf, LL_BITS + 1, L.sorted_ll, L.ll, sym, l)) { st = ST_BAD_SYMBOL; break; }
+				if (0 == l && !long_code(br.low32(), LL_BITS + 1, L.sorted_ll, L.ll, sym, l)) { st = ST_BAD_SYMBOL; break; }
 				br.drop(l);
 				if (sym < 256)
 				{
 					if (pos >= want) { st = ST_OUTPUT_OVERFLOW; break; }
-					if (0 == lane) L.out[pos] = (uint8_t) sym;
+					make_room();
+					if (0 == lane) OUTB(pos) = (uint8_t) sym;
 					++pos;
 					continue;
 				}
-				if (256 == sym) break;
+				if (256 == sym) { end_of_block = true; break; }
 				if (sym > 285) { st = ST_BAD_SYMBOL; break; }
 				uint32_t const ls = sym - 257;
 				uint32_t length;
@@ -322,7 +452,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 				br.refill();
 				e = uni(L.t_d[br.peek(D_BITS)]);
 				l = e >> 12; uint32_t ds = e & 0xfff;
-				if (0 == l && !long_code((uint32_t) br.buf, D_BITS + 1, L.sorted_d, L.d, ds, l)) { st = ST_BAD_SYMBOL; break; }
+				if (0 == l && !long_code(br.low32(), D_BITS + 1, L.sorted_d, L.d, ds, l)) { st = ST_BAD_SYMBOL; break; }
 				br.drop(l);
 				if (ds > 29) { st = ST_BAD_SYMBOL; break; }
 				uint32_t dist;
@@ -330,17 +460,12 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 				else { uint32_t const x = (ds >> 1) - 1; dist = 1 + ((2 + (ds & 1)) << x) + br.take(x); }
 				if (dist > pos) { st = ST_BAD_DISTANCE; break; }
 				if (pos + length > want) { st = ST_OUTPUT_OVERFLOW; break; }
-				// `length` bytes from `dist` back; a copy that overlaps itself repeats its first `dist` bytes
 				uint32_t const from = pos - dist;
+				make_room();
 				if (dist >= length)
-					for (uint32_t j = lane; j < length; j += WAVE) L.out[pos + j] = L.out[from + j];
-				else if (1 == dist)
-				{
-					uint8_t const v = L.out[from];
-					for (uint32_t j = lane; j < length; j += WAVE) L.out[pos + j] = v;
-				}
+					for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = OUTB(from + j);
 				else
-					for (uint32_t j = lane; j < length; j += WAVE) L.out[pos + j] = L.out[from + j % dist];
+					for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = OUTB(from + j % dist);
 				pos += length;
 			}
 		}
@@ -349,22 +474,8 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 		__syncthreads();
 		if (ST_OK == st)
 		{
-			// LDS -> global: bytes up to the first dword boundary of the destination, whole dwords, the bytes that are left
-			uint8_t *dst = out + blk.out_off;
-			uint32_t const head = (uint32_t) ((4 - (reinterpret_cast <uintptr_t>(dst) & 3)) & 3);
-			uint32_t const h = (head < want) ? head : want;
-			if (lane < h) dst[lane] = L.out[lane];
-			uint32_t const n_dw = (want - h) / 4;
-			uint32_t *dst32 = reinterpret_cast <uint32_t *>(dst + h);
-			uint32_t const *lds32 = reinterpret_cast <uint32_t const *>(L.out);
-			for (uint32_t i = lane; i < n_dw; i += WAVE)
-			{
-				uint32_t const o = h + 4 * i;		// byte offset in LDS; h is 0 .. 3
-				uint32_t const w0 = lds32[o >> 2], w1 = lds32[(o >> 2) + 1 < OUT_CAP / 4 ? (o >> 2) + 1 : (o >> 2)];
-				dst32[i] = __builtin_amdgcn_alignbyte(w1, w0, o & 3);
-			}
-			uint32_t const tail = h + 4 * n_dw;
-			if (tail + lane < want) dst[tail + lane] = L.out[tail + lane];
+			while (want - flushed > OUT_HALF) { store_region(flushed, OUT_HALF); flushed += OUT_HALF; }
+			store_region(flushed, want - flushed);
 		}
 		if (0 == lane) status[b] = st;
 	}

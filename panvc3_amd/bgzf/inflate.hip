@@ -156,9 +156,20 @@ struct bit_reader
 	__device__ __forceinline__ uint64_t consumed_bits() const { return uint64_t(32) * next_word - valid - lead_bits; }
 };
 
+// Entries of the literal / length table: a literal is length << 8 | byte (0x0100 .. 0x0aff: one comparison tells), anything else
+// 0x8000 | length << 9 | (symbol - 256); 0: the code is not in the table.
+__device__ __forceinline__ uint16_t litlen_entry(uint32_t sym, uint32_t len) { return (uint16_t) ((sym < 256) ? ((len << 8) | sym) : (0x8000u | (len << 9) | (sym - 256))); }
+__device__ __forceinline__ bool is_literal(uint32_t e) { return e - 0x100u < 0x0f00u; }
+__device__ __forceinline__ void litlen_decode(uint32_t e, uint32_t &sym, uint32_t &len)		// of a non-zero entry
+{
+	if (is_literal(e)) { sym = e & 0xff; len = e >> 8; }
+	else { sym = 256 + (e & 31); len = (e >> 9) & 15; }
+}
+
 // Canonical codes of lens[0 .. n) (RFC 1951 3.2.2) into a look-up table indexed by the next `bits` bits of the stream
-// (entry = symbol | length << 12) and, for longer codes, the symbols sorted by (length, symbol) with the first code and the
+// (entry = symbol | length << 12, or litlen_entry) and, for longer codes, the symbols sorted by (length, symbol) with the first code and the
 // count of every length.  Returns false for an over-subscribed code.  Called by the whole wave.
+template <bool t_litlen>
 __device__ bool build_table(uint8_t const *lens, uint32_t n, uint32_t bits, uint16_t *table, uint16_t *sorted, code_info &ci, uint32_t *flag)
 {
 	unsigned const lane = threadIdx.x;
@@ -197,7 +208,7 @@ __device__ bool build_table(uint8_t const *lens, uint32_t n, uint32_t bits, uint
 		if (l <= bits)
 		{
 			uint32_t const r = __brev(code) >> (32 - l);
-			uint16_t const e = (uint16_t) (s | (l << 12));
+			uint16_t const e = t_litlen ? litlen_entry(s, l) : (uint16_t) (s | (l << 12));
 			for (uint32_t j = r; j < (1u << bits); j += (1u << l)) table[j] = e;
 		}
 	}
@@ -237,6 +248,9 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 		bit_reader br;
 		br.start(in + blk.in_off, blk.in_len, L.ring);
 		uint32_t pos = 0, st = ST_OK;
+#ifdef PVC3_INF_COUNT
+		uint32_t c_pass = 0, c_slow = 0, c_lit = 0, c_match = 0, c_tables = 0;
+#endif
 		// The output's last 32 KB live in LDS (a match reaches no further back); what lies behind goes to global memory half a
 		// ring at a time, before the bytes that will take its place are written.
 		uint32_t flushed = 0;
@@ -357,7 +371,10 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 				if (0 == L.lens[256]) { st = ST_BAD_CODE_LENGTHS; break; }		// no end-of-block code
 			}
 			uint8_t const *lens_d = L.lens + ((1 == type) ? 288 : n_ll);
-			if (!build_table(L.lens, n_ll, LL_BITS, L.t_ll, L.sorted_ll, L.ll, &L.flag) || !build_table(lens_d, n_d, D_BITS, L.t_d, L.sorted_d, L.d, &L.flag))
+#ifdef PVC3_INF_COUNT
+			++c_tables;
+#endif
+			if (!build_table <true>(L.lens, n_ll, LL_BITS, L.t_ll, L.sorted_ll, L.ll, &L.flag) || !build_table <false>(lens_d, n_d, D_BITS, L.t_d, L.sorted_d, L.d, &L.flag))
 			{ st = ST_BAD_CODE_LENGTHS; break; }
 
 			// ---- the symbols -----------------------------------------------------------------------------------------------------------
@@ -368,6 +385,9 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 			// is wrong go through the one-token path behind the walk.
 			for (bool end_of_block = false; !end_of_block && ST_OK == st; )
 			{
+#ifdef PVC3_INF_COUNT
+				++c_pass;
+#endif
 				br.refill();
 				uint64_t const mine = br.from_bit(lane);
 				uint32_t const e_ll = L.t_ll[(uint32_t) mine & ((1u << LL_BITS) - 1)], e_d = L.t_d[(uint32_t) mine & ((1u << D_BITS) - 1)];
@@ -380,14 +400,26 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 #ifndef PVC3_INF_SKIP_LIT
 					if (lane < n_lit) OUTB(pos + lane) = (uint8_t) lits;
 #endif
+#ifdef PVC3_INF_COUNT
+					c_lit += n_lit;
+#endif
 					pos += n_lit; n_lit = 0;
 				};
-				while (o < WAVE)
+				for (;;)
 				{
-					uint32_t const e = (uint32_t) __builtin_amdgcn_readlane((int) e_ll, (int) o);
-					uint32_t const l = e >> 12, sym = e & 0xfff;
-					if (0 == l) { slow = true; break; }
-					if (sym < 256) { lits = (lane == n_lit) ? (int) sym : lits; ++n_lit; o += l; continue; }
+					// the literals: one comparison each
+					uint32_t e = 0;
+					while (o < WAVE)
+					{
+						e = (uint32_t) __builtin_amdgcn_readlane((int) e_ll, (int) o);
+						if (!is_literal(e)) break;
+						lits = (lane == n_lit) ? (int) (e & 0xff) : lits;
+						++n_lit;
+						o += e >> 8;
+					}
+					if (o >= WAVE) break;		// out of the lanes
+					if (0 == e) { slow = true; break; }
+					uint32_t const l = (e >> 9) & 15, sym = 256 + (e & 31);
 					if (256 == sym) { o += l; end_of_block = true; break; }
 					if (sym > 285) { st = ST_BAD_SYMBOL; break; }
 					uint32_t const ls = sym - 257;
@@ -421,18 +453,25 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 #else
 					(void) from;
 #endif
+#ifdef PVC3_INF_COUNT
+					++c_match;
+#endif
 					pos += length;
 					o = od + ld + xd;
 				}
 				if (ST_OK == st) flush_literals();
 				br.drop(o);
 				if (!slow || ST_OK != st) continue;
+#ifdef PVC3_INF_COUNT
+				++c_slow;
+#endif
 
 				// one token the long way
 				br.refill();
 				uint32_t e = uni(L.t_ll[br.peek(LL_BITS)]);
-				uint32_t l = e >> 12, sym = e & 0xfff;
-				if (0 == l && !long_code(br.low32(), LL_BITS + 1, L.sorted_ll, L.ll, sym, l)) { st = ST_BAD_SYMBOL; break; }
+				uint32_t l = 0, sym = 0;
+				if (e) litlen_decode(e, sym, l);
+				else if (!long_code(br.low32(), LL_BITS + 1, L.sorted_ll, L.ll, sym, l)) { st = ST_BAD_SYMBOL; break; }
 				br.drop(l);
 				if (sym < 256)
 				{
@@ -477,6 +516,10 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 			while (want - flushed > OUT_HALF) { store_region(flushed, OUT_HALF); flushed += OUT_HALF; }
 			store_region(flushed, want - flushed);
 		}
+#ifdef PVC3_INF_COUNT
+		__threadfence();
+		if (0 == lane && want >= 20) { uint32_t const c[5] = {c_pass, c_slow, c_lit, c_match, c_tables}; for (int k = 0; k < 20; ++k) dst[k] = (uint8_t) (c[k / 4] >> (8 * (k & 3))); }
+#endif
 		if (0 == lane) status[b] = st;
 	}
 }

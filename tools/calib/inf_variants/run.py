@@ -5,7 +5,7 @@ usage (on the GPU box): python tools/calib/inf_variants/run.py"""
 import os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
 root = os.path.dirname(os.path.dirname(os.path.dirname(here)))
-for name, flags in (("base", []), ("no_copy", ["-DPVC3_INF_SKIP_COPY"]), ("no_literals", ["-DPVC3_INF_SKIP_LIT"]), ("neither", ["-DPVC3_INF_SKIP_COPY", "-DPVC3_INF_SKIP_LIT"])):
+for name, flags in (("base", []), ("no_copy", ["-DPVC3_INF_SKIP_COPY"]), ("no_literals", ["-DPVC3_INF_SKIP_LIT"]), ("neither", ["-DPVC3_INF_SKIP_COPY", "-DPVC3_INF_SKIP_LIT"]), ("zcount", ["-DPVC3_INF_COUNT"])):
 	subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fvisibility=hidden", "-shared"] + flags
 						  + ["-o", os.path.join(here, "lib%s.so" % name), os.path.join(root, "panvc3_amd", "bgzf", "deflate.hip"), os.path.join(root, "panvc3_amd", "bgzf", "inflate.hip")])
 code = r'''
@@ -20,6 +20,12 @@ for p in pieces:
 inf = bgzf.BlockInflater(0, max_in=len(pieces)*66000, max_out=len(pieces)*65280, max_blocks=len(pieces), n_slots=1)
 got, status, ms = inf.inflate(streams, [len(p) for p in pieces], repeats=3)
 print(os.environ.get("PVC3_BGZF_LIB","default").split("/")[-1], "%%d blocks %%.3f ms" %% (len(pieces), ms), "statuses", sorted(set(int(x) for x in status)))
+if "zcount" in os.environ.get("PVC3_BGZF_LIB", ""):
+    import struct
+    tot = [0] * 5
+    for g in got:
+        for k, v in enumerate(struct.unpack("<5I", g[:20])): tot[k] += v
+    print("per block: passes %%.0f, tokens the long way %%.0f, literals %%.0f, matches in the walk %%.0f, deflate blocks %%.1f" %% tuple(t / len(got) for t in tot))
 ''' % (root, root)
 sys.path.insert(0, os.path.join(root, "tools"))
 import cli_e2e

@@ -14,7 +14,7 @@ IN_STRIDE = 65536
 OUT_STRIDE = 65536
 SYMBOLS = ("pvc3_bgzf_create", "pvc3_bgzf_destroy", "pvc3_bgzf_max_blocks", "pvc3_bgzf_slot_input", "pvc3_bgzf_slot_lengths", "pvc3_bgzf_submit",
 		   "pvc3_bgzf_wait", "pvc3_bgzf_deflate", "pvc3_bgzf_last_error",
-		   "pvc3_bgzf_inflater_create", "pvc3_bgzf_inflater_destroy", "pvc3_bgzf_inflater_input", "pvc3_bgzf_inflater_output", "pvc3_bgzf_inflater_blocks",
+		   "pvc3_bgzf_inflater_create", "pvc3_bgzf_inflater_destroy", "pvc3_bgzf_inflater_blocks_in_flight", "pvc3_bgzf_inflater_input", "pvc3_bgzf_inflater_output", "pvc3_bgzf_inflater_blocks",
 		   "pvc3_bgzf_inflater_submit", "pvc3_bgzf_inflater_wait")
 BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8")])
 _L = None

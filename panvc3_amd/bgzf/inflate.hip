@@ -629,6 +629,7 @@ int pvc3_bgzf_inflater_create(int device, size_t max_in_bytes, size_t max_out_by
 	return 0;
 }
 
+uint32_t pvc3_bgzf_inflater_blocks_in_flight(pvc3_bgzf_inflater const *h) { return h ? h->grid_max : 0; }
 uint8_t *pvc3_bgzf_inflater_input(pvc3_bgzf_inflater *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].h_in : nullptr; }
 uint8_t *pvc3_bgzf_inflater_output(pvc3_bgzf_inflater *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].h_out : nullptr; }
 pvc3_bgzf_block *pvc3_bgzf_inflater_blocks(pvc3_bgzf_inflater *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].h_blocks : nullptr; }

@@ -162,6 +162,7 @@ public:
 	virtual std::size_t max_in() const = 0;
 	virtual std::size_t max_out() const = 0;
 	virtual std::size_t max_blocks() const = 0;
+	virtual std::size_t blocks_in_flight() const = 0;		// a group of that many blocks takes as long as a group of one
 	virtual uint8_t *input(unsigned slot) = 0;
 	virtual uint8_t *output(unsigned slot) = 0;
 	virtual block *blocks(unsigned slot) = 0;
@@ -293,21 +294,35 @@ class byte_reader
 				continue;
 			}
 			dst.len = out;
-			if (g && out <= g->max_out() && blocks.size() <= g->max_blocks())
+			if (g && out <= g->max_out())
 			{
-				// The piece's blocks on the GPU, their bytes in the page-locked output of this piece's slot; what the GPU refuses
-				// is inflated here, and every block's checksum is verified here.
+				// As many of the piece's blocks as the GPU works on at a time go there (a group of them takes the GPU as long as one
+				// block), the rest are inflated by the threads here meanwhile; all bytes land in the page-locked output of this piece's
+				// slot.  What the GPU refuses is inflated here afterwards, and every block's checksum is verified here.
+				std::size_t const n_group = std::min(blocks.size(), std::max <std::size_t>(1, std::min(g->blocks_in_flight(), g->max_blocks())));
 				group_inflater::block *gb = g->blocks(dst.slot);
-				for (std::size_t i = 0; i < blocks.size(); ++i)
+				for (std::size_t i = 0; i < n_group; ++i)
 					gb[i] = group_inflater::block{blocks[i].in_off, (uint32_t) blocks[i].in_len, (uint32_t) blocks[i].out_len, blocks[i].out_off};
-				g->submit(dst.slot, blocks.size(), off, out);
-				uint32_t const *status = g->wait(dst.slot);
+				std::size_t const out_group = (n_group < blocks.size()) ? blocks[n_group].out_off : out;
+				std::size_t const in_group = (n_group < blocks.size()) ? blocks[n_group].in_off : off;
+				g->submit(dst.slot, n_group, in_group, out_group);
 				uint8_t *dbuf = g->output(dst.slot);
 				dst.ptr = dbuf;
+				std::exception_ptr here_error;
+				try
+				{
+					parallel_for(blocks.size() - n_group, m_threads, [&](std::size_t k) {
+						block const &b = blocks[n_group + k];
+						inflate_block(cbuf + b.in_off, b.in_len, dbuf + b.out_off, b.out_len, b.crc);
+					});
+				}
+				catch (...) { here_error = std::current_exception(); }
+				uint32_t const *status = g->wait(dst.slot);		// (also when a block failed here: the slot must not stay busy)
+				if (here_error) std::rethrow_exception(here_error);
 				std::atomic <uint64_t> refused{0};
-				std::size_t const n_tasks = std::min <std::size_t>(blocks.size(), 8 * (std::size_t) m_threads);
+				std::size_t const n_tasks = std::min <std::size_t>(n_group, 8 * (std::size_t) m_threads);
 				parallel_for(n_tasks, m_threads, [&](std::size_t t) {
-					for (std::size_t i = blocks.size() * t / n_tasks; i < blocks.size() * (t + 1) / n_tasks; ++i)
+					for (std::size_t i = n_group * t / n_tasks; i < n_group * (t + 1) / n_tasks; ++i)
 					{
 						block const &b = blocks[i];
 						if (0 == b.out_len) continue;
@@ -316,7 +331,7 @@ class byte_reader
 						inflate_block(cbuf + b.in_off, b.in_len, dbuf + b.out_off, b.out_len, b.crc);
 					}
 				});
-				m_group_blocks += blocks.size(); m_group_refused += refused.load();
+				m_group_blocks += n_group; m_group_refused += refused.load();
 			}
 			else
 			{

@@ -81,6 +81,7 @@ public:
 	std::size_t max_in() const override { return m_max_in; }
 	std::size_t max_out() const override { return m_max_out; }
 	std::size_t max_blocks() const override { return m_max_blocks; }
+	std::size_t blocks_in_flight() const override { return pvc3_bgzf_inflater_blocks_in_flight(m_handle); }
 	uint8_t *input(unsigned slot) override { return pvc3_bgzf_inflater_input(m_handle, slot); }
 	uint8_t *output(unsigned slot) override { return pvc3_bgzf_inflater_output(m_handle, slot); }
 	block *blocks(unsigned slot) override { return reinterpret_cast <block *>(pvc3_bgzf_inflater_blocks(m_handle, slot)); }

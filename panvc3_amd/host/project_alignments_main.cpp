@@ -451,10 +451,10 @@ int main(int argc, char **argv)
 				// The BGZF compressor's page-locked staging takes a while to allocate and is not needed before the first batch has been
 				// rewritten: it comes up on a thread of its own, behind the contexts (the HIP runtime is up by now).
 				// The inflater of the input's blocks likewise; the reader, which has been inflating on the host threads since the process
-				// began, hands its pieces over from the next one on.  Pieces of 16 MB of the file, 96 MB of page-locked output each.
+				// began, shares its pieces with it from the next one on: pieces of 32 MB of the file, 160 MB of page-locked output each.
 				if (opt.gpu_inflate)
 					inflater_coming = std::async(std::launch::async, [&]() {
-						block_inflater = std::make_unique <gpu_group_inflater>(opt.devices.front(), (std::size_t) 32 << 20, (std::size_t) 96 << 20, 4096, 2);
+						block_inflater = std::make_unique <gpu_group_inflater>(opt.devices.front(), (std::size_t) 65 << 20, (std::size_t) 160 << 20, 4096, 2);
 						reader.attach(block_inflater.get());
 						t_inflater_up = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
 					});

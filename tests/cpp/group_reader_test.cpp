@@ -32,6 +32,7 @@ public:
 	std::size_t max_in() const override { return m_max_in; }
 	std::size_t max_out() const override { return m_max_out; }
 	std::size_t max_blocks() const override { return m_max_blocks; }
+	std::size_t blocks_in_flight() const override { return 5; }		// (pieces of more blocks are shared with the reader's own threads)
 	uint8_t *input(unsigned slot) override { return m_in[slot].data(); }
 	uint8_t *output(unsigned slot) override { return m_out[slot].data(); }
 	block *blocks(unsigned slot) override { return m_blocks[slot].data(); }

@@ -420,6 +420,17 @@ public:
 		if (m_raw) { std::fclose(m_raw); m_raw = nullptr; }
 	}
 
+	// close(), and the buffers given back (a process that has used the GPU pays at exit for the memory it still holds).
+	void release()
+	{
+		close();
+		std::vector <uint8_t>().swap(m_cbuf);
+		std::vector <uint8_t>().swap(m_cur.data);
+		std::vector <uint8_t>().swap(m_next.data);
+		m_cur.ptr = m_next.ptr = nullptr; m_cur.len = m_next.len = 0; m_dpos = 0; m_clen = 0;
+		m_group.store(nullptr); m_group_in_use = nullptr;
+	}
+
 	// Reads exactly n bytes unless the stream ends; returns the number read.
 	std::size_t read(void *dst, std::size_t n)
 	{

@@ -435,7 +435,8 @@ int main(int argc, char **argv)
 		std::unique_ptr <gpu_group_deflater> block_deflater;
 		std::future <std::unique_ptr <gpu_group_deflater>> deflater_coming;
 		bool const want_gpu_deflate = opt.gpu_deflate && opt.output_bam && opt.compression_level < 0;
-		double t_startup = 0.0, t_contexts_up = 0.0, t_deflater_up = 0.0, t_inflater_up = 0.0, t_files_read = 0.0;
+		double t_startup = 0.0, t_contexts_up = 0.0, t_deflater_up = 0.0, t_inflater_up = 0.0, t_files_read = 0.0, inflater_kernel_s = 0.0;
+		uint64_t inflater_groups = 0;
 		auto prepare_devices = [&]() {
 			// The GPU contexts come up on a thread of their own (the HIP runtime takes a few tenths of a second to start) while the
 			// index file and the reference are read.
@@ -1099,11 +1100,40 @@ int main(int argc, char **argv)
 			wq_done = true;
 		}
 		wq_cv.notify_all();
+		// While the writer finishes the last batches and the file is closed, everything else this process holds is given back on a
+		// thread of its own: a process that has used the GPU pays at exit for the memory it still holds (0.07-0.09 s per GB of
+		// ordinary memory: tools/calib/exit_cost_hip.py), and that is time the caller waits.
+		bool const profile_exit = nullptr != std::getenv("PVC3_EXIT_PROFILE");
+		if (reader_thread.joinable()) reader_thread.join();		// (it has returned: the queue was empty and done)
+		std::thread teardown_thread;
+		if (!profile_exit)
+			teardown_thread = std::thread([&]() {
+				// Ordinary memory only, two things at a time.  (Page-locked memory is left to the exit: giving it back here takes as
+				// long as the exit would, and hipHostFree holds the runtime up for the writer, whose last group is on the GPU.)
+				auto quietly = [](auto &&f) { return std::async(std::launch::async, [f]() { try { f(); } catch (...) {} }); };
+				auto a = quietly([&]() {
+					{
+						std::lock_guard <std::mutex> lock(rq_mutex);
+						rq.clear(); rq_free.clear();
+					}
+					std::vector <slice_state>().swap(slices);
+				});
+				auto b = quietly([&]() {
+					reader.release();
+					if (inflater_coming.valid()) inflater_coming.get();
+					if (block_inflater) { inflater_groups = block_inflater->groups(); inflater_kernel_s = block_inflater->kernel_seconds(); }
+					pvc3_index_destroy(index); index = nullptr;		// the host's copy of the index: the contexts are not used again
+				});
+				a.get(); b.get();
+			});
+		struct join_teardown { std::thread &t; ~join_teardown() { if (t.joinable()) t.join(); } } teardown_joiner{teardown_thread};
 		writer_thread.join();
 		if (writer_error) std::rethrow_exception(writer_error);
 		double const t_writer_joined = since(t_start);
 		writer.close();
 		double const t_closed = since(t_start);
+		if (teardown_thread.joinable()) teardown_thread.join();
+		double const t_torn_down = since(t_start);
 		(void) contexts; (void) index;		// not taken down one by one: see the end of this block
 
 		// ---- finish (:1033-1073) ---------------------------------------------------------------------------------------------------------
@@ -1132,14 +1162,13 @@ int main(int argc, char **argv)
 					  << ", GPU " << tm.gpu << ", rewriting " << tm.rewrite << ", waiting for the writer " << tm.wait_write << ", writer thread " << tm_write << '\n';
 		if (opt.debugging_output)
 			std::cerr << "\tTimeline (s): GPU contexts " << t_contexts_up << " and BGZF compressor " << t_deflater_up << " (their thread), index file and FASTA " << t_files_read << ", both " << t_prepared << ", first batch read " << t_first_batch << ", index on the GPUs (start-up done) " << t_startup << ", last batch rewritten " << t_batches_done << ", writer thread joined " << t_writer_joined
-					  << ", output closed " << t_closed << "; wall clock at the start " << std::fixed << epoch_start << ", now "
+					  << ", output closed " << t_closed << ", memory given back " << t_torn_down << "; wall clock at the start " << std::fixed << epoch_start << ", now "
 					  << std::chrono::duration <double>(std::chrono::system_clock::now().time_since_epoch()).count() << std::defaultfloat
 					  << "; resident set (MB): contexts up " << rss_prepared << ", index uploaded " << rss_startup << ", last batch rewritten " << rss_batches_done
 					  << ", peak " << peak_rss_mb() << "; CPU time (s): " << cpu_seconds() << '\n';
-		if (inflater_coming.valid()) inflater_coming.get();
-		if (opt.debugging_output && block_inflater)
-			std::cerr << "\tBGZF input on the GPU: up after " << t_inflater_up << " s, " << reader.group_blocks() << " blocks in " << block_inflater->groups() << " pieces, kernel "
-					  << block_inflater->kernel_seconds() << " s; inflated on the host instead " << reader.group_refused() << '\n';
+		if (opt.debugging_output && opt.gpu_inflate)
+			std::cerr << "\tBGZF input on the GPU: up after " << t_inflater_up << " s, " << reader.group_blocks() << " blocks in " << inflater_groups << " pieces, kernel "
+					  << inflater_kernel_s << " s; inflated on the host instead " << reader.group_refused() << '\n';
 		if (opt.debugging_output && block_deflater)
 			std::cerr << "\tBGZF on the GPU: " << block_deflater->blocks() << " blocks in " << block_deflater->groups() << " groups, kernel " << block_deflater->kernel_seconds() << " s\n";
 		if (!removed_tag_counts.empty())
@@ -1152,7 +1181,7 @@ int main(int argc, char **argv)
 		// the worker pool and the HIP runtime down one by one: that took as long as projecting a million records, and the
 		// driver frees all of it with the process (the reference ends with exit(0) from its main queue as well,
 		// project_alignments.cc:1079-1089).
-		if (std::getenv("PVC3_EXIT_PROFILE"))		// what the exit would cost, step by step (tools/cli_timeline.py)
+		if (profile_exit)		// what the exit would cost, step by step (tools/cli_timeline.py); nothing was given back above
 		{
 			auto lap = [&, t = now()](char const *what) mutable { std::cerr << "\tteardown: " << what << ' ' << since(t) << " s\n"; t = now(); };
 			slot_states.clear(); lap("page-locked batch arrays");

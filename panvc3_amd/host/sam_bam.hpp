@@ -541,6 +541,7 @@ public:
 
 	void set_threads(unsigned n) { m_in.set_threads(n); }
 	void attach(group_inflater *g) { m_in.attach(g); }		// BGZF input inflated elsewhere from the next piece on (byte_reader::attach)
+	void release() { m_in.release(); }						// the input is closed and its buffers are given back
 	uint64_t group_blocks() const { return m_in.group_blocks(); }
 	uint64_t group_refused() const { return m_in.group_refused(); }
 

@@ -33,5 +33,11 @@ for _ in range(args.runs):
 			b = float(line.split(", now ")[1].split(";")[0])
 			cpu = float(line.split("CPU time (s): ")[1]) if "CPU time (s): " in line else 0.0
 			print("    before main's clock starts %.3f s, main %.3f s, after its last line %.3f s; CPU time %.2f s = %.1f cores busy" % (a - e0, b - a, e1 - b, cpu, cpu / (b - a)))
-		if "Stages" in line or "Timeline" in line or "BGZF on" in line or "teardown" in line:
+		if "memory given back" in line:
+			import re
+			m = re.search(r"last batch rewritten ([0-9.e-]+), writer thread joined ([0-9.e-]+), output closed ([0-9.e-]+), memory given back ([0-9.e-]+)", line)
+			if m:
+				t = [float(x) for x in m.groups()]
+				print("    after the last batch: writer thread %.3f s, closing the output %.3f s, still giving memory back %.3f s" % (t[1] - t[0], t[2] - t[1], t[3] - t[2]))
+		if "Stages" in line or "Timeline" in line or "BGZF on" in line or "BGZF input" in line or "teardown" in line:
 			print("   ", line.strip())

@@ -1105,6 +1105,7 @@ int main(int argc, char **argv)
 		// ordinary memory: tools/calib/exit_cost_hip.py), and that is time the caller waits.
 		bool const profile_exit = nullptr != std::getenv("PVC3_EXIT_PROFILE");
 		if (reader_thread.joinable()) reader_thread.join();		// (it has returned: the queue was empty and done)
+		if (inflater_coming.valid()) inflater_coming.get();		// (--bgzf-inflate=gpu and no inflater: an error, not a silent run on the host threads)
 		std::thread teardown_thread;
 		if (!profile_exit)
 			teardown_thread = std::thread([&]() {
@@ -1120,7 +1121,6 @@ int main(int argc, char **argv)
 				});
 				auto b = quietly([&]() {
 					reader.release();
-					if (inflater_coming.valid()) inflater_coming.get();
 					if (block_inflater) { inflater_groups = block_inflater->groups(); inflater_kernel_s = block_inflater->kernel_seconds(); }
 					pvc3_index_destroy(index); index = nullptr;		// the host's copy of the index: the contexts are not used again
 				});

@@ -138,7 +138,7 @@ def build_host(force=False, verbose=False):
 		("panvc3_project_alignments", ["-L" + HERE, "-lpvc3_hip", "-lpvc3_bgzf", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
 		("panvc3_rewrite_cigar", ["-lz"]),
 		("panvc3_convert_bed_positions", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
-		("panvc3_recalculate_mapq", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
+		("panvc3_recalculate_mapq", ["-L" + HERE, "-lpvc3_hip", "-lpvc3_bgzf", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
 	):
 		src = os.path.join(HOST, name.replace("panvc3_", "") + "_main.cpp")
 		dst = os.path.join(BIN, name)

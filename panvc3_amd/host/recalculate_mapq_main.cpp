@@ -22,8 +22,11 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
 #include "../../include/pvc3.h"
 #include "sam_bam.hpp"
+#include "gpu_deflate.hpp"
 
 using namespace pvc3host;
 
@@ -92,6 +95,7 @@ int main(int argc, char **argv)
 	std::string tag_xn = "XN", tag_xr = "XR", tag_xp = "XP", tag_yr = "YR", tag_yp = "YP", tag_xs = "XS", tag_ys = "YS";
 	unsigned threads = default_io_threads();
 	std::size_t batch_records = 1u << 20;
+	bool gpu_deflate = true;		// --bgzf-deflate=gpu|host: BAM output's blocks are compressed on the GPU (as panvc3_project_alignments)
 	static option const opts[] = {
 		{"alignments", required_argument, nullptr, 'a'}, {"bam-input", no_argument, nullptr, 'B'}, {"output-path", required_argument, nullptr, 'o'},
 		{"output-bam", no_argument, nullptr, 'b'}, {"status-output-interval", required_argument, nullptr, 1000}, {"verbose", no_argument, nullptr, 1001},
@@ -101,7 +105,7 @@ int main(int argc, char **argv)
 		{"original-rnext-tag", required_argument, nullptr, 1011}, {"original-pnext-tag", required_argument, nullptr, 1012}, {"original-alignment-score-tag", required_argument, nullptr, 1013},
 		{"new-alignment-score-tag", required_argument, nullptr, 1014}, {"print-invocation", no_argument, nullptr, 1015}, {"print-pid", no_argument, nullptr, 1016},
 		{"print-reference-names", no_argument, nullptr, 1017}, {"threads", required_argument, nullptr, 1018}, {"device", required_argument, nullptr, 1019},
-		{"batch-records", required_argument, nullptr, 1020}, {"help", no_argument, nullptr, 'h'}, {"version", no_argument, nullptr, 'V'}, {nullptr, 0, nullptr, 0}};
+		{"batch-records", required_argument, nullptr, 1020}, {"bgzf-deflate", required_argument, nullptr, 1021}, {"help", no_argument, nullptr, 'h'}, {"version", no_argument, nullptr, 'V'}, {nullptr, 0, nullptr, 0}};
 	int c;
 	while (-1 != (c = getopt_long(argc, argv, "a:Bo:bhV", opts, nullptr)))
 	{
@@ -132,8 +136,17 @@ int main(int argc, char **argv)
 			case 1018: threads = (unsigned) std::max(1, std::atoi(optarg)); break;
 			case 1019: device = std::atol(optarg); break;
 			case 1020: batch_records = (std::size_t) std::max(1L, std::atol(optarg)); break;
+			case 1021:
+				if (0 == std::strcmp(optarg, "gpu")) gpu_deflate = true;
+				else if (0 == std::strcmp(optarg, "host")) gpu_deflate = false;
+				else die("--bgzf-deflate expects gpu or host");
+				break;
 			case 'V': std::cout << "recalculate-mapq 0.1 (panvc3-mi355x)\n"; return 0;
-			case 'h': std::cout << "Usage: panvc3_recalculate_mapq --alignments=alignments.bam > projected.sam\n"; return 0;
+			case 'h':
+				std::cout << "Usage: panvc3_recalculate_mapq --alignments=alignments.bam > projected.sam\n"
+							 "  (the options of the reference's recalculate-mapq/cmdline.ggo; in addition --device=INT, --threads=INT, --batch-records=INT and\n"
+							 "  --bgzf-deflate=gpu|host: where the blocks of BAM output are compressed, on the GPU by default)\n";
+				return 0;
 			default: return EXIT_FAILURE;
 		}
 	}
@@ -165,6 +178,7 @@ int main(int argc, char **argv)
 		sam_header const &in_header = reader.header;
 		sam_header out_header = in_header;
 		append_sam_program_info(in_header, out_header, "panvc3.recalculate-mapq.", "PanVC 3 recalculate_mapq", argc, argv);		// main.cc:1291-1304
+		std::unique_ptr <gpu_group_deflater> block_deflater;		// (before the writer, which uses it until it is closed)
 		alignment_writer writer;
 		writer.set_threads(threads);
 		writer.open(output_path, output_bam, out_header);
@@ -176,6 +190,11 @@ int main(int argc, char **argv)
 
 		pvc3_context *ctx{};
 		check(pvc3_context_create((int) device, &ctx));
+		if (output_bam && gpu_deflate)
+		{
+			block_deflater = std::make_unique <gpu_group_deflater>((int) device, 512, 2);
+			writer.attach(block_deflater.get());
+		}
 		std::cerr << "Processing the alignments…\n";
 
 		uint16_t const k_xr = tag_key(tag_xr.c_str()), k_xp = tag_key(tag_xp.c_str()), k_yr = tag_key(tag_yr.c_str()), k_yp = tag_key(tag_yp.c_str());

@@ -500,6 +500,9 @@ def test_recalculate_mapq_cli(tools, tmp_path):
 		head = [l for l in open(tmp_path / "out.sam").read().split("\n") if l.startswith("@PG")]
 		assert head[-1].startswith("@PG\tID:panvc3.recalculate-mapq.1\tPN:PanVC 3 recalculate_mapq") and "PP:panvc3.project-alignments.1" in head[-1]
 		# BAM out, small batches: the same records
-		_run(args + ["--output-bam", "--output-path=out.bam", "--batch-records=100"], cwd=tmp_path)
+		_run(args + ["--output-bam", "--output-path=out.bam", "--batch-records=100"], cwd=tmp_path)		# (the blocks compressed on the GPU)
+		_run(args + ["--output-bam", "--output-path=out_host.bam", "--batch-records=100", "--bgzf-deflate=host"], cwd=tmp_path)
+		import gzip
+		assert gzip.decompress((tmp_path / "out.bam").read_bytes())[-20000:] == gzip.decompress((tmp_path / "out_host.bam").read_bytes())[-20000:]
 		_, _, back = bamio.read_bam(tmp_path / "out.bam")
 		assert [(b["qname"], b["mapq"]) for b in back] == [(r.qname, mapq) for r, mapq, _ in want]

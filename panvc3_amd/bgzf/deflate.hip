@@ -473,12 +473,10 @@ __global__ __launch_bounds__(WAVE) void k_deflate_blocks(
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 
-#define g_error g_bgzf_error
-
 int fail(int code, char const *what, hipError_t e = hipSuccess)
 {
-	if (hipSuccess != e) std::snprintf(g_error, sizeof(g_error), "%s: %s", what, hipGetErrorString(e));
-	else std::snprintf(g_error, sizeof(g_error), "%s", what);
+	if (hipSuccess != e) std::snprintf(g_bgzf_error, sizeof(g_bgzf_error), "%s: %s", what, hipGetErrorString(e));
+	else std::snprintf(g_bgzf_error, sizeof(g_bgzf_error), "%s", what);
 	return code;
 }
 
@@ -507,7 +505,7 @@ struct pvc3_bgzf
 
 extern "C" {
 
-char const *pvc3_bgzf_last_error(void) { return g_error; }
+char const *pvc3_bgzf_last_error(void) { return g_bgzf_error; }
 
 void pvc3_bgzf_destroy(pvc3_bgzf *h)
 {
@@ -574,7 +572,7 @@ int pvc3_bgzf_create(int device, uint32_t max_blocks, uint32_t n_slots, pvc3_bgz
 		if (0 == rc) check(hipEventCreate(&s.stop), "hipEventCreate");
 		if (0 == rc) check(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
 	}
-	if (rc) { char keep[sizeof(g_error)]; std::memcpy(keep, g_error, sizeof(keep)); pvc3_bgzf_destroy(h); std::memcpy(g_error, keep, sizeof(keep)); return rc; }
+	if (rc) { char keep[sizeof(g_bgzf_error)]; std::memcpy(keep, g_bgzf_error, sizeof(keep)); pvc3_bgzf_destroy(h); std::memcpy(g_bgzf_error, keep, sizeof(keep)); return rc; }
 	*out = h;
 	return 0;
 }

@@ -74,6 +74,7 @@ def main():
 	p = subprocess.run([os.path.join(ROOT, "bin", "test_fast_deflate_test")], input=sample, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
 					   env=dict(os.environ, PVC3_DEFLATE_TIMING="1"))
 	print("host encoder (fast_deflate.hpp), one core:", p.stderr.decode().strip())
+	comp.close()
 	if not ok:
 		raise SystemExit(1)
 

@@ -11,3 +11,4 @@ for p in pieces:
 inf = bgzf.BlockInflater(0, max_in=len(pieces) * 66000, max_out=len(pieces) * 65280, max_blocks=len(pieces), n_slots=1)
 got, status, ms = inf.inflate(streams, [len(p) for p in pieces], repeats=2)
 print("%d blocks %.3f ms" % (len(pieces), ms))
+inf.close()

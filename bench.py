@@ -64,6 +64,9 @@ def parse_args(argv=None):
 	ap.add_argument("--skip-host-buffers", action="store_true", help="leave out the PCIe-inclusive legs (their smaller launches would enter rocprofv3's per-kernel averages)")
 	ap.add_argument("--sorted", action="store_true", help="sort the records by (source entry, position) like a coordinate-sorted BAM (secondary data point; the default is the unsorted worst case)")
 	ap.add_argument("--skip-sorted-leg", action="store_true", help="leave out the second measurement of the same records in coordinate order (the order of a sorted BAM, which is what the workflows feed project_alignments)")
+	ap.add_argument("--other-configs", default="C5,C3G", help="further BASELINE.json configurations measured at full size after the main one (a few steps each, never part of `value`): other_configs in the JSON line; empty disables")
+	ap.add_argument("--other-steps", type=int, default=5)
+	ap.add_argument("--setup-only", action="store_true", help="run the set-up of every rank (shared genome, this rank's reads, the host side of the index), print its seconds and peak resident set, and stop before anything touches a GPU (ranks then meet over gloo): rehearsal of the N-rank launch on a box without N GPUs")
 	ap.add_argument("--no-build", action="store_true", help="never compile: exit non-zero if a native library is stale (use under rocprofv3, after `python3 -m panvc3_amd.build`)")
 	return ap.parse_args(argv)
 
@@ -158,6 +161,75 @@ def traffic_for(config, scale):
 	return None, None
 
 
+def measure_other_config(config, args, local_rank, threads, cores):
+	"""One more BASELINE.json configuration at full size on this GPU: ms per step, kernel times, the whole step against the HBM
+	roofline, and a sample of the results compared with the oracle.  Everything it makes is released again."""
+	import numpy as np
+	import torch
+	import panvc3_amd
+	from tests.synth import synth
+	from oracle import oracle as orc
+	gp, rp, desc = synth.config(config, scale=args.scale)
+	t0 = time.time()
+	genome = synth.Genome(gp, n_threads=min(threads, gp.n_contigs))
+	reads = synth.Reads(genome, rp, n_threads=threads)
+	batch = reads.batch()
+	n = int(reads.n)
+	t_gen = time.time() - t0
+	index = panvc3_amd.Index()
+	genome.fill_index(index)
+	ctx = panvc3_amd.Context(local_rank)
+	ctx.set_option("window_read_length", int(rp.read_len))
+	ctx.upload_index(index)
+	ctx.set_timing(True)
+	db = panvc3_amd.DeviceBatch(ctx, batch)
+	params = panvc3_amd.api.make_params(0, -1, args.score_mode)
+	try:
+		for _ in range(2):
+			db.project(params)
+			stats = db.finish()
+		keys = ("project", "mid", "general", "realign", "pack")
+		ms = dict.fromkeys(keys, 0.0)
+		steps = max(1, args.other_steps)
+		torch.cuda.synchronize()
+		tb = time.perf_counter()
+		for _ in range(steps):
+			db.project(params)
+			st = db.finish()
+			for k in ms:
+				ms[k] += st["ms_" + k]
+		torch.cuda.synchronize()
+		dt = time.perf_counter() - tb
+		ms_step = dt / steps * 1e3
+		out = {
+			"workload": desc, "records": n, "steps": steps, "ms_per_step": ms_step, "value": n * steps / dt, "unit": "alignments/s",
+			"kernel_ms": {k: v / steps for k, v in ms.items()},
+			"whole_step": {"algorithmic_bytes": stats["algorithmic_bytes"], "GBps": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9, "frac": stats["algorithmic_bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+			"batch": {"fast_path_records": stats["n_fast_path"], "mid_path_records": stats["n_mid_path"], "realigned_records": stats["n_realigned_records"], "indel_runs": stats["n_runs"]},
+			"setup_seconds": t_gen,
+		}
+		# parity: the first records of the same batch through the oracle (a few seconds of CPU)
+		o = orc.Oracle()
+		genome.fill_index(o)
+		sample = int(min(n, 200_000))
+		want = o.batch_project(synth.slice_batch(batch, 0, sample), 0, -1, args.score_mode, n_threads=cores)
+		got = db.download()
+		n_c = int(want["out_cigar_off"][sample])
+		same = (
+			np.array_equal(got["dst_pos"][:sample], want["dst_pos"]) and np.array_equal(got["mate_dst_pos"][:sample], want["mate_dst_pos"])
+			and np.array_equal(got["out_cigar_off"][:sample + 1], want["out_cigar_off"]) and np.array_equal(got["out_cigar"][:n_c], want["out_cigar"])
+			and np.array_equal(got["status"][:sample], want["status"])
+			and np.array_equal(got["run_off"][:sample + 1], want["run_off"]) and np.array_equal(got["runs"][:int(want["run_off"][sample])], want["runs"])
+		)
+		out["parity_sample"] = {"records": sample, "bit_identical": bool(same)}
+		if not same:
+			raise SystemExit("parity failure against the oracle on the %s sample" % config)
+		return out
+	finally:
+		db.close()
+		ctx.close()
+
+
 def main():
 	args = parse_args()
 	if args.gpus < 1:
@@ -176,22 +248,32 @@ def main():
 	import torch
 	import torch.distributed as dist
 
-	if not torch.cuda.is_available():
+	setup_only = args.setup_only
+	if not setup_only and not torch.cuda.is_available():
 		raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-	torch.cuda.set_device(local_rank)
-	device = torch.device("cuda", local_rank)
+	device = None
+	if not setup_only:
+		torch.cuda.set_device(local_rank)
+		device = torch.device("cuda", local_rank)
 	# PVC3_BENCH_FORCE_DIST=1: go through RCCL (process group, barriers, the three all-reduces) with a single rank too, so that
 	# the N > 1 code path can be exercised on a one-GPU box (tests/test_multiproc_gpu.py).
 	use_dist = world > 1 or "1" == os.environ.get("PVC3_BENCH_FORCE_DIST")
 	if use_dist:
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 		os.environ.setdefault("MASTER_PORT", "29533")
-		dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)		# "nccl" is RCCL on ROCm
+		if setup_only:
+			dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+		else:
+			dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)		# "nccl" is RCCL on ROCm
 
 	import panvc3_amd
 	from panvc3_amd import build as pvc3_build
 	from panvc3_amd.shard import reduce_job
 	from tests.synth import synth
+
+	def barrier():
+		if use_dist:
+			dist.barrier()
 
 	cores = usable_cpus()
 	threads = max(1, cores // max(1, world))
@@ -205,7 +287,23 @@ def main():
 		desc += "; this rank's shard: %d records" % rp.n_records
 	rp.seed = rp.seed + 1000 * rank			# every rank samples its own reads (weak scaling); the genome is identical
 	t0 = time.time()
-	genome = synth.Genome(gp, n_threads=min(threads, gp.n_contigs))
+	if world > 1:
+		# One genome for the node: rank 0 generates it with every granted core into a file under /dev/shm, all ranks map that
+		# file (one copy of its pages, however many ranks) and the name is removed once everybody has it.  (All ranks of a
+		# single-node job see the same /dev/shm; the driver runs one node.)
+		shared = "/dev/shm/pvc3_bench_%s_%g_%s.genome" % (config, args.scale, os.environ.get("MASTER_PORT", "0"))
+		if 0 == rank:
+			g0 = synth.Genome(gp, n_threads=min(cores, gp.n_contigs))
+			g0.save(shared + ".tmp")
+			os.replace(shared + ".tmp", shared)
+			del g0
+		barrier()
+		genome = synth.Genome(mapped_from=shared)
+		barrier()
+		if 0 == rank:
+			os.unlink(shared)
+	else:
+		genome = synth.Genome(gp, n_threads=min(threads, gp.n_contigs))
 	t1 = time.time()
 	reads = synth.Reads(genome, rp, n_threads=threads)
 	batch = reads.batch()
@@ -213,10 +311,22 @@ def main():
 	if args.sorted:
 		order = np.lexsort((batch["src_pos"], batch["src_entry"]))
 		batch = synth.reorder_batch(batch, order)
-	log("%s; scale %.4g: genome %.1f s, %d records %.1f s (%d host threads)" % (desc, args.scale, t1 - t0, n_local, time.time() - t1, threads))
+	t_reads = time.time()
+	log("%s; scale %.4g: genome %.1f s, %d records %.1f s (%d host threads)" % (desc, args.scale, t1 - t0, n_local, t_reads - t1, threads))
 
 	index = panvc3_amd.Index()
 	genome.fill_index(index)
+	import resource
+	# every rank's set-up on one line each (stderr): what an N-rank launch costs before the first kernel
+	print("[bench] rank %d of %d: set-up %.1f s (genome %.1f, reads %.1f, index on the host %.1f; %d threads), peak resident set %.0f MB"
+		  % (rank, world, time.time() - t0, t1 - t0, t_reads - t1, time.time() - t_reads, threads, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0), file=sys.stderr, flush=True)
+	if setup_only:
+		barrier()
+		if use_dist:
+			dist.destroy_process_group()
+		if 0 == rank:
+			print(json.dumps({"setup_only": True, "n_ranks": world, "records_per_rank": n_local, "seconds": time.time() - t0}), flush=True)
+		return
 	ctx = panvc3_amd.Context(local_rank)
 	ctx.set_option("window_read_length", int(rp.read_len))		# position windows of 128 bytes up to 158 bases, 256 beyond (what a caller that knows its reads passes)
 	for kv in args.option:
@@ -236,10 +346,6 @@ def main():
 		# GPU on one node they would add up to > 20 GB of host memory per rank.
 		batch = None
 		del reads, genome, index
-
-	def barrier():
-		if use_dist:
-			dist.barrier()
 
 	# ---- warm-up (also sizes the workspaces) -------------------------------------------------------------------------------
 	stats = None
@@ -329,11 +435,19 @@ def main():
 		if world == 1 and not args.skip_host_buffers:
 			k = int(min(n_local, 4_000_000))
 			sb = synth.slice_batch(batch, 0, k)
-			panvc3_amd.project_batch(ctx, synth.slice_batch(batch, 0, min(k, 100_000)))		# first-use allocations
-			tb = time.perf_counter()
-			panvc3_amd.project_batch(ctx, sb)
-			dt = time.perf_counter() - tb
-			result["host_buffers"] = {"value": k / dt, "unit": "alignments/s", "records": k, "what": "pvc3_batch_project: pageable host arrays in, host arrays out (H2D + kernels + D2H, no overlap between batches)"}
+			from panvc3_amd import api as pvc3_api
+			_, _ = pvc3_api.batch_project_call(ctx, synth.slice_batch(batch, 0, min(k, 100_000)), params)		# first-use allocations
+			# pvc3_batch_project itself (the call INTEGRATION.md §2 shows): ordinary arrays in, ordinary arrays out; three calls in a row, the
+			# result arrays of the first used again by the others (a caller in a loop has them)
+			rates, keep_out = [], None
+			for _ in range(3):
+				tb = time.perf_counter()
+				res_hb, _ = pvc3_api.batch_project_call(ctx, sb, params, out=keep_out)
+				rates.append(k / (time.perf_counter() - tb))
+				keep_out = res_hb["_arrays"]
+			del res_hb, keep_out
+			result["host_buffers"] = {"value": rates[-1], "unit": "alignments/s", "records": k, "calls": rates,
+				"what": "pvc3_batch_project: ordinary (pageable) host arrays in, host arrays out (H2D + kernels + D2H, no overlap between batches; the arrays travel through the context's page-locked staging ring); three calls in a row, `value` is the last"}
 			# the same with the arrays in page-locked memory (pvc3_host_alloc), as a caller that fills them directly would have them
 			pb, owners = panvc3_amd.pinned_batch(sb)
 			res0, _ = panvc3_amd.project_batch(ctx, pb, pinned_out=True)		# the output arrays are reused below
@@ -392,10 +506,25 @@ def main():
 			result["parity_sample"] = {"records": sample, "bit_identical": bool(same)}
 			if not same:
 				raise SystemExit("parity failure against the oracle on the bench sample")
-		print(json.dumps(result), flush=True)
 
 	db.close()
 	ctx.close()
+	if rank == 0:
+		# ---- the other single-GPU configurations of BASELINE.json at full size (never `value`): C5 = configs[4], C3G = C3 on a gap-dense MSA ----
+		if world == 1 and not args.skip_host_buffers and args.other_configs:
+			batch = reads = genome = index = None
+			result["other_configs"] = {}
+			for oc in [c.strip().upper() for c in args.other_configs.split(",") if c.strip()]:
+				if oc == config:
+					continue
+				try:
+					result["other_configs"][oc] = measure_other_config(oc, args, local_rank, threads, cores)
+					log("%s: %.2f ms per step" % (oc, result["other_configs"][oc]["ms_per_step"]))
+				except SystemExit:
+					raise
+				except Exception as exc:
+					result["other_configs"][oc] = {"error": str(exc)[-300:]}
+		print(json.dumps(result), flush=True)
 	if use_dist:
 		dist.barrier()
 		dist.destroy_process_group()

@@ -190,7 +190,9 @@ PVC3_API int pvc3_context_synchronize(pvc3_context *ctx);
  * alignment scratch slots together never exceed it), "trace_initial" (32-bit words of the alignment trace buffer), "arena_initial", "runs_initial",
  * "fast_path" (0: no lane-parallel compare in k_project_fast), "mid_path" (0: skip k_project_mid; with both at 0 every
  * record goes through the cooperative column walk of k_project_general), "packed_dp" (0: every indel run is aligned by the
- * striped one-run-per-wavefront kernel instead of the packed kernels); and those that take effect at the next
+ * striped one-run-per-wavefront kernel instead of the packed kernels), "staging_threads" (default 4: the threads that move
+ * ORDINARY host arrays — not page-locked ones — through the context's page-locked staging chunks on their way to and from
+ * the device; set before the first such copy); and those that take effect at the next
  * pvc3_context_upload_index and cost HBM only:
  * "position_windows" (default 1): for every entry and the entry it is projected to, one 128- or 256-byte line per 64 or 128
  *   source positions that holds what a record starting there needs of the index — start column, projected position, the
@@ -247,6 +249,10 @@ PVC3_API int pvc3_pipeline_submit(pvc3_pipeline *pipeline, pvc3_batch_in const *
  * it had one (PVC3_E_CAPACITY: results larger than the output arrays; PVC3_E_INVALID: malformed offsets). */
 PVC3_API int pvc3_pipeline_wait(pvc3_pipeline *pipeline, pvc3_batch_stats *stats);
 PVC3_API int pvc3_pipeline_in_flight(pvc3_pipeline const *pipeline, uint32_t *count);
+/* Waits until every copy and kernel queued by this pipeline has run (the batches stay in flight: their results are still
+ * collected with pvc3_pipeline_wait).  A caller that runs a batch of its own on the same context next to the pipeline
+ * (pvc3_dbatch_*) calls this first: the context's alignment scratch and trace buffers are shared by all its batches. */
+PVC3_API int pvc3_pipeline_synchronize(pvc3_pipeline *pipeline);
 
 /* Page-locked host memory for the batch arrays (hipHostMalloc): with pageable arrays the copies of pvc3_dbatch_create /
  * pvc3_dbatch_download run at about a third of the PCIe rate.  Any thread; free with pvc3_host_free. */

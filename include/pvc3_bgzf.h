@@ -81,6 +81,27 @@ PVC3_BGZF_API pvc3_bgzf_block *pvc3_bgzf_inflater_blocks(pvc3_bgzf_inflater *h, 
 PVC3_BGZF_API int pvc3_bgzf_inflater_submit(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t n_blocks, size_t in_bytes, size_t out_bytes);
 PVC3_BGZF_API int pvc3_bgzf_inflater_wait(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t const **status, float *kernel_ms);
 
+/* The device-resident form of the inflater, for a caller whose kernels read the inflated bytes (the record path,
+ * include/pvc3_records.h): the slot's input is uploaded as before, but the blocks' bytes go to DEVICE memory of the caller — block
+ * i's to d_out + blocks[i].out_off — and stay there.  What comes back is every block's status and the CRC-32 of its bytes,
+ * computed on the device, for the caller to compare with the checksum in the file.  (max_out_bytes of the create call may be 1
+ * for an inflater that is only used this way.)  When pvc3_bgzf_inflater_wait_device has returned, the bytes are in d_out. */
+PVC3_BGZF_API int pvc3_bgzf_inflater_submit_device(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t n_blocks, size_t in_bytes, void *d_out, size_t d_out_bytes);
+PVC3_BGZF_API int pvc3_bgzf_inflater_wait_device(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t const **status, uint32_t const **crc, float *kernel_ms);
+
+/* The device-resident form of the compressor: the uncompressed bytes are written by kernels of the caller straight into the
+ * compressor's device input (byte o of the stream at (o / PVC3_BGZF_BLOCK) * PVC3_BGZF_IN_STRIDE + PVC3_BGZF_IN_PAD + o %
+ * PVC3_BGZF_BLOCK of pvc3_bgzf_dev_input(h, slot)), and what comes back is the bytes of the BGZF FILE: every block with its gzip /
+ * BC header, stream, CRC-32 (computed on the device) and ISIZE, one behind the other, in page-locked memory.
+ * pvc3_bgzf_dev_submit may only be called when the kernels that wrote the slot's input have finished. */
+typedef struct pvc3_bgzf_dev pvc3_bgzf_dev;
+PVC3_BGZF_API int pvc3_bgzf_dev_create(int device, uint32_t max_blocks, uint32_t n_slots, pvc3_bgzf_dev **out);
+PVC3_BGZF_API void pvc3_bgzf_dev_destroy(pvc3_bgzf_dev *h);
+PVC3_BGZF_API void *pvc3_bgzf_dev_input(pvc3_bgzf_dev *h, uint32_t slot);			/* device pointer */
+PVC3_BGZF_API uint64_t pvc3_bgzf_dev_capacity(pvc3_bgzf_dev const *h);			/* uncompressed bytes per slot */
+PVC3_BGZF_API int pvc3_bgzf_dev_submit(pvc3_bgzf_dev *h, uint32_t slot, uint64_t n_bytes);
+PVC3_BGZF_API int pvc3_bgzf_dev_wait(pvc3_bgzf_dev *h, uint32_t slot, uint8_t const **file_bytes, uint64_t *n_file_bytes, float *kernel_ms);
+
 PVC3_BGZF_API char const *pvc3_bgzf_last_error(void);
 
 #ifdef __cplusplus

@@ -119,8 +119,22 @@ def lib():
 		"pvc3_pipeline_submit": ([vp, P(BatchIn), P(BatchOut), P(Params)], i32),
 		"pvc3_pipeline_wait": ([vp, P(BatchStats)], i32),
 		"pvc3_pipeline_in_flight": ([vp, P(u32)], i32),
+		"pvc3_pipeline_synchronize": ([vp], i32),
 		"pvc3_host_alloc": ([u64, P(vp)], i32),
 		"pvc3_host_free": ([vp], None),
+		# include/pvc3_records.h (the record path on the GPU; its caller is the C++ command line, the binding is for tests)
+		"pvc3_records_create": ([vp, vp, P(vp)], i32),
+		"pvc3_records_destroy": ([vp], None),
+		"pvc3_records_buffer": ([vp, u32, P(vp), P(u64)], i32),
+		"pvc3_records_upload": ([vp, u32, u64, vp, u64], i32),
+		"pvc3_records_frame": ([vp, u32, u64, vp, u32, u64, i32, vp, P(i32), P(u64)], i32),
+		"pvc3_records_project": ([vp, P(Params), P(BatchStats)], i32),
+		"pvc3_records_rewrite": ([vp, vp, u64, u32, u32, u32, P(u64), P(u64), P(i32), P(u64)], i32),
+		"pvc3_records_rewrite_to_host": ([vp, vp, u64, P(u64), P(u64), P(i32), P(u64)], i32),
+		"pvc3_records_runs": ([vp, vp, u64], i32),
+		"pvc3_records_removed_tags": ([vp, vp], i32),
+		"pvc3_records_batch_sizes": ([vp, P(u64), P(u64)], i32),
+		"pvc3_records_download_batch": ([vp] + [vp] * 14, i32),
 	}
 	for name, (argtypes, restype) in sig.items():
 		f = getattr(L, name)

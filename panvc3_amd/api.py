@@ -486,6 +486,41 @@ def project_batch(ctx, batch, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, pin
 		db.close()
 
 
+def batch_project_call(ctx, batch, params=None, out=None):
+	"""pvc3_batch_project, the one call of the C ABI with host arrays in and host arrays out: the context keeps
+	its device batch from call to call.  `out`: result arrays of a previous call to use again (their sizes are the capacities);
+	otherwise arrays with room for four times the input's CIGAR operations are made, and made larger if the call asks for it.
+	Returns (results, stats)."""
+	L = _lib.lib()
+	p = params if isinstance(params, Params) else make_params(**(params or {}))
+	bi, keep = _pack_batch_in(batch)
+	n = bi.n
+	n_cig_in = int(np.asarray(batch["cigar_off"])[-1]) if n else 0
+	if out is None:
+		out = dict(dst_pos=np.empty(n, np.uint32), mate_dst_pos=np.empty(n, np.uint32), status=np.empty(n, np.int32), out_cigar_off=np.empty(n + 1, np.uint64), run_off=np.empty(n + 1, np.uint64),
+				   out_cigar=np.empty(max(16, 4 * n_cig_in + 16 * n), np.uint32), runs=np.empty(max(16, n // 8 + 1024), RUN_DTYPE))
+	for attempt in range(2):
+		bo = BatchOut()
+		for k in ("dst_pos", "mate_dst_pos", "status", "out_cigar_off", "out_cigar", "run_off", "runs"):
+			setattr(bo, k, out[k].ctypes.data)
+		bo.out_cigar_cap = out["out_cigar"].size
+		bo.run_cap = out["runs"].size
+		st = BatchStats()
+		rc = L.pvc3_batch_project(ctx._h, C.byref(bi), C.byref(bo), C.byref(p), C.byref(st))
+		if -5 == rc and 0 == attempt:		# PVC3_E_CAPACITY: the sizes needed are in the offset arrays' last elements
+			out["out_cigar"] = np.empty(int(out["out_cigar_off"][n]) + 16, np.uint32)
+			out["runs"] = np.empty(int(out["run_off"][n]) + 16, RUN_DTYPE)
+			continue
+		check(rc)
+		break
+	stats = _stats_dict(st)
+	res = dict(out)
+	res["out_cigar"] = out["out_cigar"][:int(stats["out_cigar_total"])]
+	res["runs"] = out["runs"][:int(stats["n_runs"])]
+	res["_arrays"] = out
+	return res, stats
+
+
 class AlignmentProjector:
 	"""Mirror of panvc3::alignment_projector (include/panvc3/alignment_projector.hh:32-75) over the GPU path.
 

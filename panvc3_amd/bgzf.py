@@ -15,7 +15,8 @@ OUT_STRIDE = 65536
 SYMBOLS = ("pvc3_bgzf_create", "pvc3_bgzf_destroy", "pvc3_bgzf_max_blocks", "pvc3_bgzf_slot_input", "pvc3_bgzf_slot_lengths", "pvc3_bgzf_submit",
 		   "pvc3_bgzf_wait", "pvc3_bgzf_deflate", "pvc3_bgzf_last_error",
 		   "pvc3_bgzf_inflater_create", "pvc3_bgzf_inflater_destroy", "pvc3_bgzf_inflater_blocks_in_flight", "pvc3_bgzf_inflater_input", "pvc3_bgzf_inflater_output", "pvc3_bgzf_inflater_blocks",
-		   "pvc3_bgzf_inflater_submit", "pvc3_bgzf_inflater_wait")
+		   "pvc3_bgzf_inflater_submit", "pvc3_bgzf_inflater_wait", "pvc3_bgzf_inflater_submit_device", "pvc3_bgzf_inflater_wait_device",
+		   "pvc3_bgzf_dev_create", "pvc3_bgzf_dev_destroy", "pvc3_bgzf_dev_input", "pvc3_bgzf_dev_capacity", "pvc3_bgzf_dev_submit", "pvc3_bgzf_dev_wait")
 BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8")])
 _L = None
 
@@ -49,6 +50,17 @@ def lib():
 			getattr(L, name).restype = C.c_void_p
 		L.pvc3_bgzf_inflater_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t]
 		L.pvc3_bgzf_inflater_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_float)]
+		L.pvc3_bgzf_inflater_submit_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p, C.c_size_t]
+		L.pvc3_bgzf_inflater_wait_device.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float)]
+		L.pvc3_bgzf_dev_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+		L.pvc3_bgzf_dev_destroy.argtypes = [C.c_void_p]
+		L.pvc3_bgzf_dev_destroy.restype = None
+		L.pvc3_bgzf_dev_input.argtypes = [C.c_void_p, C.c_uint32]
+		L.pvc3_bgzf_dev_input.restype = C.c_void_p
+		L.pvc3_bgzf_dev_capacity.argtypes = [C.c_void_p]
+		L.pvc3_bgzf_dev_capacity.restype = C.c_uint64
+		L.pvc3_bgzf_dev_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+		L.pvc3_bgzf_dev_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
 		_L = L
 	return _L
 
@@ -154,6 +166,60 @@ class BlockInflater:
 			got.append(out[o:o + n].tobytes() if 0 == status[i] else None)
 			o += n
 		return got, status, best
+
+
+_HIP = None
+
+
+def hip_runtime():
+	"""The HIP runtime the library is linked with, for the few raw calls the device-resident forms need in tests and tools
+	(hipMalloc / hipMemcpy / hipFree of buffers that kernels of the caller would write in the product)."""
+	global _HIP
+	if _HIP is None:
+		lib()
+		H = C.CDLL("libamdhip64.so")
+		H.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+		H.hipFree.argtypes = [C.c_void_p]
+		H.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+		H.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+		_HIP = H
+	return _HIP
+
+
+H2D, D2H = 1, 2
+
+
+class DeviceCompressor:
+	"""pvc3_bgzf_dev_*: the compressor whose input lies in device memory (here filled with hipMemcpy; in the product by the record
+	path's kernels).  deflate() returns the bytes of the BGZF file: blocks with header, stream, CRC-32 and ISIZE."""
+
+	def __init__(self, device=0, max_blocks=256, n_slots=2):
+		self._L = lib()
+		h = C.c_void_p()
+		_check(self._L.pvc3_bgzf_dev_create(device, max_blocks, n_slots, C.byref(h)))
+		self._h = h
+		self.max_blocks = max_blocks
+
+	def close(self):
+		if self._h:
+			self._L.pvc3_bgzf_dev_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		self.close()
+
+	def deflate(self, data, slot=0):
+		data = bytes(data)
+		assert 0 < len(data) <= self._L.pvc3_bgzf_dev_capacity(self._h)
+		d_in = self._L.pvc3_bgzf_dev_input(self._h, slot)
+		H = hip_runtime()
+		for b in range(0, -(-len(data) // BLOCK)):
+			chunk = data[b * BLOCK:(b + 1) * BLOCK]
+			assert 0 == H.hipMemcpy(d_in + b * IN_STRIDE + IN_PAD, chunk, len(chunk), H2D)
+		_check(self._L.pvc3_bgzf_dev_submit(self._h, slot, len(data)))
+		out, n, ms = C.c_void_p(), C.c_uint64(), C.c_float()
+		_check(self._L.pvc3_bgzf_dev_wait(self._h, slot, C.byref(out), C.byref(n), C.byref(ms)))
+		return C.string_at(out, n.value), ms.value
 
 
 def bgzf_member(stream, data):

@@ -31,6 +31,7 @@
 #include <new>
 
 #include "../../include/pvc3_bgzf.h"
+#include "crc32_device.hpp"
 
 thread_local char g_bgzf_error[256];		// the message of the calling thread's last failure (both files of the library)
 
@@ -471,6 +472,70 @@ __global__ __launch_bounds__(WAVE) void k_deflate_blocks(
 	}
 }
 
+// ---- the device-resident form: blocks whose bytes a kernel of the caller wrote (pvc3_bgzf_dev_*) ---------------------------------------
+// k_block_lengths: the lengths of the blocks of n_bytes of input.  k_frame_blocks: every block as it lies in a BGZF file — the
+// 18-byte gzip header with the BC field, the stream, CRC-32 and ISIZE (SAMv1 §4.1.1) — one behind the other, so that what
+// comes back from the GPU is written to the file as it is.
+__global__ void k_block_lengths(uint64_t n_bytes, uint32_t n_blocks, uint32_t *__restrict__ len)
+{
+	uint32_t const b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_blocks) return;
+	uint64_t const lo = (uint64_t) b * PVC3_BGZF_BLOCK;
+	len[b] = (uint32_t) ((n_bytes - lo < PVC3_BGZF_BLOCK) ? (n_bytes - lo) : PVC3_BGZF_BLOCK);
+}
+
+// Exclusive prefix sums of the framed sizes by one workgroup (a few thousand blocks); file_off[n_blocks] = total.
+__global__ __launch_bounds__(1024) void k_frame_offsets(uint32_t const *__restrict__ out_len, uint32_t n_blocks, uint64_t *__restrict__ file_off)
+{
+	__shared__ uint64_t part[1024];
+	__shared__ uint64_t carry;
+	if (0 == threadIdx.x) carry = 0;
+	__syncthreads();
+	for (uint32_t b0 = 0; b0 < n_blocks; b0 += 1024)
+	{
+		uint32_t const b = b0 + threadIdx.x;
+		uint64_t const v = (b < n_blocks) ? (uint64_t) (18 + (out_len[b] & ~SIZE_MISMATCH) + 8) : 0;
+		part[threadIdx.x] = v;
+		__syncthreads();
+		for (uint32_t d = 1; d < 1024; d <<= 1)
+		{
+			uint64_t const t = (threadIdx.x >= d) ? part[threadIdx.x - d] : 0;
+			__syncthreads();
+			part[threadIdx.x] += t;
+			__syncthreads();
+		}
+		if (b < n_blocks) file_off[b] = carry + part[threadIdx.x] - v;
+		__syncthreads();
+		if (1023 == threadIdx.x) carry += part[1023];
+		__syncthreads();
+	}
+	if (0 == threadIdx.x) file_off[n_blocks] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_frame_blocks(uint8_t const *__restrict__ streams, uint32_t const *__restrict__ out_len, uint32_t const *__restrict__ in_len, uint32_t const *__restrict__ crc,
+	uint64_t const *__restrict__ file_off, uint32_t n_blocks, uint8_t *__restrict__ file)
+{
+	for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x)
+	{
+		uint32_t const clen = out_len[b] & ~SIZE_MISMATCH;
+		uint8_t *dst = file + file_off[b];
+		uint8_t const *src = streams + (size_t) b * PVC3_BGZF_OUT_STRIDE;
+		uint32_t const bsize = 18 + clen + 8;
+		if (threadIdx.x < 18)
+		{
+			uint8_t const head[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t) ((bsize - 1) & 0xff), (uint8_t) ((bsize - 1) >> 8)};
+			dst[threadIdx.x] = head[threadIdx.x];
+		}
+		else if (threadIdx.x < 26)
+		{
+			uint32_t const k = threadIdx.x - 18;
+			uint32_t const v = (k < 4) ? crc[b] : in_len[b];
+			dst[18 + clen + k] = (uint8_t) (v >> (8 * (k & 3)));
+		}
+		for (uint32_t x = threadIdx.x; x < clen; x += 256) dst[18 + x] = src[x];
+	}
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 
 int fail(int code, char const *what, hipError_t e = hipSuccess)
@@ -646,6 +711,152 @@ int pvc3_bgzf_deflate(pvc3_bgzf *h, uint8_t const *src, size_t n, uint32_t piece
 			dst_len[first + i] = ol[i];
 		}
 	}
+	return 0;
+}
+
+// ---- pvc3_bgzf_dev_* -------------------------------------------------------------------------------------------------------------------
+}	// extern "C"
+
+struct pvc3_bgzf_dev
+{
+	int device{};
+	uint32_t max_blocks{}, n_slots{}, grid_max{};
+	hipStream_t stream{};
+	uint8_t *d_out{}, *d_file{};
+	uint32_t *d_len{}, *d_out_len{}, *d_tokens{}, *d_crc{};
+	uint64_t *d_file_off{};
+	pvc3_crc::tables *d_crc_tables{};
+	size_t file_cap{};
+	struct slot
+	{
+		uint8_t *d_in{};				// the caller's kernels write here
+		uint8_t *h_file{};				// page-locked: the framed blocks
+		uint32_t *h_out_len{};
+		uint64_t *h_file_off{};
+		hipEvent_t start{}, stop{}, sizes{}, done{};
+		uint32_t n{};
+		bool busy{};
+	} slots[4];
+};
+
+extern "C" {
+
+void pvc3_bgzf_dev_destroy(pvc3_bgzf_dev *h)
+{
+	if (!h) return;
+	(void) hipSetDevice(h->device);
+	if (h->stream) (void) hipStreamSynchronize(h->stream);
+	for (auto &s : h->slots)
+	{
+		for (hipEvent_t e : {s.start, s.stop, s.sizes, s.done}) if (e) (void) hipEventDestroy(e);
+		if (s.d_in) (void) hipFree(s.d_in);
+		if (s.h_file) (void) hipHostFree(s.h_file);
+		if (s.h_out_len) (void) hipHostFree(s.h_out_len);
+		if (s.h_file_off) (void) hipHostFree(s.h_file_off);
+	}
+	for (void *p : {(void *) h->d_out, (void *) h->d_file, (void *) h->d_len, (void *) h->d_out_len, (void *) h->d_tokens, (void *) h->d_crc, (void *) h->d_file_off, (void *) h->d_crc_tables})
+		if (p) (void) hipFree(p);
+	if (h->stream) (void) hipStreamDestroy(h->stream);
+	delete h;
+}
+
+int pvc3_bgzf_dev_create(int device, uint32_t max_blocks, uint32_t n_slots, pvc3_bgzf_dev **out)
+{
+	if (!out || 0 == max_blocks || max_blocks > (1u << 20) || 0 == n_slots || n_slots > 4) return fail(E_INVALID, "pvc3_bgzf_dev_create: bad argument");
+	*out = nullptr;
+	int count = 0;
+	if (hipSuccess != hipGetDeviceCount(&count) || device < 0 || device >= count) return fail(E_NO_DEVICE, "pvc3_bgzf_dev_create: no such GPU");
+	HIP_TRY(hipSetDevice(device), "hipSetDevice");
+	pvc3_bgzf_dev *h = new (std::nothrow) pvc3_bgzf_dev;
+	if (!h) return fail(E_NOMEM, "out of memory");
+	h->device = device; h->max_blocks = max_blocks; h->n_slots = n_slots;
+	int rc = 0;
+	auto check = [&](hipError_t e, char const *what) { if (0 == rc && hipSuccess != e) rc = fail((hipErrorOutOfMemory == e) ? E_NOMEM : E_HIP, what, e); };
+	hipDeviceProp_t prop;
+	check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+	if (0 == rc)
+	{
+		int per_cu = 0;
+		check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate_blocks, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+		if (per_cu < 1) per_cu = 1;
+		h->grid_max = (uint32_t) prop.multiProcessorCount * (uint32_t) per_cu;
+		if (h->grid_max > max_blocks) h->grid_max = max_blocks;
+	}
+	check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
+	size_t const in_bytes = (size_t) max_blocks * PVC3_BGZF_IN_STRIDE, out_bytes = (size_t) max_blocks * PVC3_BGZF_OUT_STRIDE;
+	h->file_cap = (size_t) max_blocks * (PVC3_BGZF_BLOCK + 5 + 26);		// a block that does not shrink is stored: five bytes more
+	if (0 == rc) check(hipMalloc((void **) &h->d_out, out_bytes), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_file, h->file_cap), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_len, max_blocks * sizeof(uint32_t)), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_out_len, max_blocks * sizeof(uint32_t)), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_crc, max_blocks * sizeof(uint32_t)), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_file_off, ((size_t) max_blocks + 1) * sizeof(uint64_t)), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_tokens, (size_t) h->grid_max * TOKENS_PER_WAVE * sizeof(uint32_t)), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_crc_tables, sizeof(pvc3_crc::tables)), "hipMalloc");
+	if (0 == rc) { pvc3_crc::tables const t = pvc3_crc::make_tables(); check(hipMemcpy(h->d_crc_tables, &t, sizeof(t), hipMemcpyHostToDevice), "hipMemcpy"); }
+	for (uint32_t i = 0; i < n_slots && 0 == rc; ++i)
+	{
+		auto &s = h->slots[i];
+		check(hipMalloc((void **) &s.d_in, in_bytes), "hipMalloc");
+		if (0 == rc) check(hipMemset(s.d_in, 0, in_bytes), "hipMemset");		// (the pads in front of the blocks are read)
+		if (0 == rc) check(hipHostMalloc((void **) &s.h_file, h->file_cap, hipHostMallocDefault), "hipHostMalloc");
+		if (0 == rc) check(hipHostMalloc((void **) &s.h_out_len, max_blocks * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+		if (0 == rc) check(hipHostMalloc((void **) &s.h_file_off, ((size_t) max_blocks + 1) * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc");
+		if (0 == rc) check(hipEventCreate(&s.start), "hipEventCreate");
+		if (0 == rc) check(hipEventCreate(&s.stop), "hipEventCreate");
+		if (0 == rc) check(hipEventCreateWithFlags(&s.sizes, hipEventDisableTiming), "hipEventCreate");
+		if (0 == rc) check(hipEventCreateWithFlags(&s.done, hipEventDisableTiming), "hipEventCreate");
+	}
+	if (rc) { char keep[sizeof(g_bgzf_error)]; std::memcpy(keep, g_bgzf_error, sizeof(keep)); pvc3_bgzf_dev_destroy(h); std::memcpy(g_bgzf_error, keep, sizeof(keep)); return rc; }
+	*out = h;
+	return 0;
+}
+
+void *pvc3_bgzf_dev_input(pvc3_bgzf_dev *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].d_in : nullptr; }
+uint64_t pvc3_bgzf_dev_capacity(pvc3_bgzf_dev const *h) { return h ? (uint64_t) h->max_blocks * PVC3_BGZF_BLOCK : 0; }
+
+int pvc3_bgzf_dev_submit(pvc3_bgzf_dev *h, uint32_t slot, uint64_t n_bytes)
+{
+	if (!h || slot >= h->n_slots || 0 == n_bytes || n_bytes > (uint64_t) h->max_blocks * PVC3_BGZF_BLOCK) return fail(E_INVALID, "pvc3_bgzf_dev_submit: bad argument");
+	auto &s = h->slots[slot];
+	if (s.busy) return fail(E_STATE, "pvc3_bgzf_dev_submit: the slot has not been waited for");
+	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+	uint32_t const n_blocks = (uint32_t) ((n_bytes + PVC3_BGZF_BLOCK - 1) / PVC3_BGZF_BLOCK);
+	uint32_t const grid = (n_blocks < h->grid_max) ? n_blocks : h->grid_max;
+	hipLaunchKernelGGL(k_block_lengths, dim3((n_blocks + 255) / 256), dim3(256), 0, h->stream, n_bytes, n_blocks, h->d_len);
+	HIP_TRY(hipEventRecord(s.start, h->stream), "hipEventRecord");
+	hipLaunchKernelGGL(k_deflate_blocks, dim3(grid), dim3(WAVE), 0, h->stream, s.d_in, h->d_len, h->d_out, h->d_out_len, h->d_tokens, n_blocks);
+	HIP_TRY(hipGetLastError(), "k_deflate_blocks");
+	HIP_TRY(hipEventRecord(s.stop, h->stream), "hipEventRecord");
+	hipLaunchKernelGGL(pvc3_crc::k_crc32_ranges, dim3((n_blocks < 4096) ? n_blocks : 4096), dim3(64), 0, h->stream, s.d_in, nullptr, h->d_len, PVC3_BGZF_IN_STRIDE, PVC3_BGZF_IN_PAD, n_blocks, h->d_crc_tables, h->d_crc);
+	hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, h->stream, h->d_out_len, n_blocks, h->d_file_off);
+	hipLaunchKernelGGL(k_frame_blocks, dim3((n_blocks < 2048) ? n_blocks : 2048), dim3(256), 0, h->stream, h->d_out, h->d_out_len, h->d_len, h->d_crc, h->d_file_off, n_blocks, h->d_file);
+	HIP_TRY(hipGetLastError(), "k_frame_blocks");
+	HIP_TRY(hipMemcpyAsync(s.h_out_len, h->d_out_len, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(s.h_file_off, h->d_file_off, ((size_t) n_blocks + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipEventRecord(s.sizes, h->stream), "hipEventRecord");
+	s.n = n_blocks; s.busy = true;
+	return 0;
+}
+
+int pvc3_bgzf_dev_wait(pvc3_bgzf_dev *h, uint32_t slot, uint8_t const **file_bytes, uint64_t *n_file_bytes, float *kernel_ms)
+{
+	if (!h || slot >= h->n_slots || !file_bytes || !n_file_bytes) return fail(E_INVALID, "pvc3_bgzf_dev_wait: bad argument");
+	auto &s = h->slots[slot];
+	if (!s.busy) return fail(E_STATE, "pvc3_bgzf_dev_wait: nothing was submitted");
+	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+	s.busy = false;
+	// The sizes first: how many bytes the framed blocks are is known on the device only; then exactly those bytes.
+	HIP_TRY(hipEventSynchronize(s.sizes), "hipEventSynchronize");
+	for (uint32_t i = 0; i < s.n; ++i)
+		if (s.h_out_len[i] & SIZE_MISMATCH) return fail(E_STATE, "k_deflate_blocks: a stream is not as long as computed");
+	uint64_t const total = s.h_file_off[s.n];
+	if (total > h->file_cap) return fail(E_STATE, "pvc3_bgzf_dev_wait: the framed blocks exceed their buffer");
+	HIP_TRY(hipMemcpyAsync(s.h_file, h->d_file, total, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
+	HIP_TRY(hipEventSynchronize(s.done), "hipEventSynchronize");
+	if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, s.start, s.stop), "hipEventElapsedTime");
+	*file_bytes = s.h_file; *n_file_bytes = total;
 	return 0;
 }
 

@@ -30,6 +30,7 @@
 #include <new>
 
 #include "../../include/pvc3_bgzf.h"
+#include "crc32_device.hpp"
 
 extern thread_local char g_bgzf_error[256];		// deflate.hip
 
@@ -550,11 +551,17 @@ struct pvc3_bgzf_inflater
 	uint8_t *d_in{}, *d_out{};
 	pvc3_bgzf_block *d_blocks{};
 	uint32_t *d_status{};
+	// the device-resident form (pvc3_bgzf_inflater_submit_device): where the blocks' bytes went and their checksums
+	uint64_t *d_off{};
+	uint32_t *d_lens{}, *d_crc{};
+	pvc3_crc::tables *d_crc_tables{};
 	struct slot
 	{
 		uint8_t *h_in{}, *h_out{};
 		pvc3_bgzf_block *h_blocks{};
 		uint32_t *h_status{};
+		uint64_t *h_off{};
+		uint32_t *h_lens{}, *h_crc{};
 		hipEvent_t start{}, stop{}, done{};
 		uint32_t n{};
 		bool busy{};
@@ -574,6 +581,9 @@ void pvc3_bgzf_inflater_destroy(pvc3_bgzf_inflater *h)
 		if (s.h_out) (void) hipHostFree(s.h_out);
 		if (s.h_blocks) (void) hipHostFree(s.h_blocks);
 		if (s.h_status) (void) hipHostFree(s.h_status);
+		if (s.h_off) (void) hipHostFree(s.h_off);
+		if (s.h_lens) (void) hipHostFree(s.h_lens);
+		if (s.h_crc) (void) hipHostFree(s.h_crc);
 		if (s.start) (void) hipEventDestroy(s.start);
 		if (s.stop) (void) hipEventDestroy(s.stop);
 		if (s.done) (void) hipEventDestroy(s.done);
@@ -582,6 +592,7 @@ void pvc3_bgzf_inflater_destroy(pvc3_bgzf_inflater *h)
 	if (h->d_out) (void) hipFree(h->d_out);
 	if (h->d_blocks) (void) hipFree(h->d_blocks);
 	if (h->d_status) (void) hipFree(h->d_status);
+	for (void *p : {(void *) h->d_off, (void *) h->d_lens, (void *) h->d_crc, (void *) h->d_crc_tables}) if (p) (void) hipFree(p);
 	if (h->stream) (void) hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -658,6 +669,71 @@ int pvc3_bgzf_inflater_submit(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t n_b
 	if (out_bytes) HIP_TRY(hipMemcpyAsync(s.h_out, h->d_out, out_bytes, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
 	HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
 	s.n = n_blocks; s.busy = true;
+	return 0;
+}
+
+// The device-resident form: the slot's input is uploaded as before, but the blocks' bytes go to DEVICE memory of the caller (block
+// i's at d_out + blocks[i].out_off) and stay there; what comes back is every block's status and the CRC-32 of its bytes, computed
+// on the device, for the caller to compare with the checksum in the file.  max_out_bytes of pvc3_bgzf_inflater_create may be 1 for
+// an inflater that is only used this way (no page-locked output is needed).
+int pvc3_bgzf_inflater_submit_device(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t n_blocks, size_t in_bytes, void *d_out, size_t d_out_bytes)
+{
+	if (!h || slot >= h->n_slots || 0 == n_blocks || n_blocks > h->max_blocks || in_bytes > h->max_in || !d_out)
+		return fail(E_INVALID, "pvc3_bgzf_inflater_submit_device: bad argument");
+	auto &s = h->slots[slot];
+	if (s.busy) return fail(E_STATE, "pvc3_bgzf_inflater_submit_device: the slot has not been waited for");
+	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+	if (!h->d_off)
+	{
+		HIP_TRY(hipMalloc((void **) &h->d_off, h->max_blocks * sizeof(uint64_t)), "hipMalloc");
+		HIP_TRY(hipMalloc((void **) &h->d_lens, h->max_blocks * sizeof(uint32_t)), "hipMalloc");
+		HIP_TRY(hipMalloc((void **) &h->d_crc, h->max_blocks * sizeof(uint32_t)), "hipMalloc");
+		HIP_TRY(hipMalloc((void **) &h->d_crc_tables, sizeof(pvc3_crc::tables)), "hipMalloc");
+		pvc3_crc::tables const t = pvc3_crc::make_tables();
+		HIP_TRY(hipMemcpy(h->d_crc_tables, &t, sizeof(t), hipMemcpyHostToDevice), "hipMemcpy");
+	}
+	if (!s.h_off)
+	{
+		HIP_TRY(hipHostMalloc((void **) &s.h_off, h->max_blocks * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc");
+		HIP_TRY(hipHostMalloc((void **) &s.h_lens, h->max_blocks * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+		HIP_TRY(hipHostMalloc((void **) &s.h_crc, h->max_blocks * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+	}
+	for (uint32_t i = 0; i < n_blocks; ++i)
+	{
+		pvc3_bgzf_block const &b = s.h_blocks[i];
+		if (b.in_off > in_bytes || b.in_len > in_bytes - b.in_off || b.out_off > d_out_bytes || b.out_len > d_out_bytes - b.out_off)
+			return fail(E_INVALID, "pvc3_bgzf_inflater_submit_device: a block outside the slot's input or the output");
+		s.h_off[i] = b.out_off; s.h_lens[i] = b.out_len;
+	}
+	HIP_TRY(hipMemcpyAsync(h->d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(h->d_blocks, s.h_blocks, n_blocks * sizeof(pvc3_bgzf_block), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(h->d_off, s.h_off, n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(h->d_lens, s.h_lens, n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
+	uint32_t const grid = (n_blocks < h->grid_max) ? n_blocks : h->grid_max;
+	HIP_TRY(hipEventRecord(s.start, h->stream), "hipEventRecord");
+	hipLaunchKernelGGL(k_inflate_blocks, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, (uint8_t *) d_out, h->d_status, n_blocks);
+	HIP_TRY(hipGetLastError(), "k_inflate_blocks");
+	HIP_TRY(hipEventRecord(s.stop, h->stream), "hipEventRecord");
+	hipLaunchKernelGGL(pvc3_crc::k_crc32_ranges, dim3((n_blocks < 4096) ? n_blocks : 4096), dim3(64), 0, h->stream, (uint8_t const *) d_out, h->d_off, h->d_lens, 0u, 0u, n_blocks, h->d_crc_tables, h->d_crc);
+	HIP_TRY(hipGetLastError(), "k_crc32_ranges");
+	HIP_TRY(hipMemcpyAsync(s.h_status, h->d_status, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(s.h_crc, h->d_crc, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
+	s.n = n_blocks; s.busy = true;
+	return 0;
+}
+
+int pvc3_bgzf_inflater_wait_device(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t const **status, uint32_t const **crc, float *kernel_ms)
+{
+	if (!h || slot >= h->n_slots) return fail(E_INVALID, "pvc3_bgzf_inflater_wait_device: bad argument");
+	auto &s = h->slots[slot];
+	if (!s.busy) return fail(E_STATE, "pvc3_bgzf_inflater_wait_device: nothing was submitted");
+	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+	s.busy = false;
+	HIP_TRY(hipEventSynchronize(s.done), "hipEventSynchronize");
+	if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, s.start, s.stop), "hipEventElapsedTime");
+	if (status) *status = s.h_status;
+	if (crc) *crc = s.h_crc;
 	return 0;
 }
 

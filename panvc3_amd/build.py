@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpvc3_hip.so")
-SOURCES = ["api.cpp", "index.cpp", "kernels.hip", "project_fast.hip", "project_probes.hip", "project_mid.hip", "project_general.hip", "realign.hip", "mapq.hip"]
+SOURCES = ["api.cpp", "records_api.cpp", "index.cpp", "kernels.hip", "project_fast.hip", "project_probes.hip", "project_mid.hip", "project_general.hip", "realign.hip", "mapq.hip", "records.hip"]
 ARCH = "gfx950"
 
 
@@ -51,6 +51,7 @@ def _plan():
 	"""(compile steps [(object, key, command)], link step (marker, key, command))."""
 	headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
 	headers.append(os.path.join(HERE, "..", "include", "pvc3.h"))
+	headers.append(os.path.join(HERE, "..", "include", "pvc3_records.h"))
 	flags = [
 		"-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off", "-fvisibility=hidden",
 		"-Wall", "-Wextra", "-Wno-unused-parameter", "-x", "hip",
@@ -110,7 +111,7 @@ def build_bgzf(force=False, verbose=False):
 	the BAM writer's, not the projection's, and kernel_key() above stays the key of the projection kernels alone."""
 	os.makedirs(OBJ, exist_ok=True)
 	cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fvisibility=hidden", "-Wall", "-Wextra", "-shared", "-o", BGZF_LIB] + BGZF_SRC
-	key = _key(BGZF_SRC + [os.path.join(HERE, "..", "include", "pvc3_bgzf.h")], cmd[1:])
+	key = _key(BGZF_SRC + [os.path.join(HERE, "bgzf", "crc32_device.hpp"), os.path.join(HERE, "..", "include", "pvc3_bgzf.h")], cmd[1:])
 	marker = os.path.join(OBJ, "libpvc3_bgzf.so")
 	if force or not os.path.exists(BGZF_LIB) or _stale(marker, key):
 		if verbose:
@@ -129,7 +130,7 @@ def build_host(force=False, verbose=False):
 	"""The C++ host pipeline (g++): bin/panvc3_index_msa and bin/panvc3_project_alignments (the latter links libpvc3_hip.so)."""
 	build(force=False, verbose=verbose)
 	os.makedirs(BIN, exist_ok=True)
-	headers = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "pvc3.h"), os.path.join(HERE, "..", "include", "pvc3_bgzf.h")]
+	headers = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", f) for f in ("pvc3.h", "pvc3_bgzf.h", "pvc3_records.h")]
 	cxx = os.environ.get("CXX", "g++")
 	flags = ["-O2", "-g", "-std=c++17", "-Wall", "-Wextra", "-pthread"]
 	out = []

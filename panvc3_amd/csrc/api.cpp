@@ -13,6 +13,8 @@
 
 #include "host_state.hpp"
 #include "pvc3_internal.hpp"
+#include "staging.hpp"
+#include "context.hpp"
 
 using namespace pvc3;
 
@@ -33,85 +35,6 @@ int set_error(int code, char const *fmt, ...)
 
 #define HIP_TRY(expr) do { hipError_t const e_ = (expr); if (hipSuccess != e_) return set_error((hipErrorOutOfMemory == e_) ? PVC3_E_NOMEM : PVC3_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 #define PVC3_TRY(expr) do { int const rc_ = (expr); if (rc_) return rc_; } while (0)
-
-struct pvc3_context
-{
-	int device{};
-	hipStream_t own_stream{};
-	hipStream_t stream{};
-	bool timing{};
-	hipEvent_t ev[8]{};
-
-	// Index replica in HBM.
-	std::vector <void *> index_allocs;
-	dev_entry *d_entries{};
-	uint32_t n_entries{};
-	uint64_t index_bytes{};
-	uint64_t workspace_bytes{};
-
-	dev_params *d_params{};
-	pvc3_params params{0, 0, -1, 0};
-
-	// Options.
-	uint32_t realign_waves{8192};		// packed alignment kernels: one 64-thread block each
-	uint32_t big_waves{1024};			// striped alignment kernel (runs that do not fit the packed kernels): waves = scratch slots
-	uint32_t realign_lds_bytes{};
-	uint64_t scratch_per_wave{128 * 1024};
-	uint64_t scratch_budget{UINT64_C(8) << 30};	// the scratch slots together never exceed this: fewer waves when one run needs a large slot
-	uint64_t arena_initial{};
-	uint64_t runs_initial{};
-	uint32_t fast_path{1};
-	uint32_t mid_path{1};
-	uint32_t packed_dp{1};
-	uint32_t paired_blocks{1};			// upload_index: paired copies of the gap bit-vector blocks (dev_entry::paired)
-	uint32_t text_window{1};			// upload_index: windowed copies of the packed texts (dev_entry::text4w; only without position windows)
-	uint32_t position_windows{1};		// upload_index: position windows (dev_entry::pwin) when they fit the device
-	uint32_t window_read_length{150};	// longest read whose compare is to be served from one window: up to 158 bases -> 128-byte windows, else 256
-	uint64_t window_reserve{UINT64_C(24) << 30};	// HBM that must stay free after the windows (batches, arenas, trace)
-	pvc3_dbatch *kept_batch{};			// pvc3_batch_project keeps its device batch for the next call (no hipMalloc / hipFree per batch)
-	bool have_windows{};				// the uploaded index has them: k_project_fast runs, otherwise k_project_fast_probes
-	bool wide_windows{};				// ... of 256 bytes
-	uint8_t *scratch{};
-	uint64_t scratch_alloc{};
-	uint32_t *trace{};					// trace words of the packed alignment kernels
-	uint64_t trace_cap{};				// in words
-	uint64_t trace_initial{};			// option: words to start with (0: sized by the batch)
-};
-
-namespace {
-struct batch_caps
-{
-	uint64_t n{}, cigar{}, seq{}, qual{};		// records, CIGAR operations, SEQ bytes, QUAL bytes uploaded with the batch
-	uint64_t qual_compact{};					// bytes of the compact QUAL buffer of a pipelined batch (0: QUAL travels with the batch)
-	bool mates{};
-};
-}
-
-struct pvc3_dbatch
-{
-	pvc3_context *ctx{};
-	uint64_t n{};
-	dev_batch_in in{};
-	dev_batch_work work{};
-	dev_batch_packed packed{};
-	uint64_t *scan_tmp{};
-	unsigned long long *d_checksum{};
-	std::vector <void *> allocs;		// everything except the growable arenas
-	uint64_t bytes{};
-	batch_caps caps{};
-	// optional inputs: device arrays exist when the capacities ask for them, `in` points to them when the batch has them
-	uint64_t *up_qual_off{};
-	uint8_t *up_qual{};
-	uint32_t *up_mate_src_entry{}, *up_mate_dst_entry{}, *up_mate_pos{};
-	uint32_t *d_invalid{};				// the first malformed record, 0xFFFFFFFF if the layout is sound (k_validate_batch)
-	bool projected{};
-	bool finished{};
-	bool timed{};						// the context's timing events bracket THIS batch's kernels (never in a pipeline: the next batch re-records them)
-	pvc3_params params{};
-	uint32_t attempts{};
-	dev_counters counters{};
-	uint64_t totals[2]{};				// packed CIGAR operations and runs of the finished batch
-};
 
 namespace {
 
@@ -456,6 +379,7 @@ int pvc3_context_set_option(pvc3_context *ctx, char const *key, int64_t value)
 	else if ("position_windows" == k) ctx->position_windows = (0 != value);	// likewise
 	else if ("window_read_length" == k) ctx->window_read_length = (uint32_t) ((value > 4096) ? 4096 : value);	// likewise
 	else if ("window_reserve" == k) ctx->window_reserve = (uint64_t) value;	// likewise
+	else if ("staging_threads" == k) ctx->stager.set_threads((uint32_t) ((value > 64) ? 64 : value));	// before the first ordinary array is copied
 	else return set_error(PVC3_E_INVALID, "pvc3_context_set_option: unknown option %s", key);
 	return PVC3_OK;
 }
@@ -777,7 +701,7 @@ int dbatch_load(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_in const *in, hipS
 
 	auto put = [&](auto const *dst, auto const *src, uint64_t count, uint64_t pad) -> int {
 		uint8_t *p = (uint8_t *) const_cast <void *>((void const *) dst);
-		if (count) HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(*src), hipMemcpyHostToDevice, s));
+		if (count) HIP_TRY(ctx->stager.h2d(p, src, count * sizeof(*src), s));		// page-locked arrays directly, ordinary ones through the staging ring
 		if (pad) HIP_TRY(hipMemsetAsync(p + count * sizeof(*src), 0, pad, s));
 		return PVC3_OK;
 	};
@@ -983,19 +907,20 @@ int pvc3_dbatch_download(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_out *out)
 	uint64_t const n = b->n;
 	if (!out->out_cigar_off || !out->run_off || (n && (!out->dst_pos || !out->mate_dst_pos || !out->status)))
 		return set_error(PVC3_E_INVALID, "pvc3_dbatch_download: a required output array is null");
-	HIP_TRY(hipMemcpy(out->out_cigar_off, b->packed.out_cigar_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
-	HIP_TRY(hipMemcpy(out->run_off, b->packed.run_off, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	hipStream_t const s = ctx->stream;
+	HIP_TRY(ctx->stager.d2h(out->out_cigar_off, b->packed.out_cigar_off, (n + 1) * sizeof(uint64_t), s));
+	HIP_TRY(ctx->stager.d2h(out->run_off, b->packed.run_off, (n + 1) * sizeof(uint64_t), s));
 	uint64_t const n_cig = out->out_cigar_off[n], n_runs = out->run_off[n];
 	if (n_cig > out->out_cigar_cap || n_runs > out->run_cap)
 		return set_error(PVC3_E_CAPACITY, "pvc3_dbatch_download: need room for %llu CIGAR operations and %llu runs", (unsigned long long) n_cig, (unsigned long long) n_runs);
 	if (n)
 	{
-		HIP_TRY(hipMemcpy(out->dst_pos, b->work.dst_pos, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(out->mate_dst_pos, b->work.mate_dst_pos, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-		HIP_TRY(hipMemcpy(out->status, b->packed.status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+		HIP_TRY(ctx->stager.d2h(out->dst_pos, b->work.dst_pos, n * sizeof(uint32_t), s));
+		HIP_TRY(ctx->stager.d2h(out->mate_dst_pos, b->work.mate_dst_pos, n * sizeof(uint32_t), s));
+		HIP_TRY(ctx->stager.d2h(out->status, b->packed.status, n * sizeof(int32_t), s));
 	}
-	if (n_cig) HIP_TRY(hipMemcpy(out->out_cigar, b->packed.out_cigar, n_cig * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	if (n_runs) HIP_TRY(hipMemcpy(out->runs, b->packed.runs, n_runs * sizeof(pvc3_run), hipMemcpyDeviceToHost));
+	if (n_cig) HIP_TRY(ctx->stager.d2h(out->out_cigar, b->packed.out_cigar, n_cig * sizeof(uint32_t), s));
+	if (n_runs) HIP_TRY(ctx->stager.d2h(out->runs, b->packed.runs, n_runs * sizeof(pvc3_run), s));
 	return PVC3_OK;
 }
 
@@ -1065,6 +990,31 @@ int pvc3_batch_project(pvc3_context *ctx, pvc3_batch_in const *in, pvc3_batch_ou
 	return rc;
 }
 
+
+}	// extern "C"
+
+namespace pvc3 {
+
+int batch_object_alloc(pvc3_context *ctx, uint64_t max_records, uint64_t max_cigar_ops, pvc3_dbatch **out)
+{
+	batch_caps caps;
+	caps.n = max_records; caps.cigar = max_cigar_ops; caps.seq = 0; caps.qual = 0; caps.mates = true;
+	return dbatch_alloc(ctx, caps, out);
+}
+
+int batch_object_project(pvc3_context *ctx, pvc3_dbatch *b, pvc3_params const *params)
+{
+	return pvc3_dbatch_project(ctx, b, params);
+}
+
+int batch_object_complete(pvc3_context *ctx, pvc3_dbatch *b, pvc3_batch_stats *stats)
+{
+	return pvc3_dbatch_finish(ctx, b, stats);
+}
+
+}
+
+extern "C" {
 
 // ---- pipelined entry point -----------------------------------------------------------------------------------------------
 // The reference's record loop reads, projects and writes one record at a time (project_alignments.cc:600-627).  Here batch
@@ -1262,6 +1212,14 @@ int pvc3_pipeline_in_flight(pvc3_pipeline const *p, uint32_t *count)
 {
 	if (!p || !count) return set_error(PVC3_E_INVALID, "pvc3_pipeline_in_flight: null argument");
 	*count = (uint32_t) (p->submitted - p->retired);
+	return PVC3_OK;
+}
+
+int pvc3_pipeline_synchronize(pvc3_pipeline *p)
+{
+	if (!p) return set_error(PVC3_E_INVALID, "pvc3_pipeline_synchronize: null argument");
+	PVC3_TRY(check_device(p->ctx));
+	for (hipStream_t s : {p->s_h2d, p->s_kernels, p->s_d2h}) HIP_TRY(hipStreamSynchronize(s));
 	return PVC3_OK;
 }
 

@@ -377,6 +377,8 @@ public:
 	~byte_reader() { close(); }
 
 	void set_threads(unsigned n) { m_threads = n ? n : 1; }
+	bool is_bgzf_file() const { return nullptr != m_raw; }
+	void set_piece_bytes(std::size_t n) { if (!m_started && n >= (1u << 16)) CHUNK = n; }		// compressed bytes read and inflated at a time (before the first read)
 
 	// From the next piece on the blocks of BGZF input are inflated by `g` (which must outlive this reader's use).  May be called
 	// from another thread than the one that reads.
@@ -773,6 +775,21 @@ public:
 
 	void write(std::string const &s) { write(s.data(), s.size()); }
 
+	// Everything written so far as BGZF blocks of its own (the last one short), on the file when this returns; and BGZF blocks made
+	// elsewhere, written as they are.  (For the record path on the GPU, which makes the blocks of the records itself.)
+	void flush_all()
+	{
+		if (!m_bgzf || m_group) throw io_error("flush_all: only for BGZF output without an attached compressor");
+		flush_blocks(true);
+		if (m_writing.valid()) m_writing.get();
+	}
+	void write_framed(void const *p, std::size_t n)
+	{
+		if (!m_bgzf || m_group || !m_pending.empty()) throw io_error("write_framed: unwritten bytes in front of the blocks");
+		if (m_writing.valid()) m_writing.get();
+		write_raw(p, n);
+	}
+
 	void close()
 	{
 		if (!m_file) return;
@@ -783,7 +800,16 @@ public:
 		struct closer
 		{
 			byte_writer &w; FILE *f; bool owns; bool done;
-			~closer() { if (!done) { w.m_pending.clear(); w.m_group = nullptr; w.m_in_flight.clear(); w.m_file = nullptr; if (owns) std::fclose(f); } }
+			~closer()
+			{
+				if (done) return;
+				// an error on the way: a write that is still running on the file finishes first, and the groups on the compressor are waited for
+				if (w.m_writing.valid()) { try { w.m_writing.get(); } catch (...) {} }
+				if (w.m_group)
+					for (auto const &g : w.m_in_flight) { try { uint8_t const *o{}; uint32_t const *l{}; w.m_group->wait(g.first, o, l); } catch (...) {} }
+				w.m_pending.clear(); w.m_group = nullptr; w.m_in_flight.clear(); w.m_file = nullptr;
+				if (owns) std::fclose(f);
+			}
 		} guard{*this, f, owns, false};
 		if (m_bgzf)
 		{

@@ -1,0 +1,396 @@
+// device_records.hpp — the record loop of panvc3_project_alignments with the records on the GPU from the file's compressed
+// blocks to the output's compressed blocks (--record-path=gpu; BGZF BAM file in, BAM out).
+//
+// What the reference's loop does record by record on one thread (project-alignments/project_alignments.cc:484-655: seqan3's
+// BAM reader, the filters, project_task::process(), seqan3's BAM writer) is here three threads that only move bytes:
+//   the reader      reads pieces of the file into page-locked memory and lists their BGZF blocks;
+//   this thread     has the blocks inflated on the GPU into a stream buffer (include/pvc3_bgzf.h, device-resident form), compares
+//                   the checksums the GPU computed with those in the file, and runs the record path on that buffer
+//                   (include/pvc3_records.h): records found, filtered, scattered into batch arrays, projected, written anew
+//                   straight into the compressor's input; then starts the compressor;
+//   the writer      takes the compressor's output — the bytes of the BGZF file, headers and checksums included — and writes it.
+// The inflater works on the next piece while the records of this one are processed and the compressor works on the previous
+// one: three independent streams on the GPU.  The host touches no record.
+#pragma once
+
+#include <zlib.h>
+
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "../../include/pvc3.h"
+#include "../../include/pvc3_bgzf.h"
+#include "../../include/pvc3_records.h"
+#include "bgzf.hpp"
+
+namespace pvc3host {
+
+struct device_records_result
+{
+	uint64_t matched{}, flags_not_matched{}, ref_id_missing{}, seq_missing{}, records{}, batches{}, n_runs{};
+	uint64_t blocks_in{}, blocks_refused{}, bytes_in{}, bytes_out{};
+	double inflate_kernel_s{}, deflate_kernel_s{};
+	double t_wait_read{}, t_inflate_wait{}, t_frame{}, t_project{}, t_rewrite{}, t_wait_writer{}, t_reader{}, t_writer{};
+	std::vector <std::pair <uint32_t, uint32_t>> ranges;
+	std::vector <uint64_t> removed_tags;		// [65536]
+};
+
+struct device_records_options
+{
+	char const *path{};
+	int device{};
+	pvc3_context *ctx{};
+	pvc3_records_config config{};			// tables filled by the caller
+	pvc3_params params{};
+	uint64_t header_bytes{};				// uncompressed bytes in front of the first record
+	bool want_ranges{};
+	bool host_inflate{};					// --bgzf-inflate=host: the blocks are inflated by the host's threads and uploaded
+	unsigned threads{1};
+	std::size_t piece_compressed{std::size_t(32) << 20};		// compressed bytes read at a time
+	std::size_t piece_stream{std::size_t(160) << 20};		// uncompressed bytes of a piece at most
+	std::function <void(void const *, std::size_t)> write_blocks;		// BGZF blocks to the output file, in order
+	std::function <void(uint64_t)> progress;					// records so far (status lines)
+};
+
+namespace detail {
+
+inline void zlib_inflate_block(uint8_t const *src, std::size_t in_len, uint8_t *dst, std::size_t out_len)
+{
+	z_stream zs{};
+	if (Z_OK != inflateInit2(&zs, -15)) throw io_error("inflateInit2 failed");
+	zs.next_in = const_cast <uint8_t *>(src); zs.avail_in = (uInt) in_len;
+	zs.next_out = dst; zs.avail_out = (uInt) out_len;
+	int const rc = inflate(&zs, Z_FINISH);
+	inflateEnd(&zs);
+	if (Z_STREAM_END != rc || zs.total_out != out_len) throw io_error("corrupt BGZF block");
+}
+
+}
+
+inline device_records_result run_device_records(device_records_options const &opt)
+{
+	device_records_result res;
+	res.removed_tags.assign(65536, 0);
+	auto now = []() { return std::chrono::steady_clock::now(); };
+	auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration <double>(std::chrono::steady_clock::now() - t0).count(); };
+	auto bgzf_check = [](int rc, char const *what) { if (rc) throw io_error(std::string(what) + ": " + pvc3_bgzf_last_error()); };
+	auto rec_check = [](int rc, char const *what) { if (rc) throw io_error(std::string(what) + ": " + pvc3_last_error()); };
+
+	constexpr unsigned IN_SLOTS = PVC3_RECORDS_SLOTS, OUT_SLOTS = 2;
+	std::size_t const max_in = opt.piece_compressed + (std::size_t(1) << 17);		// what a piece left over of its last block + the next read
+	uint32_t const max_blocks_in = (uint32_t) (max_in / 28 / 8 + 4096);
+	uint32_t const max_blocks_out = (uint32_t) ((opt.piece_stream + opt.piece_stream / 2) / PVC3_BGZF_BLOCK + 64);
+
+	// ---- the three objects on the GPU ---------------------------------------------------------------------------------------------
+	pvc3_bgzf_inflater *inflater{};
+	pvc3_bgzf_dev *deflater{};
+	pvc3_records *records{};
+	struct cleanup
+	{
+		pvc3_bgzf_inflater *&i; pvc3_bgzf_dev *&d; pvc3_records *&r;
+		~cleanup() { if (r) pvc3_records_destroy(r); if (d) pvc3_bgzf_dev_destroy(d); if (i) pvc3_bgzf_inflater_destroy(i); }
+	} cleanup_guard{inflater, deflater, records};
+	bgzf_check(pvc3_bgzf_inflater_create(opt.device, max_in, opt.host_inflate ? opt.piece_stream : 1, max_blocks_in, IN_SLOTS, &inflater), "pvc3_bgzf_inflater_create");
+	bgzf_check(pvc3_bgzf_dev_create(opt.device, max_blocks_out, OUT_SLOTS, &deflater), "pvc3_bgzf_dev_create");
+	pvc3_records_config cfg = opt.config;
+	cfg.max_stream_bytes = opt.piece_stream;
+	rec_check(pvc3_records_create(opt.ctx, &cfg, &records), "pvc3_records_create");
+	uint64_t const out_capacity = pvc3_bgzf_dev_capacity(deflater);
+
+	// ---- the reader ------------------------------------------------------------------------------------------------------------------
+	struct piece
+	{
+		unsigned slot{};
+		uint32_t n_blocks{};
+		std::size_t in_bytes{}, out_bytes{};
+		std::vector <uint64_t> block_off;		// [n_blocks + 1] where the blocks' bytes begin in the stream buffer, from its front
+		std::vector <uint32_t> crc;
+		bool last{};
+	};
+	std::mutex m;
+	std::condition_variable cv;
+	std::deque <piece> ready;
+	bool slot_free[IN_SLOTS];
+	for (auto &f : slot_free) f = true;
+	bool reader_done = false, stop = false;
+	std::exception_ptr reader_error;
+	FILE *raw = std::fopen(opt.path, "rb");
+	if (!raw) throw io_error(std::string("unable to open ") + opt.path);
+	struct close_file { FILE *f; ~close_file() { if (f) std::fclose(f); } } raw_guard{raw};
+
+	std::thread reader([&]() {
+		try
+		{
+			std::vector <uint8_t> left;		// what the last piece did not use of its input (a partial block, or blocks beyond the piece's room)
+			bool eof = false;
+			for (unsigned k = 0; ; ++k)
+			{
+				unsigned const slot = k % IN_SLOTS;
+				{
+					std::unique_lock <std::mutex> lock(m);
+					cv.wait(lock, [&]() { return stop || slot_free[slot]; });
+					if (stop) return;
+					slot_free[slot] = false;
+				}
+				auto const t0 = now();
+				uint8_t *in = pvc3_bgzf_inflater_input(inflater, slot);
+				pvc3_bgzf_block *blocks = pvc3_bgzf_inflater_blocks(inflater, slot);
+				piece p;
+				p.slot = slot;
+				std::size_t have = left.size();
+				if (have) std::memcpy(in, left.data(), have);
+				left.clear();
+				for (bool read_more = have < opt.piece_compressed; ; read_more = true)
+				{
+					if (read_more && !eof && have < max_in)
+					{
+						std::size_t const want = std::min(max_in - have, opt.piece_compressed);
+						std::size_t const got = std::fread(in + have, 1, want, raw);
+						if (got < want) { if (std::ferror(raw)) throw io_error("read error"); eof = true; }
+						have += got;
+					}
+					// the whole blocks at hand, as many as the stream buffer has room for
+					std::size_t off = 0, out = 0;
+					p.n_blocks = 0; p.block_off.clear(); p.crc.clear();
+					while (p.n_blocks < max_blocks_in)
+					{
+						std::size_t data_off = 0;
+						std::size_t const bs = byte_reader::bgzf_block_size(in + off, have - off, data_off);
+						if (0 == bs || off + bs > have) break;
+						if (bs < data_off + 8) throw io_error("corrupt BGZF stream (short block)");
+						uint32_t crc, isize;
+						std::memcpy(&crc, in + off + bs - 8, 4);
+						std::memcpy(&isize, in + off + bs - 4, 4);
+						if (isize > 65536) throw io_error("corrupt BGZF stream (ISIZE beyond 64 KiB)");
+						if (out + isize > opt.piece_stream) break;
+						if (isize)
+						{
+							blocks[p.n_blocks] = pvc3_bgzf_block{off + data_off, (uint32_t) (bs - data_off - 8), isize, out};
+							p.block_off.push_back(out); p.crc.push_back(crc);
+							++p.n_blocks;
+						}
+						out += isize; off += bs;
+					}
+					if (0 == off && have)
+					{
+						// not one whole block: more of the file, or the file is damaged
+						if (eof) throw io_error("truncated BGZF stream");
+						if (have >= max_in) throw io_error("a BGZF block larger than the reader's buffer");
+						continue;
+					}
+					p.block_off.push_back(out);
+					p.in_bytes = off; p.out_bytes = out;
+					left.assign(in + off, in + have);
+					p.last = eof && left.empty();
+					break;
+				}
+				res.t_reader += since(t0);
+				bool const last = p.last;
+				{
+					std::lock_guard <std::mutex> lock(m);
+					ready.push_back(std::move(p));
+					if (last) reader_done = true;
+				}
+				cv.notify_all();
+				if (last) return;
+			}
+		}
+		catch (...) { std::lock_guard <std::mutex> lock(m); reader_error = std::current_exception(); reader_done = true; cv.notify_all(); }
+	});
+
+	// ---- the writer ------------------------------------------------------------------------------------------------------------------
+	std::deque <unsigned> to_write;
+	bool out_free[OUT_SLOTS];
+	for (auto &f : out_free) f = true;
+	bool writer_done = false;
+	std::exception_ptr writer_error;
+	std::thread writer([&]() {
+		try
+		{
+			for (;;)
+			{
+				unsigned slot;
+				{
+					std::unique_lock <std::mutex> lock(m);
+					cv.wait(lock, [&]() { return writer_done || !to_write.empty(); });
+					if (to_write.empty()) return;
+					slot = to_write.front(); to_write.pop_front();
+				}
+				auto const t0 = now();
+				uint8_t const *bytes{}; uint64_t n = 0; float ms = 0;
+				bgzf_check(pvc3_bgzf_dev_wait(deflater, slot, &bytes, &n, &ms), "pvc3_bgzf_dev_wait");
+				opt.write_blocks(bytes, n);
+				res.deflate_kernel_s += 1e-3 * ms; res.bytes_out += n;
+				res.t_writer += since(t0);
+				{
+					std::lock_guard <std::mutex> lock(m);
+					out_free[slot] = true;
+				}
+				cv.notify_all();
+			}
+		}
+		catch (...) { std::lock_guard <std::mutex> lock(m); writer_error = std::current_exception(); writer_done = true; cv.notify_all(); }
+	});
+	struct join_threads
+	{
+		std::thread &a, &b; std::mutex &m; std::condition_variable &cv; bool &stop, &writer_done;
+		~join_threads() { { std::lock_guard <std::mutex> l(m); stop = true; writer_done = true; } cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); }
+	} joiner{reader, writer, m, cv, stop, writer_done};
+
+	// ---- this thread: pieces through the GPU ------------------------------------------------------------------------------------------
+	void *base[IN_SLOTS]; uint64_t front = 0;
+	for (unsigned s = 0; s < IN_SLOTS; ++s) rec_check(pvc3_records_buffer(records, s, &base[s], &front), "pvc3_records_buffer");
+	std::deque <piece> inflating;		// submitted to the inflater, oldest first
+	bool first = true, seen_last = false;
+	unsigned out_slot = 0;
+	std::vector <uint8_t> scratch;
+	std::vector <pvc3_run> runs;
+
+	auto start_inflate = [&](piece &p) {
+		if (0 == p.n_blocks) return;
+		if (opt.host_inflate)
+		{
+			// the host's threads inflate into the inflater's page-locked output, which is uploaded as a whole
+			uint8_t const *in = pvc3_bgzf_inflater_input(inflater, p.slot);
+			uint8_t *out = pvc3_bgzf_inflater_output(inflater, p.slot);
+			pvc3_bgzf_block const *blocks = pvc3_bgzf_inflater_blocks(inflater, p.slot);
+			parallel_for(p.n_blocks, opt.threads, [&](std::size_t i) {
+				static thread_local fast_inflater quick;
+				pvc3_bgzf_block const &b = blocks[i];
+				if (!(quick.inflate(in + b.in_off, b.in_len, out + b.out_off, b.out_len) && fast_crc32(0, out + b.out_off, b.out_len) == p.crc[i]))
+				{
+					detail::zlib_inflate_block(in + b.in_off, b.in_len, out + b.out_off, b.out_len);
+					if (fast_crc32(0, out + b.out_off, b.out_len) != p.crc[i]) throw io_error("BGZF block checksum mismatch");
+				}
+			});
+			rec_check(pvc3_records_upload(records, p.slot, 0, out, p.out_bytes), "pvc3_records_upload");
+			return;
+		}
+		bgzf_check(pvc3_bgzf_inflater_submit_device(inflater, p.slot, p.n_blocks, p.in_bytes, (uint8_t *) base[p.slot] + front, opt.piece_stream), "pvc3_bgzf_inflater_submit_device");
+	};
+	auto finish_inflate = [&](piece &p) {
+		if (0 == p.n_blocks || opt.host_inflate) return;
+		uint32_t const *status{}, *crc{};
+		float ms = 0;
+		bgzf_check(pvc3_bgzf_inflater_wait_device(inflater, p.slot, &status, &crc, &ms), "pvc3_bgzf_inflater_wait_device");
+		res.inflate_kernel_s += 1e-3 * ms;
+		// whatever the GPU refused, or whose checksum is not the file's: inflated here (zlib decides what is corrupt) and put in its place
+		uint8_t const *in = pvc3_bgzf_inflater_input(inflater, p.slot);
+		pvc3_bgzf_block const *blocks = pvc3_bgzf_inflater_blocks(inflater, p.slot);
+		for (uint32_t i = 0; i < p.n_blocks; ++i)
+		{
+			if (0 == status[i] && crc[i] == p.crc[i]) continue;
+			++res.blocks_refused;
+			pvc3_bgzf_block const &b = blocks[i];
+			scratch.resize(b.out_len);
+			detail::zlib_inflate_block(in + b.in_off, b.in_len, scratch.data(), b.out_len);
+			if (fast_crc32(0, scratch.data(), b.out_len) != p.crc[i]) throw io_error("BGZF block checksum mismatch");
+			rec_check(pvc3_records_upload(records, p.slot, b.out_off, scratch.data(), b.out_len), "pvc3_records_upload");
+		}
+	};
+
+	for (;;)
+	{
+		// up to two pieces with the inflater
+		auto t0 = now();
+		for (;;)
+		{
+			std::unique_lock <std::mutex> lock(m);
+			if (inflating.size() >= 2 || seen_last) break;
+			if (ready.empty())
+			{
+				if (!inflating.empty() && !reader_done) break;		// nothing more at hand: work on what is there
+				cv.wait(lock, [&]() { return reader_done || !ready.empty(); });
+				if (reader_error) std::rethrow_exception(reader_error);
+				if (ready.empty()) break;
+			}
+			piece p = std::move(ready.front()); ready.pop_front();
+			lock.unlock();
+			seen_last = p.last;
+			start_inflate(p);
+			inflating.push_back(std::move(p));
+		}
+		res.t_wait_read += since(t0);
+		if (reader_error) std::rethrow_exception(reader_error);
+		if (writer_error) std::rethrow_exception(writer_error);
+		if (inflating.empty()) break;
+		piece p = std::move(inflating.front()); inflating.pop_front();
+		t0 = now();
+		finish_inflate(p);
+		res.t_inflate_wait += since(t0); t0 = now();
+		res.blocks_in += p.n_blocks; res.bytes_in += p.out_bytes;
+		// the compressed bytes are no longer needed: the reader may fill the slot again (the stream buffer of the same number
+		// stays this thread's until the piece's records are written)
+		uint64_t skip = 0;
+		if (first)
+		{
+			if (opt.header_bytes > p.out_bytes) throw io_error("the BAM header is longer than the first piece of the file");
+			skip = opt.header_bytes; first = false;
+		}
+		pvc3_records_frame_result fr{};
+		int code = 0; uint64_t bad_record = 0;
+		int rc = pvc3_records_frame(records, p.slot, p.out_bytes, p.block_off.data(), p.n_blocks, skip, p.last ? 1 : 0, &fr, &code, &bad_record);
+		if (rc && code) throw io_error(std::string("input record ") + std::to_string(bad_record) + ": " + pvc3_last_error());
+		rec_check(rc, "pvc3_records_frame");
+		res.matched += fr.matched; res.flags_not_matched += fr.flags_not_matched; res.ref_id_missing += fr.ref_id_missing; res.seq_missing += fr.seq_missing;
+		res.t_frame += since(t0); t0 = now();
+		{
+			std::lock_guard <std::mutex> lock(m);
+			slot_free[p.slot] = true;		// (its input; see above)
+		}
+		cv.notify_all();
+		if (fr.n_batch)
+		{
+			pvc3_batch_stats stats{};
+			rec_check(pvc3_records_project(records, &opt.params, &stats), "pvc3_records_project");
+			res.t_project += since(t0); t0 = now();
+			{
+				std::unique_lock <std::mutex> lock(m);
+				cv.wait(lock, [&]() { return writer_done || out_free[out_slot]; });
+				if (writer_error) std::rethrow_exception(writer_error);
+				out_free[out_slot] = false;
+			}
+			res.t_wait_writer += since(t0); t0 = now();
+			uint64_t n_bytes = 0, n_runs = 0;
+			rc = pvc3_records_rewrite(records, pvc3_bgzf_dev_input(deflater, out_slot), out_capacity, PVC3_BGZF_BLOCK, PVC3_BGZF_IN_STRIDE, PVC3_BGZF_IN_PAD, &n_bytes, &n_runs, &code, &bad_record);
+			if (rc && code)
+				throw io_error(std::string("input record ") + std::to_string(bad_record) + " cannot be projected or written (" + pvc3_last_error()
+					+ "; the reference asserts here: position or CIGAR inconsistent with the index)");
+			rec_check(rc, "pvc3_records_rewrite");
+			res.n_runs += n_runs;
+			if (opt.want_ranges && n_runs)
+			{
+				runs.resize(n_runs);
+				rec_check(pvc3_records_runs(records, runs.data(), n_runs), "pvc3_records_runs");
+				for (auto const &r : runs) res.ranges.emplace_back(r.ref_position, r.ref_length);
+			}
+			bgzf_check(pvc3_bgzf_dev_submit(deflater, out_slot, n_bytes), "pvc3_bgzf_dev_submit");
+			{
+				std::lock_guard <std::mutex> lock(m);
+				to_write.push_back(out_slot);
+			}
+			cv.notify_all();
+			out_slot = (out_slot + 1) % OUT_SLOTS;
+			res.t_rewrite += since(t0);
+			res.records += fr.n_batch; ++res.batches;
+			if (opt.progress) opt.progress(res.records);
+		}
+		if (p.last) break;
+	}
+	{
+		std::lock_guard <std::mutex> lock(m);
+		writer_done = true;
+	}
+	cv.notify_all();
+	writer.join();
+	if (writer_error) std::rethrow_exception(writer_error);
+	reader.join();
+	if (reader_error) std::rethrow_exception(reader_error);
+	rec_check(pvc3_records_removed_tags(records, res.removed_tags.data()), "pvc3_records_removed_tags");
+	return res;
+}
+
+}

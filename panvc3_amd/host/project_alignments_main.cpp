@@ -34,6 +34,7 @@
 #include "msa_index_file.hpp"
 #include "sam_bam.hpp"
 #include "gpu_deflate.hpp"
+#include "device_records.hpp"
 
 using namespace pvc3host;
 
@@ -105,6 +106,8 @@ struct options
 	std::string separator{"_"};
 	bool bam_input{}, output_bam{}, keep_duplicate_ranges{}, print_invocation{}, print_pid{}, io_only{}, debugging_output{};
 	bool gpu_deflate{true};				// --bgzf-deflate=gpu|host: BAM output with the built-in encoder is compressed on the first GPU
+	int record_path{-1};				// --record-path=gpu|host: -1 = gpu where it applies (BGZF BAM file in, BAM out with the built-in encoder on the GPU, one GPU)
+	bool inflate_given{};				// --bgzf-inflate was given
 	bool gpu_inflate{false};			// --bgzf-inflate=gpu|host: the blocks of BGZF input are inflated on the first GPU (7 GB/s: sixteen host threads are faster)
 	std::vector <std::string> preserve_tags;
 	std::string rname_tag{"XR"}, pos_tag{"XP"}, rnext_tag{"YR"}, pnext_tag{"YP"}, query_ranges_tag{"XB"}, ref_ranges_tag{"YB"}, rec_idx_tag;
@@ -167,7 +170,11 @@ void usage()
 		"      --compression-level=-1..9        BAM output: -1 (default) the built-in deflate encoders, 0..9 zlib at that level\n"
 		"      --bgzf-deflate=gpu|host          where the built-in encoder runs: on the first GPU (default) or on the host threads\n"
 		"      --bgzf-inflate=gpu|host          where the blocks of BGZF input (BAM, bgzip'ed SAM) are inflated: on the host threads (default)\n"
-		"                                       or on the first GPU once it is up (for hosts with few cores: 7 GB/s)\n";
+		"                                       or on the first GPU once it is up (for hosts with few cores: 7 GB/s)\n"
+		"      --record-path=gpu|host           where the records are cut out of the input and written anew: on the GPU (default for a BAM file\n"
+		"                                       in and BAM out on one GPU: the blocks are inflated, the records found, projected, rewritten\n"
+		"                                       and compressed without leaving it; --bgzf-inflate=host then only moves the inflating) or by\n"
+		"                                       the host's threads (every other input and output)\n";
 }
 
 // process_headers (project_alignments.cc:1092-1253)
@@ -310,7 +317,7 @@ int main(int argc, char **argv)
 		{"gap-opening-cost", required_argument, nullptr, 'g'}, {"gap-extension-cost", required_argument, nullptr, 'e'},
 		{"print-invocation", no_argument, nullptr, 1009}, {"print-pid", no_argument, nullptr, 1010}, {"debugging-output", no_argument, nullptr, 1011},
 		{"device", required_argument, nullptr, 1012}, {"batch-size", required_argument, nullptr, 1013}, {"io-only", no_argument, nullptr, 1014}, {"threads", required_argument, nullptr, 1015},
-		{"devices", required_argument, nullptr, 1016}, {"compression-level", required_argument, nullptr, 1017}, {"bgzf-deflate", required_argument, nullptr, 1018}, {"bgzf-inflate", required_argument, nullptr, 1019},
+		{"devices", required_argument, nullptr, 1016}, {"compression-level", required_argument, nullptr, 1017}, {"bgzf-deflate", required_argument, nullptr, 1018}, {"bgzf-inflate", required_argument, nullptr, 1019}, {"record-path", required_argument, nullptr, 1020},
 		{"help", no_argument, nullptr, 'h'}, {"version", no_argument, nullptr, 'V'}, {nullptr, 0, nullptr, 0}};
 	int c;
 	while (-1 != (c = getopt_long(argc, argv, "a:Bm:r:d:s:u:o:bl:t:qg:e:hV", long_opts, nullptr)))
@@ -361,6 +368,12 @@ int main(int argc, char **argv)
 				if (0 == std::strcmp(optarg, "gpu")) opt.gpu_inflate = true;
 				else if (0 == std::strcmp(optarg, "host")) opt.gpu_inflate = false;
 				else die("--bgzf-inflate expects gpu or host");
+				opt.inflate_given = true;
+				break;
+			case 1020:
+				if (0 == std::strcmp(optarg, "gpu")) opt.record_path = 1;
+				else if (0 == std::strcmp(optarg, "host")) opt.record_path = 0;
+				else die("--record-path expects gpu or host");
 				break;
 			case 1013: opt.batch_size = std::strtoull(optarg, nullptr, 10); break;
 			case 1014: opt.io_only = true; break;
@@ -437,6 +450,7 @@ int main(int argc, char **argv)
 		bool const want_gpu_deflate = opt.gpu_deflate && opt.output_bam && opt.compression_level < 0;
 		double t_startup = 0.0, t_contexts_up = 0.0, t_deflater_up = 0.0, t_inflater_up = 0.0, t_files_read = 0.0, inflater_kernel_s = 0.0;
 		uint64_t inflater_groups = 0;
+		bool aux_codecs = true;		// the reader's GPU inflater and the writer's GPU compressor (not for the record path on the GPU, which has its own)
 		auto prepare_devices = [&]() {
 			// The GPU contexts come up on a thread of their own (the HIP runtime takes a few tenths of a second to start) while the
 			// index file and the reference are read.
@@ -453,13 +467,13 @@ int main(int argc, char **argv)
 				// rewritten: it comes up on a thread of its own, behind the contexts (the HIP runtime is up by now).
 				// The inflater of the input's blocks likewise; the reader, which has been inflating on the host threads since the process
 				// began, shares its pieces with it from the next one on: pieces of 32 MB of the file, 160 MB of page-locked output each.
-				if (opt.gpu_inflate)
+				if (aux_codecs && opt.gpu_inflate)
 					inflater_coming = std::async(std::launch::async, [&]() {
 						block_inflater = std::make_unique <gpu_group_inflater>(opt.devices.front(), (std::size_t) 65 << 20, (std::size_t) 160 << 20, 4096, 2);
 						reader.attach(block_inflater.get());
 						t_inflater_up = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
 					});
-				if (want_gpu_deflate)
+				if (aux_codecs && want_gpu_deflate)
 					deflater_coming = std::async(std::launch::async, [&]() {
 						char const *group = std::getenv("PVC3_BGZF_GROUP_BLOCKS");		// tests: small groups, many of them
 						std::size_t const blocks = group ? (std::size_t) std::max(1, std::atoi(group)) : 512;
@@ -522,6 +536,114 @@ int main(int argc, char **argv)
 		alignment_writer writer;
 		writer.set_threads(opt.threads);
 		writer.open(opt.output_path, opt.output_bam, out_header, opt.compression_level);
+
+		// ---- the record path on the GPU (device_records.hpp): BGZF BAM file in, BAM out, one GPU --------------------------------------------
+		bool const device_records_apply = reader.is_bgzf_file() && opt.alignments && opt.output_bam && opt.compression_level < 0 && opt.gpu_deflate && 1 == opt.devices.size();
+		if (1 == opt.record_path && !device_records_apply)
+			die("--record-path=gpu needs a BAM file as input (--alignments=x.bam), BAM output (--output-bam) with the built-in encoder on the GPU, and one GPU");
+		if (0 != opt.record_path && device_records_apply)
+		{
+			uint64_t const header_bytes = reader.bam_header_bytes();
+			reader.release();		// the header has been read: the file is read anew, raw, by the record path's own reader
+			bool const want_host_inflate = opt.inflate_given && !opt.gpu_inflate;
+			aux_codecs = false;
+			prepare_devices();
+			check(pvc3_context_set_option(device_contexts[0], "window_read_length", 150), "pvc3_context_set_option");
+			double const t_prepared = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+			{
+				// the longest read decides between 128- and 256-byte position windows: the first records of the file are looked at on the host
+				uint32_t longest = 0;
+				alignment_reader peek;
+				peek.set_threads(1);
+				peek.set_piece_bytes(std::size_t(1) << 20);
+				peek.open(opt.alignments, true);
+				bam_record rec;
+				for (unsigned k = 0; k < 2000 && peek.next(rec); ++k) longest = std::max(longest, rec.l_seq());
+				if (longest) check(pvc3_context_set_option(device_contexts[0], "window_read_length", longest), "pvc3_context_set_option");
+			}
+			if (pvc3_context_upload_index(device_contexts[0], index)) die(std::string("pvc3_context_upload_index: ") + pvc3_last_error());
+			t_startup = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+
+			device_records_options dro;
+			dro.path = opt.alignments; dro.device = opt.devices.front(); dro.ctx = device_contexts[0];
+			dro.params = pvc3_params{opt.gap_open, opt.gap_ext, PVC3_SCORE_FP64, 0};
+			dro.header_bytes = header_bytes; dro.want_ranges = nullptr != opt.realigned_ranges; dro.host_inflate = want_host_inflate; dro.threads = opt.threads;
+			if (char const *e = std::getenv("PVC3_BGZF_CHUNK")) { std::size_t const v = (std::size_t) std::strtoull(e, nullptr, 10); if (v >= 1024) dro.piece_compressed = v; }
+			if (char const *e = std::getenv("PVC3_RECORDS_STREAM")) { std::size_t const v = (std::size_t) std::strtoull(e, nullptr, 10); if (v >= 65536) dro.piece_stream = v; }
+			std::vector <uint32_t> r_dst(in_header.refs.size()), name_off(in_header.refs.size() + 1, 0);
+			std::vector <int32_t> r_out(in_header.refs.size());
+			std::string names;
+			for (std::size_t i = 0; i < in_header.refs.size(); ++i)
+			{
+				r_dst[i] = dst_entries[ref_id_mapping[i]]; r_out[i] = (int32_t) ref_id_mapping[i];
+				names += in_header.refs[i].name; name_off[i + 1] = (uint32_t) names.size();
+			}
+			std::vector <uint16_t> kept_tags(preserved.begin(), preserved.end());
+			pvc3_records_config &cfg = dro.config;
+			cfg.n_refs = (uint32_t) in_header.refs.size(); cfg.src_entry = src_entries.data(); cfg.dst_entry = r_dst.data(); cfg.out_ref_id = r_out.data();
+			cfg.ref_names = names.data(); cfg.ref_name_off = name_off.data(); cfg.preserved_tags = kept_tags.data(); cfg.n_preserved_tags = (uint32_t) kept_tags.size();
+			auto set_tag = [](char (&dst)[2], std::string const &name) { dst[0] = name.empty() ? 0 : name[0]; dst[1] = name.empty() ? 0 : name[1]; };
+			set_tag(cfg.rname_tag, opt.rname_tag); set_tag(cfg.pos_tag, opt.pos_tag); set_tag(cfg.rnext_tag, opt.rnext_tag); set_tag(cfg.pnext_tag, opt.pnext_tag);
+			set_tag(cfg.query_ranges_tag, opt.query_ranges_tag); set_tag(cfg.ref_ranges_tag, opt.ref_ranges_tag); set_tag(cfg.rec_idx_tag, opt.rec_idx_tag);
+			writer.flush_blocks();		// the header: blocks of its own
+			dro.write_blocks = [&](void const *p, std::size_t n) { writer.write_blocks(p, n); };
+			double next_status = 60.0 * (double) opt.status_interval;
+			dro.progress = [&](uint64_t records_done) {
+				if (opt.status_interval <= 0) return;
+				double const running = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+				if (running < next_status) return;
+				std::cerr << "Time spent processing: " << (uint64_t) running << " s; processed " << records_done << " records";
+				if (records_done) std::cerr << " (in " << (running * 1e6 / (double) records_done) << " µs / record)";
+				std::cerr << ".\n";
+				next_status = running + 60.0 * (double) opt.status_interval;
+			};
+			device_records_result const dr = run_device_records(dro);
+			double const t_batches_done = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+			writer.close();
+			double const t_closed = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+			if (opt.realigned_ranges)
+			{
+				auto ranges = dr.ranges;
+				if (!opt.keep_duplicate_ranges)
+				{
+					std::sort(ranges.begin(), ranges.end());
+					ranges.erase(std::unique(ranges.begin(), ranges.end()), ranges.end());
+				}
+				FILE *f = std::fopen(opt.realigned_ranges, "w");
+				if (!f) die(std::string("unable to open ") + opt.realigned_ranges);
+				std::fputs("Location\tLength\n", f);
+				for (auto const &rr : ranges) std::fprintf(f, "%u\t%u\n", rr.first, rr.second);
+				std::fclose(f);
+			}
+			double const secs = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+			std::cerr << "Done. Time spent: " << secs << " s.\n";
+			std::cerr << "\tMatched reads:         " << dr.matched << '\n';
+			std::cerr << "\tReference ID missing:  " << dr.ref_id_missing << '\n';
+			std::cerr << "\tFlags not matched:     " << dr.flags_not_matched << '\n';
+			std::cerr << "\tSequence missing:      " << dr.seq_missing << '\n';
+			std::cerr << "\tRe-aligned ranges:     " << dr.n_runs << '\n';
+			if (opt.debugging_output)
+			{
+				std::cerr << "\tRecord path on the GPU: " << dr.records << " records in " << dr.batches << " pieces; " << dr.blocks_in << " blocks in (" << dr.blocks_refused << " inflated on the host instead), "
+						  << dr.bytes_in << " bytes of records in, " << dr.bytes_out << " bytes of file out; kernels: inflate " << dr.inflate_kernel_s << " s, deflate " << dr.deflate_kernel_s << " s\n";
+				std::cerr << "\tStages (s): start-up " << t_startup << ", reader thread " << dr.t_reader << ", main: waiting for it " << dr.t_wait_read << ", waiting for the inflater " << dr.t_inflate_wait
+						  << ", records found and scattered " << dr.t_frame << ", projected " << dr.t_project << ", rewritten " << dr.t_rewrite << ", waiting for the writer " << dr.t_wait_writer << ", writer thread " << dr.t_writer << '\n';
+				std::cerr << "\tTimeline (s): GPU contexts " << t_contexts_up << ", index file and FASTA " << t_files_read << ", both " << t_prepared << ", index on the GPUs (start-up done) " << t_startup
+						  << ", last batch rewritten " << t_batches_done << ", output closed " << t_closed << "; wall clock at the start " << std::fixed << epoch_start << ", now "
+						  << std::chrono::duration <double>(std::chrono::system_clock::now().time_since_epoch()).count() << std::defaultfloat
+						  << "; resident set (MB): peak " << peak_rss_mb() << "; CPU time (s): " << cpu_seconds() << '\n';
+			}
+			bool any_removed = false;
+			for (auto const c : dr.removed_tags) any_removed = any_removed || c;
+			if (any_removed)
+			{
+				std::cerr << "\tRemoved tags:\n";
+				for (std::size_t key = 0; key < dr.removed_tags.size(); ++key)
+					if (dr.removed_tags[key]) std::cerr << "\t\t" << (char) (key >> 8) << (char) (key & 0xff) << ": " << dr.removed_tags[key] << '\n';
+			}
+			std::cout.flush(); std::cerr.flush(); std::fflush(nullptr);
+			std::_Exit(0);
+		}
 
 		// The output file is written by a thread of its own (BGZF deflate is most of the CPU time of a BAM-to-BAM run): batch k
 		// is compressed and written while batch k + 1 is rewritten and batch k + 2 is read.
@@ -816,6 +938,9 @@ int main(int argc, char **argv)
 		// capacities or whose results do not fit the arrays they were to land in.
 		auto project_alone = [&](slot_state &sl) {
 			pvc3_context *ctx = contexts[sl.device];
+			// The same GPU's next batch is already queued on its pipeline, and all batches of a context share its alignment scratch
+			// and trace buffers: that batch's kernels run first.
+			if (pipelines[sl.device]) check(pvc3_pipeline_synchronize(pipelines[sl.device]), "pvc3_pipeline_synchronize");
 			pvc3_batch_in const in = batch_in_of(sl);
 			pvc3_dbatch *db{};
 			pvc3_batch_stats stats{};
@@ -843,10 +968,12 @@ int main(int argc, char **argv)
 			}
 			sl.o_dst_pos.reserve(n); sl.o_mate.reserve(n); sl.o_status.reserve(n); sl.o_cigar_off.reserve(n + 1); sl.o_run_off.reserve(n + 1);
 			sl.o_cigar.reserve(std::max <uint64_t>(4 * in.cigar_off[n], 16 * n)); sl.o_runs.reserve(n + 1024);
+			static bool const tiny_results = nullptr != std::getenv("PVC3_CLI_TINY_RESULTS");		// tests: every batch's results outgrow their arrays
 			sl.pipelined = n <= pipe_caps.max_records && in.cigar_off[n] <= pipe_caps.max_cigar_ops && in.seq_off[n] <= pipe_caps.max_seq_bytes;
 			if (sl.pipelined)
 			{
-				pvc3_batch_out const out = batch_out_of(sl);
+				pvc3_batch_out out = batch_out_of(sl);
+				if (tiny_results) { out.out_cigar_cap = std::min <uint64_t>(out.out_cigar_cap, n); out.run_cap = 0; }
 				check(pvc3_pipeline_submit(pipelines[sl.device], &in, &out, &params), "pvc3_pipeline_submit");
 			}
 			sl.in_flight = true;

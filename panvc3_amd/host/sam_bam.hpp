@@ -535,9 +535,15 @@ class alignment_reader
 	bool m_is_bam{};
 	std::string m_line, m_pending;
 	bool m_has_pending{};
+	uint64_t m_bam_header_bytes{};
 
 public:
 	sam_header header;
+
+	// BAM input: the uncompressed bytes in front of the first record (magic, header text, reference list).
+	uint64_t bam_header_bytes() const { return m_bam_header_bytes; }
+	bool is_bgzf_file() const { return m_in.is_bgzf_file(); }
+	void set_piece_bytes(std::size_t n) { m_in.set_piece_bytes(n); }
 
 	void set_threads(unsigned n) { m_in.set_threads(n); }
 	void attach(group_inflater *g) { m_in.attach(g); }		// BGZF input inflated elsewhere from the next piece on (byte_reader::attach)
@@ -576,6 +582,8 @@ public:
 			for (auto &sq : refs)
 				for (auto const &t : header.refs)
 					if (t.name == sq.name) { sq.extra = t.extra; break; }
+			m_bam_header_bytes = 12 + (uint64_t) l_text;
+			for (auto const &sq : refs) m_bam_header_bytes += 8 + sq.name.size() + 1;
 			header.refs = std::move(refs);
 			header.index_refs();
 		}
@@ -703,6 +711,11 @@ public:
 	}
 
 	void write_formatted(char const *p, std::size_t n) { m_out.write(p, n); }
+
+	// For a caller that makes the BGZF blocks of the records itself (the record path on the GPU): what has been written so far (the
+	// header) goes out as blocks of its own, then the caller's blocks as they are; close() ends the file as usual.
+	void flush_blocks() { m_out.flush_all(); }
+	void write_blocks(void const *p, std::size_t n) { m_out.write_framed(p, n); }
 
 	void close() { m_out.close(); }
 };

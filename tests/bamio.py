@@ -93,17 +93,30 @@ def _bgzf_block(data):
 	return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize - 1) + comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
 
 
-def write_bam(path, header_text, refs, records):
-	"""refs: [(name, length)]; records: Record objects."""
+def write_bam(path, header_text, refs, records, aligned=False, block=0xff00):
+	"""refs: [(name, length)]; records: Record objects.  aligned: no record straddles two BGZF blocks unless it is larger than
+	one (what htslib's bam_write1 does); otherwise the stream is cut every `block` bytes wherever that falls."""
 	ref_index = {n: i for i, (n, l) in enumerate(refs)}
 	raw = b"BAM\1" + struct.pack("<i", len(header_text)) + header_text.encode() + struct.pack("<i", len(refs))
 	for n, l in refs:
 		raw += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
-	for r in records:
-		raw += bam_bytes(r, ref_index)
 	with open(path, "wb") as f:
-		for i in range(0, len(raw), 0xff00):
-			f.write(_bgzf_block(raw[i:i + 0xff00]))
+		if aligned:
+			cur = raw
+			for r in records:
+				b = bam_bytes(r, ref_index)
+				if cur and len(cur) + len(b) > block:
+					f.write(_bgzf_block(cur)); cur = b""
+				cur += b
+				while len(cur) > block:
+					f.write(_bgzf_block(cur[:block])); cur = cur[block:]
+			if cur:
+				f.write(_bgzf_block(cur))
+		else:
+			for r in records:
+				raw += bam_bytes(r, ref_index)
+			for i in range(0, len(raw), block):
+				f.write(_bgzf_block(raw[i:i + block]))
 		f.write(_bgzf_block(b""))
 
 

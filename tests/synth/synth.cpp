@@ -5,8 +5,14 @@
 //
 // PRNG: splitmix64 -> xoshiro256**; every contig and every read (pair) derives its own stream from (seed, index), so the
 // output does not depend on the thread count.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -65,10 +71,23 @@ struct rng
 
 char const NUC[4] = {'A', 'C', 'G', 'T'};
 
+struct text_view
+{
+	char const *p{};
+	uint64_t n{};
+	uint64_t size() const { return n; }
+	char operator[](uint64_t i) const { return p[i]; }
+};
+
 struct row
 {
 	std::vector <uint64_t> gap_words;	// linear: bit (c & 63) of word (c >> 6) = 1 iff column c is a gap
 	std::string text;					// unaligned characters
+	// What the readers use: the two above, or the same arrays inside a file mapped by synth_genome_map (then the two above are empty).
+	uint64_t const *gw{};
+	uint64_t n_gw{};
+	text_view tv;
+	void finish() { gw = gap_words.data(); n_gw = gap_words.size(); tv = text_view{text.data(), text.size()}; }
 };
 
 struct contig
@@ -117,6 +136,8 @@ struct synth_genome
 {
 	std::vector <contig> contigs;
 	uint32_t n_founders{};
+	void *mapping{};			// synth_genome_map: the file's pages (shared by every process that maps it)
+	uint64_t mapping_bytes{};
 };
 
 struct synth_reads
@@ -283,6 +304,7 @@ synth_genome *synth_genome_create(synth_genome_params const *p, int n_threads)
 				build_contig(*p, i, lens[i], g->contigs[i]);
 		});
 	for (auto &x : th) x.join();
+	for (auto &c : g->contigs) for (auto &r : c.rows) r.finish();
 	return g;
 }
 
@@ -303,11 +325,78 @@ synth_genome *synth_genome_from_aligned(char const *const *rows, uint32_t n_rows
 			if ('-' == rows[r][i]) set_gap(c.rows[r], i);
 			else c.rows[r].text.push_back(rows[r][i]);
 		}
+		c.rows[r].finish();
 	}
 	return g;
 }
 
-void synth_genome_free(synth_genome *g) { delete g; }
+void synth_genome_free(synth_genome *g)
+{
+	if (g && g->mapping) munmap(g->mapping, g->mapping_bytes);
+	delete g;
+}
+
+// The genome as one file (bench.py with several ranks on a node: one rank generates it into /dev/shm, the others map the same
+// pages instead of generating or holding copies of their own).  Layout: u64 magic, n_contigs, n_founders; per contig u64 n_cols;
+// per row u64 n_gap_words, n_text; then the arrays, each at a multiple of 64 bytes, in the same order.
+static uint64_t const SYNTH_MAGIC = UINT64_C(0x31474E5933435650);	// "PVC3YNG1"
+
+int synth_genome_save(synth_genome const *g, char const *path)
+{
+	FILE *f = std::fopen(path, "wb");
+	if (!f) return -1;
+	std::vector <uint64_t> head{SYNTH_MAGIC, (uint64_t) g->contigs.size(), (uint64_t) g->n_founders};
+	for (auto const &c : g->contigs)
+	{
+		head.push_back(c.n_cols);
+		for (auto const &r : c.rows) { head.push_back(r.n_gw); head.push_back(r.tv.n); }
+	}
+	bool ok = head.size() == std::fwrite(head.data(), 8, head.size(), f);
+	uint64_t at = 8 * head.size();
+	static char const zeros[64] = {0};
+	auto put = [&](void const *p, uint64_t n) {
+		uint64_t const pad = (64 - at % 64) % 64;
+		ok = ok && pad == std::fwrite(zeros, 1, pad, f) && n == std::fwrite(p, 1, n, f);
+		at += pad + n;
+	};
+	for (auto const &c : g->contigs)
+		for (auto const &r : c.rows) { put(r.gw, 8 * r.n_gw); put(r.tv.p, r.tv.n); }
+	ok = (0 == std::fclose(f)) && ok;
+	return ok ? 0 : -1;
+}
+
+synth_genome *synth_genome_map(char const *path)
+{
+	int const fd = open(path, O_RDONLY);
+	if (fd < 0) return nullptr;
+	struct stat st{};
+	if (fstat(fd, &st) || st.st_size < 24) { close(fd); return nullptr; }
+	void *m = mmap(nullptr, (size_t) st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+	close(fd);
+	if (MAP_FAILED == m) return nullptr;
+	uint64_t const *h = (uint64_t const *) m;
+	if (SYNTH_MAGIC != h[0]) { munmap(m, (size_t) st.st_size); return nullptr; }
+	synth_genome *g = new synth_genome;
+	g->mapping = m; g->mapping_bytes = (uint64_t) st.st_size;
+	g->contigs.resize(h[1]);
+	g->n_founders = (uint32_t) h[2];
+	uint64_t k = 3;
+	for (auto &c : g->contigs)
+	{
+		c.n_cols = h[k++];
+		c.rows.resize(1 + g->n_founders);
+		for (auto &r : c.rows) { r.n_gw = h[k++]; r.tv.n = h[k++]; }
+	}
+	uint64_t at = 8 * k;
+	for (auto &c : g->contigs)
+		for (auto &r : c.rows)
+		{
+			at = (at + 63) / 64 * 64; r.gw = (uint64_t const *) ((char const *) m + at); at += 8 * r.n_gw;
+			at = (at + 63) / 64 * 64; r.tv.p = (char const *) m + at; at += r.tv.n;
+		}
+	if (at > g->mapping_bytes) { synth_genome_free(g); return nullptr; }
+	return g;
+}
 uint32_t synth_genome_entry_count(synth_genome const *g) { return (uint32_t) (g->contigs.size() * (1 + g->n_founders)); }
 uint32_t synth_genome_founders(synth_genome const *g) { return g->n_founders; }
 uint32_t synth_genome_contigs(synth_genome const *g) { return (uint32_t) g->contigs.size(); }
@@ -318,7 +407,7 @@ void synth_genome_entry(synth_genome const *g, uint32_t e, uint64_t const **gap_
 	uint32_t const per = 1 + g->n_founders;
 	contig const &c = g->contigs[e / per];
 	row const &r = c.rows[e % per];
-	*gap_words = r.gap_words.data(); *n_cols = c.n_cols; *text = r.text.data(); *text_len = r.text.size();
+	*gap_words = r.gw; *n_cols = c.n_cols; *text = r.tv.p; *text_len = r.tv.n;
 }
 
 namespace {
@@ -339,7 +428,7 @@ struct read_out
 void make_read(synth_genome const &g, synth_reads_params const &p, rng &r, uint32_t contig_i, uint32_t founder, uint64_t start, read_out &out)
 {
 	uint32_t const per = 1 + g.n_founders;
-	std::string const &text = g.contigs[contig_i].rows[1 + founder].text;
+	text_view const text = g.contigs[contig_i].rows[1 + founder].tv;
 	uint32_t const L = p.read_len;
 	out.src_entry = contig_i * per + 1 + founder;
 	out.dst_entry = contig_i * per;
@@ -434,7 +523,7 @@ synth_reads *synth_reads_create(synth_genome const *g, synth_reads_params const 
 	// Contig choice proportional to founder-0 length.
 	std::vector <uint64_t> cum(g->contigs.size() + 1, 0);
 	for (size_t i = 0; i < g->contigs.size(); ++i)
-		cum[i + 1] = cum[i] + g->contigs[i].rows[1].text.size();
+		cum[i + 1] = cum[i] + g->contigs[i].rows[1].tv.size();
 
 	// Per-thread contiguous unit ranges; each thread writes thread-local vectors that are concatenated in order.
 	struct tl { synth_reads part; };
@@ -452,7 +541,7 @@ synth_reads *synth_reads_create(synth_genome const *g, synth_reads_params const 
 				uint64_t const x = r.below(cum.back());
 				uint32_t ci = (uint32_t) (std::upper_bound(cum.begin(), cum.end(), x) - cum.begin() - 1);
 				uint32_t const f = (uint32_t) r.below(g->n_founders);
-				uint64_t const flen = g->contigs[ci].rows[1 + f].text.size();
+				uint64_t const flen = g->contigs[ci].rows[1 + f].tv.size();
 				uint32_t n_here = 1;
 				uint64_t span = L + 8;
 				uint64_t insert = 0;

@@ -64,6 +64,10 @@ def lib():
 		L.synth_genome_from_aligned.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.c_uint64]
 		L.synth_genome_from_aligned.restype = C.c_void_p
 		L.synth_genome_free.argtypes = [C.c_void_p]
+		L.synth_genome_save.argtypes = [C.c_void_p, C.c_char_p]
+		L.synth_genome_save.restype = C.c_int
+		L.synth_genome_map.argtypes = [C.c_char_p]
+		L.synth_genome_map.restype = C.c_void_p
 		for f in (L.synth_genome_entry_count, L.synth_genome_founders, L.synth_genome_contigs):
 			f.argtypes = [C.c_void_p]
 			f.restype = C.c_uint32
@@ -86,9 +90,14 @@ def default_threads():
 class Genome:
 	"""Random founder MSA: entry e = contig * (1 + F) + row, row 0 = REF (destination), rows 1..F = founders."""
 
-	def __init__(self, params=None, n_threads=None, aligned_rows=None):
+	def __init__(self, params=None, n_threads=None, aligned_rows=None, mapped_from=None):
 		self._L = lib()
-		if aligned_rows is not None:
+		if mapped_from is not None:
+			h = self._L.synth_genome_map(os.fsencode(mapped_from))
+			if not h:
+				raise OSError("%s is not a genome saved by Genome.save()" % mapped_from)
+			self._h = C.c_void_p(h)
+		elif aligned_rows is not None:
 			rows = [r if isinstance(r, bytes) else r.encode() for r in aligned_rows]
 			arr = (C.c_char_p * len(rows))(*rows)
 			self._h = C.c_void_p(self._L.synth_genome_from_aligned(arr, len(rows), len(rows[0])))
@@ -102,6 +111,11 @@ class Genome:
 		if getattr(self, "_h", None):
 			self._L.synth_genome_free(self._h)
 			self._h = None
+
+	def save(self, path):
+		"""The genome as one file that Genome(mapped_from=path) maps (shared pages: several processes, one copy)."""
+		if self._L.synth_genome_save(self._h, os.fsencode(path)):
+			raise OSError("unable to write %s" % path)
 
 	def entry(self, e):
 		"""(gap_words uint64 view, n_cols, text uint8 view) — views into the generator's memory."""

@@ -14,7 +14,7 @@ from panvc3_amd import _lib
 
 
 def declared_symbols():
-	text = open(os.path.join(ROOT, "include", "pvc3.h")).read()
+	text = open(os.path.join(ROOT, "include", "pvc3.h")).read() + open(os.path.join(ROOT, "include", "pvc3_records.h")).read()
 	return sorted(set(re.findall(r"PVC3_API\s+[^;(]*?\b(pvc3_\w+)\s*\(", text)))
 
 

@@ -289,3 +289,62 @@ def test_inflate_refuses_what_is_wrong(gpu_inflater):
 		else:
 			assert status[j] != 0 or got[j] != data[:n] or n != len(data)
 	assert status[1] != 0 and status[3] != 0 and status[5] != 0 and status[7] != 0
+
+
+@pytest.mark.gpu
+def test_device_resident_compressor_makes_the_file_bytes():
+	"""pvc3_bgzf_dev_*: the input lies in device memory (the record path's kernels write it there), and what comes back is the BGZF
+	file — every block with its gzip / BC header, the stream, the CRC-32 computed on the device and ISIZE.  Python's gzip reads
+	multi-member files and verifies both trailers, so a wrong checksum, size or header fails here."""
+	import gzip
+	import struct
+	from panvc3_amd import bgzf
+	rng = np.random.default_rng(21)
+	comp = bgzf.DeviceCompressor(0, max_blocks=40, n_slots=2)
+	try:
+		for slot, n in ((0, 1), (1, 65279), (0, 65280), (1, 65281), (0, 3 * 65280 + 17), (1, 40 * 65280)):
+			data = (_bam_like(rng, n // 280 + 2) * 2)[:n] if n > 1000 else bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
+			data = (data * (n // len(data) + 1))[:n]
+			blob, ms = comp.deflate(data, slot=slot)
+			assert gzip.decompress(blob) == data
+			# block by block: header fields, BSIZE, ISIZE
+			p, total = 0, 0
+			while p < len(blob):
+				assert blob[p:p + 4] == b"\x1f\x8b\x08\x04" and blob[p + 10:p + 16] == b"\x06\x00BC\x02\x00"
+				bsize = struct.unpack_from("<H", blob, p + 16)[0] + 1
+				crc, isize = struct.unpack_from("<II", blob, p + bsize - 8)
+				assert isize == min(65280, n - total) and crc == (zlib.crc32(data[total:total + isize]) & 0xffffffff)
+				total += isize; p += bsize
+			assert p == len(blob) and total == n
+	finally:
+		comp.close()
+
+
+@pytest.mark.gpu
+def test_device_resident_inflater_and_checksums():
+	"""pvc3_bgzf_inflater_submit_device: the blocks' bytes land in device memory of the caller, and every block's CRC-32 comes back
+	as the device computed it (lengths of every residue modulo 64 and 4, the empty range, a refused block)."""
+	from panvc3_amd import bgzf
+	rng = np.random.default_rng(22)
+	sizes = [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1020, 4093, 65279, 65280, 65536, 30000]
+	pieces = []
+	for n in sizes:
+		d = _bam_like(rng, n // 250 + 2)
+		pieces.append((d * (n // len(d) + 1))[:n])
+	streams = []
+	for p in pieces:
+		c = zlib.compressobj(6, zlib.DEFLATED, -15)
+		streams.append(c.compress(p) + c.flush())
+	streams[-1] = streams[-1][:len(streams[-1]) // 2]		# a stream that ends early: refused, whatever lies in its place
+	inf = bgzf.BlockInflater(0, max_in=2 << 20, max_out=1, max_blocks=64, n_slots=2)
+	try:
+		for slot in (0, 1):
+			got, status, crcs = inf.inflate_to_device(streams, sizes, slot=slot)
+			assert list(status[:-1]) == [0] * (len(sizes) - 1) and status[-1] != 0
+			o = 0
+			for i, p in enumerate(pieces[:-1]):
+				assert got[o:o + len(p)] == p, i
+				assert int(crcs[i]) == (zlib.crc32(p) & 0xffffffff), (i, len(p))
+				o += len(p)
+	finally:
+		inf.close()

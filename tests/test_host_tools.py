@@ -340,6 +340,13 @@ def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_m
 		assert [l for l in pd.stdout.decode().split("\n") if l and not l.startswith("@")] == expect, extra
 		assert open(tmp_path / "ranges.tsv").read() == "Location\tLength\n" + "".join("%d\t%d\n" % r for r in ranges)
 
+	# Results that outgrow the arrays they were to land in (here every batch's: PVC3_CLI_TINY_RESULTS): the batch is projected again
+	# on its own — after the same GPU's next batch, which is already queued and shares the context's alignment scratch and trace
+	# buffers, has run (pvc3_pipeline_synchronize).
+	for extra in (["--batch-size=64"], ["--devices=0,0", "--batch-size=100"]):
+		pt = _run(cmd + extra, cwd=tmp_path, env={"PVC3_CLI_TINY_RESULTS": "1"})
+		assert [l for l in pt.stdout.decode().split("\n") if l and not l.startswith("@")] == expect, extra
+
 	# A BGZF-compressed multi-contig FASTA with its .gzi and .fai (what the reference requires: compressed_fasta_reader.cc:163-248):
 	# only the destination contig is read, through the indexes; the output does not change.  Also the uncompressed file + .fai.
 	decoy = "".join("ACGT"[x] for x in np.random.default_rng(1).integers(0, 4, size=30011))
@@ -393,6 +400,51 @@ def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_m
 				   "--record-index-tag=XI", "-t", "XS", "-t", "YS", "--batch-size=64"] + extra, cwd=tmp_path, env=env)
 		assert [l for l in p3.stdout.decode().split("\n") if l and not l.startswith("@")] == expect
 		assert (b"BGZF input on the GPU" in p3.stderr) == bool(extra and extra[0] == "--debugging-output")
+	# ---- the record path on the GPU (--record-path=gpu: the default for a BAM file in and BAM out on one GPU) ----------------------
+	# The file's blocks are inflated on the GPU, the records found in the inflated bytes, filtered, scattered into the batch
+	# arrays, projected, written anew and compressed without leaving it (include/pvc3_records.h, device_records.hpp).  Behind the
+	# header (whose @PG line holds the command line) the uncompressed output must be the bytes the host's threads make
+	# (--record-path=host) — for a file whose records straddle its blocks (our writer's, bamio's default), for one written the way
+	# htslib writes (no record straddles a block), with pieces of the file so small that records straddle the pieces as well and
+	# every piece holds less than four records that pass the filters, and with the blocks inflated by the host's threads.
+	def records_behind_header(path):
+		raw = gzip.decompress(open(path, "rb").read())
+		l_text, = struct.unpack_from("<i", raw, 4)
+		q = 8 + l_text
+		n_ref, = struct.unpack_from("<i", raw, q); q += 4
+		for _ in range(n_ref):
+			l_name, = struct.unpack_from("<i", raw, q); q += 4 + l_name + 4
+		return raw[q:]
+	def summary(stderr):
+		text = stderr.decode()
+		return [l for l in text.split("\n") if l.startswith("\t") and not l.startswith("\tStages") and not l.startswith("\tTimeline") and not l.startswith("\tRecord path") and not l.startswith("\tBGZF") and not l.startswith("\tteardown")]
+	bamio.write_bam(tmp_path / "htslib_style.bam", header, [(n, l) for n, l, e in in_refs], recs, aligned=True, block=20000)
+	bamio.write_bam(tmp_path / "small_blocks.bam", header, [(n, l) for n, l, e in in_refs], recs, block=700)		# records of ~ 300 bytes: most blocks hold no record start
+	base_cmd = [tools["panvc3_project_alignments"], "-m", "msa-index.dat", "-r", "genome.fa", "-d", "REF", "-s", "/", "-u", "order.txt", "--record-index-tag=XI", "-t", "XS", "-t", "YS", "-b",
+				"--output-realigned-ranges=ranges_dev.tsv", "--debugging-output"]
+	for name in ("alignments.sorted.bam", "htslib_style.bam", "small_blocks.bam"):
+		ph = _run(base_cmd + ["-a", name, "-o", "host_path.bam", "--record-path=host"], cwd=tmp_path)
+		want_bytes = records_behind_header(tmp_path / "host_path.bam")
+		want_ranges = open(tmp_path / "ranges_dev.tsv").read()
+		assert b"Record path on the GPU" not in ph.stderr
+		for env, extra in ((None, []), ({"PVC3_BGZF_CHUNK": "3000", "PVC3_RECORDS_STREAM": "65536"}, []), ({"PVC3_BGZF_CHUNK": "70000"}, ["--record-path=gpu"]), (None, ["--bgzf-inflate=host"])):
+			pd = _run(base_cmd + ["-a", name, "-o", "dev_path.bam"] + extra, cwd=tmp_path, env=env)
+			assert b"Record path on the GPU" in pd.stderr, (name, env, extra)
+			got_bytes = records_behind_header(tmp_path / "dev_path.bam")
+			if got_bytes != want_bytes:
+				_, _, a = bamio.read_bam(tmp_path / "host_path.bam")
+				_, _, b = bamio.read_bam(tmp_path / "dev_path.bam")
+				assert len(a) == len(b), (name, env, extra, len(a), len(b))
+				for x, y in zip(a, b):
+					assert x == y, (name, env, extra, x, y)
+				raise AssertionError("the record bytes differ although the parsed records agree: %s %s %s" % (name, env, extra))
+			assert open(tmp_path / "ranges_dev.tsv").read() == want_ranges
+			assert summary(pd.stderr) == summary(ph.stderr), (name, env, extra)
+	_run([tools["panvc3_project_alignments"], "--io-only", "-a", "dev_path.bam", "-o", "dev_path.sam"], cwd=tmp_path)
+	assert [l for l in open(tmp_path / "dev_path.sam").read().split("\n") if l and not l.startswith("@")] == expect
+	bad = _run(base_cmd + ["-a", "alignments.sam", "-o", "x.bam", "--record-path=gpu"], cwd=tmp_path, check=False)
+	assert bad.returncode != 0 and b"--record-path=gpu needs a BAM file" in bad.stderr
+
 	text, refs, got = bamio.read_bam(tmp_path / "out.bam")
 	assert refs == [("test", 10000)]
 	for g in got[:50]:

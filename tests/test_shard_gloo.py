@@ -175,3 +175,28 @@ def test_bench_parent_starts_ranks_and_reports_their_failure():
 	env.update(RANK="0", WORLD_SIZE="3", LOCAL_RANK="0")
 	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
 	assert r.returncode != 0 and "does not match --gpus" in r.stderr
+
+
+def test_bench_setup_of_eight_ranks_is_bounded():
+	"""`python bench.py --gpus 8 --setup-only`: the parent starts eight ranks through launch_ranks with bench.py's own argument
+	path; they meet over gloo, rank 0 generates the genome once into /dev/shm, all map it, every rank samples its own reads and
+	builds the host side of the index, prints its set-up seconds and peak resident set, and stops before a GPU is touched.  The
+	genome file is gone afterwards, no rank takes long, and no rank holds more than a small multiple of its own reads."""
+	import glob
+	import re
+	import subprocess
+	import time
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+	before = set(glob.glob("/dev/shm/pvc3_bench_*"))
+	t0 = time.time()
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scale", "0.002", "--setup-only"], env=env, capture_output=True, text=True, timeout=900)
+	assert r.returncode == 0, r.stderr[-2000:]
+	line = json.loads(r.stdout.strip().splitlines()[-1])
+	assert line["setup_only"] and line["n_ranks"] == 8 and line["records_per_rank"] == 80000
+	ranks = re.findall(r"\[bench\] rank (\d+) of 8: set-up ([0-9.]+) s \(genome ([0-9.]+), reads ([0-9.]+), index on the host ([0-9.]+); (\d+) threads\), peak resident set ([0-9.]+) MB", r.stderr)
+	assert sorted(int(x[0]) for x in ranks) == list(range(8))
+	for x in ranks:
+		assert float(x[1]) < 120.0, x			# seconds of set-up per rank (2 Mbp genome, 80 000 records)
+		assert float(x[6]) < 2500.0, x			# MB: torch + the mapped genome + this rank's reads; never eight genomes
+	assert set(glob.glob("/dev/shm/pvc3_bench_*")) == before		# the shared genome's name was removed
+	assert time.time() - t0 < 600

@@ -210,7 +210,8 @@ class Oracle:
 		k = n.value
 		return runs[:k].copy(), ref_loc[:k].copy(), first[:k].copy(), second[:k].copy(), fq.value, fr.value
 
-	def align_global(self, ref, query, qual=None, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64):
+	def align_global(self, ref, query, qual=None, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, tiebreak_mode=0):
+		score_mode = int(score_mode) | (int(tiebreak_mode) << 8)
 		r = ref.encode() if isinstance(ref, str) else bytes(ref)
 		q = query.encode() if isinstance(query, str) else bytes(query)
 		qa = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)
@@ -223,8 +224,9 @@ class Oracle:
 			raise ValueError("orc_align_global: %d" % rc)
 		return out[:n.value].copy(), score.value
 
-	def project_alignment(self, src, dst, src_pos, cigar, query, qual=None, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64):
+	def project_alignment(self, src, dst, src_pos, cigar, query, qual=None, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, tiebreak_mode=0):
 		"""Returns (dst_pos, cigar u32 array, runs structured array)."""
+		score_mode = int(score_mode) | (int(tiebreak_mode) << 8)
 		cig = cigar_encode(cigar) if isinstance(cigar, str) else np.ascontiguousarray(cigar, dtype=np.uint32)
 		q = query.encode() if isinstance(query, str) else bytes(query)
 		qa = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)
@@ -254,9 +256,10 @@ class Oracle:
 		n = self._L.orc_collapse_cigar(_ptr(cig), cig.size)
 		return cig[:n].copy()
 
-	def batch_project(self, batch, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, n_threads=1):
+	def batch_project(self, batch, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, n_threads=1, tiebreak_mode=0):
 		"""batch: dict of numpy arrays with the field names of include/pvc3.h's pvc3_batch_in.
 		Returns dict(dst_pos, mate_dst_pos, status, out_cigar_off, out_cigar, run_off, runs)."""
+		score_mode = int(score_mode) | (int(tiebreak_mode) << 8)
 		n = int(batch["src_pos"].size)
 		bi = BatchIn()
 		bi.n = n

@@ -568,12 +568,27 @@ enum { TR_DIAG = 0, TR_UP = 1, TR_LEFT = 2, TR_DIR_MASK = 3, TR_V_OPEN = 4, TR_H
 
 #define ORC_MAX_PHRED 41	/* max_letter<phred42> (utility.hh:75-80, alignment_projector.cc:108) */
 
+/* Tie-break policies (seqan3's choice among co-optimal alignments is not pinned by the reference's tests
+ * beyond four sub-problems).  They travel in bits 8-15 of the score_mode argument (ORC_TIEBREAK(mode)):
+ *   mode = 2 * p + o;  p = 0..5: the order in which equal candidates of a cell are preferred,
+ *       0 diagonal > up > left (the restated seqan3 order; the default), 1 diagonal > left > up, 2 up > diagonal > left,
+ *       3 up > left > diagonal, 4 left > diagonal > up, 5 left > up > diagonal  (up = gap in the reference = 'I', left = 'D');
+ *   o = 0: a gap that could be extended or opened at the same score is extended (default), 1: it is opened.
+ * The scores are the same under every policy; only the path among the co-optimal ones differs. */
+static int const TB_ORDER[6][3] = {{TR_DIAG, TR_UP, TR_LEFT}, {TR_DIAG, TR_LEFT, TR_UP}, {TR_UP, TR_DIAG, TR_LEFT}, {TR_UP, TR_LEFT, TR_DIAG}, {TR_LEFT, TR_DIAG, TR_UP}, {TR_LEFT, TR_UP, TR_DIAG}};
+
 int orc_align_global(
 	char const *ref, uint32_t m, char const *query, uint32_t n, uint8_t const *qual,
 	int32_t gap_open, int32_t gap_ext, int score_mode,
 	uint32_t *out_cigar, uint32_t out_cap, uint32_t *n_out, double *score_out
 )
 {
+	int const tiebreak = (score_mode >> 8) & 0xff;
+	score_mode &= 0xff;
+	if (tiebreak >= 12) return -ORC_ERR_CIGAR_OP;
+	int const *const order = TB_ORDER[tiebreak >> 1];
+	int const open_on_tie = tiebreak & 1;
+#define OPENS(ext, open) (open_on_tie ? !((open) < (ext)) : ((ext) < (open)))
 	double const go = (double) gap_open + (double) gap_ext;	/* seqan3's internal gap_open_score = open + extension */
 	double const ge = (double) gap_ext;
 
@@ -607,7 +622,7 @@ int orc_align_global(
 	{
 		double const open = M[AT(0, j - 1)] + go, ext = H[AT(0, j - 1)] + ge;
 		uint8_t t = TR_LEFT;
-		if (ext < open) { H[AT(0, j)] = open; t |= TR_H_OPEN; } else H[AT(0, j)] = ext;
+		if (OPENS(ext, open)) { H[AT(0, j)] = open; t |= TR_H_OPEN; } else H[AT(0, j)] = ext;
 		M[AT(0, j)] = H[AT(0, j)];
 		V[AT(0, j)] = -INFINITY;
 		T[AT(0, j)] = t;
@@ -617,7 +632,7 @@ int orc_align_global(
 		{	/* first column: initialise_first_column_cell */
 			double const open = M[AT(i - 1, 0)] + go, ext = V[AT(i - 1, 0)] + ge;
 			uint8_t t = TR_UP;
-			if (ext < open) { V[AT(i, 0)] = open; t |= TR_V_OPEN; } else V[AT(i, 0)] = ext;
+			if (OPENS(ext, open)) { V[AT(i, 0)] = open; t |= TR_V_OPEN; } else V[AT(i, 0)] = ext;
 			M[AT(i, 0)] = V[AT(i, 0)];
 			H[AT(i, 0)] = -INFINITY;
 			T[AT(i, 0)] = t;
@@ -632,14 +647,17 @@ int orc_align_global(
 
 			/* Gap scores arriving at (i,j); ties keep the extension. */
 			double v_open = M[AT(i - 1, j)] + go, v_ext = V[AT(i - 1, j)] + ge, v;
-			if (v_ext < v_open) { v = v_open; t |= TR_V_OPEN; } else v = v_ext;
+			if (OPENS(v_ext, v_open)) { v = v_open; t |= TR_V_OPEN; } else v = v_ext;
 			double h_open = M[AT(i, j - 1)] + go, h_ext = H[AT(i, j - 1)] + ge, h;
-			if (h_ext < h_open) { h = h_open; t |= TR_H_OPEN; } else h = h_ext;
+			if (OPENS(h_ext, h_open)) { h = h_open; t |= TR_H_OPEN; } else h = h_ext;
 
-			double best = M[AT(i - 1, j - 1)] + s;
-			uint8_t dir = TR_DIAG;
-			if (best < v) { best = v; dir = TR_UP; }
-			if (best < h) { best = h; dir = TR_LEFT; }
+			/* the candidates in the policy's order; a later one replaces an earlier one only if it is strictly better */
+			double cand[3];
+			cand[TR_DIAG] = M[AT(i - 1, j - 1)] + s; cand[TR_UP] = v; cand[TR_LEFT] = h;
+			double best = cand[order[0]];
+			uint8_t dir = (uint8_t) order[0];
+			if (best < cand[order[1]]) { best = cand[order[1]]; dir = (uint8_t) order[1]; }
+			if (best < cand[order[2]]) { best = cand[order[2]]; dir = (uint8_t) order[2]; }
 
 			M[AT(i, j)] = best; V[AT(i, j)] = v; H[AT(i, j)] = h; T[AT(i, j)] = (uint8_t) (t | dir);
 		}
@@ -692,6 +710,7 @@ int orc_align_global(
 	*n_out = cb.n;
 
 	free(rev); free(M); free(V); free(H); free(T);
+#undef OPENS
 	return cb.overflow ? -ORC_ERR_CAPACITY : 0;
 }
 

@@ -34,6 +34,8 @@ extern "C" {
 enum { ORC_M = 0, ORC_I = 1, ORC_D = 2, ORC_N = 3, ORC_S = 4, ORC_H = 5, ORC_P = 6, ORC_EQ = 7, ORC_X = 8 };
 
 enum { ORC_SCORE_FP64 = 0, ORC_SCORE_INT32_TRUNC = 1 };
+/* The tie-break policy 0 .. 11 (see orc_align_global) travels in bits 8-15 of every score_mode argument. */
+#define ORC_TIEBREAK(mode) ((int) (mode) << 8)
 
 /* Record flag bits (shared meaning with include/pvc3.h). */
 enum { ORC_FLAG_HAS_QUAL = 1u, ORC_FLAG_HAS_MATE = 2u };

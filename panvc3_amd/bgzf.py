@@ -167,6 +167,32 @@ class BlockInflater:
 			o += n
 		return got, status, best
 
+	def inflate_to_device(self, streams, sizes, slot=0):
+		"""pvc3_bgzf_inflater_submit_device: the streams inflated into device memory (allocated here), one behind the other; returns
+		(the bytes copied back, statuses, the CRC-32 of every block as the device computed them)."""
+		inp, out, blocks = self._views(slot)
+		pos, opos = 3, 0
+		for i, (s, n) in enumerate(zip(streams, sizes)):
+			inp[pos:pos + len(s)] = np.frombuffer(s, dtype=np.uint8)
+			blocks[i] = (pos, len(s), n, opos)
+			pos += len(s) + 5
+			opos += n
+		H = hip_runtime()
+		d = C.c_void_p()
+		assert 0 == H.hipMalloc(C.byref(d), opos + 4096)
+		try:
+			assert 0 == H.hipMemset(d, 0xAB, opos + 4096)
+			_check(self._L.pvc3_bgzf_inflater_submit_device(self._h, slot, len(streams), pos, d, opos))
+			st, crc, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+			_check(self._L.pvc3_bgzf_inflater_wait_device(self._h, slot, C.byref(st), C.byref(crc), C.byref(ms)))
+			status = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint32)), shape=(len(streams),)).copy()
+			crcs = np.ctypeslib.as_array(C.cast(crc, C.POINTER(C.c_uint32)), shape=(len(streams),)).copy()
+			host = (C.c_uint8 * max(1, opos))()
+			assert 0 == H.hipMemcpy(host, d, opos, D2H)
+			return bytes(host)[:opos], status, crcs
+		finally:
+			H.hipFree(d)
+
 
 _HIP = None
 

@@ -722,7 +722,7 @@ struct pvc3_bgzf_dev
 	int device{};
 	uint32_t max_blocks{}, n_slots{}, grid_max{};
 	hipStream_t stream{};
-	uint8_t *d_out{}, *d_file{};
+	uint8_t *d_out{};
 	uint32_t *d_len{}, *d_out_len{}, *d_tokens{}, *d_crc{};
 	uint64_t *d_file_off{};
 	pvc3_crc::tables *d_crc_tables{};
@@ -730,6 +730,7 @@ struct pvc3_bgzf_dev
 	struct slot
 	{
 		uint8_t *d_in{};				// the caller's kernels write here
+		uint8_t *d_file{};				// the framed blocks on the device (a slot's own: they are fetched when its sizes are known, which may be after the next slot was submitted)
 		uint8_t *h_file{};				// page-locked: the framed blocks
 		uint32_t *h_out_len{};
 		uint64_t *h_file_off{};
@@ -750,11 +751,12 @@ void pvc3_bgzf_dev_destroy(pvc3_bgzf_dev *h)
 	{
 		for (hipEvent_t e : {s.start, s.stop, s.sizes, s.done}) if (e) (void) hipEventDestroy(e);
 		if (s.d_in) (void) hipFree(s.d_in);
+		if (s.d_file) (void) hipFree(s.d_file);
 		if (s.h_file) (void) hipHostFree(s.h_file);
 		if (s.h_out_len) (void) hipHostFree(s.h_out_len);
 		if (s.h_file_off) (void) hipHostFree(s.h_file_off);
 	}
-	for (void *p : {(void *) h->d_out, (void *) h->d_file, (void *) h->d_len, (void *) h->d_out_len, (void *) h->d_tokens, (void *) h->d_crc, (void *) h->d_file_off, (void *) h->d_crc_tables})
+	for (void *p : {(void *) h->d_out, (void *) h->d_len, (void *) h->d_out_len, (void *) h->d_tokens, (void *) h->d_crc, (void *) h->d_file_off, (void *) h->d_crc_tables})
 		if (p) (void) hipFree(p);
 	if (h->stream) (void) hipStreamDestroy(h->stream);
 	delete h;
@@ -786,7 +788,6 @@ int pvc3_bgzf_dev_create(int device, uint32_t max_blocks, uint32_t n_slots, pvc3
 	size_t const in_bytes = (size_t) max_blocks * PVC3_BGZF_IN_STRIDE, out_bytes = (size_t) max_blocks * PVC3_BGZF_OUT_STRIDE;
 	h->file_cap = (size_t) max_blocks * (PVC3_BGZF_BLOCK + 5 + 26);		// a block that does not shrink is stored: five bytes more
 	if (0 == rc) check(hipMalloc((void **) &h->d_out, out_bytes), "hipMalloc");
-	if (0 == rc) check(hipMalloc((void **) &h->d_file, h->file_cap), "hipMalloc");
 	if (0 == rc) check(hipMalloc((void **) &h->d_len, max_blocks * sizeof(uint32_t)), "hipMalloc");
 	if (0 == rc) check(hipMalloc((void **) &h->d_out_len, max_blocks * sizeof(uint32_t)), "hipMalloc");
 	if (0 == rc) check(hipMalloc((void **) &h->d_crc, max_blocks * sizeof(uint32_t)), "hipMalloc");
@@ -798,6 +799,7 @@ int pvc3_bgzf_dev_create(int device, uint32_t max_blocks, uint32_t n_slots, pvc3
 	{
 		auto &s = h->slots[i];
 		check(hipMalloc((void **) &s.d_in, in_bytes), "hipMalloc");
+		if (0 == rc) check(hipMalloc((void **) &s.d_file, h->file_cap), "hipMalloc");
 		if (0 == rc) check(hipMemset(s.d_in, 0, in_bytes), "hipMemset");		// (the pads in front of the blocks are read)
 		if (0 == rc) check(hipHostMalloc((void **) &s.h_file, h->file_cap, hipHostMallocDefault), "hipHostMalloc");
 		if (0 == rc) check(hipHostMalloc((void **) &s.h_out_len, max_blocks * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
@@ -830,7 +832,7 @@ int pvc3_bgzf_dev_submit(pvc3_bgzf_dev *h, uint32_t slot, uint64_t n_bytes)
 	HIP_TRY(hipEventRecord(s.stop, h->stream), "hipEventRecord");
 	hipLaunchKernelGGL(pvc3_crc::k_crc32_ranges, dim3((n_blocks < 4096) ? n_blocks : 4096), dim3(64), 0, h->stream, s.d_in, nullptr, h->d_len, PVC3_BGZF_IN_STRIDE, PVC3_BGZF_IN_PAD, n_blocks, h->d_crc_tables, h->d_crc);
 	hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, h->stream, h->d_out_len, n_blocks, h->d_file_off);
-	hipLaunchKernelGGL(k_frame_blocks, dim3((n_blocks < 2048) ? n_blocks : 2048), dim3(256), 0, h->stream, h->d_out, h->d_out_len, h->d_len, h->d_crc, h->d_file_off, n_blocks, h->d_file);
+	hipLaunchKernelGGL(k_frame_blocks, dim3((n_blocks < 2048) ? n_blocks : 2048), dim3(256), 0, h->stream, h->d_out, h->d_out_len, h->d_len, h->d_crc, h->d_file_off, n_blocks, s.d_file);
 	HIP_TRY(hipGetLastError(), "k_frame_blocks");
 	HIP_TRY(hipMemcpyAsync(s.h_out_len, h->d_out_len, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
 	HIP_TRY(hipMemcpyAsync(s.h_file_off, h->d_file_off, ((size_t) n_blocks + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
@@ -852,7 +854,7 @@ int pvc3_bgzf_dev_wait(pvc3_bgzf_dev *h, uint32_t slot, uint8_t const **file_byt
 		if (s.h_out_len[i] & SIZE_MISMATCH) return fail(E_STATE, "k_deflate_blocks: a stream is not as long as computed");
 	uint64_t const total = s.h_file_off[s.n];
 	if (total > h->file_cap) return fail(E_STATE, "pvc3_bgzf_dev_wait: the framed blocks exceed their buffer");
-	HIP_TRY(hipMemcpyAsync(s.h_file, h->d_file, total, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(s.h_file, s.d_file, total, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
 	HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
 	HIP_TRY(hipEventSynchronize(s.done), "hipEventSynchronize");
 	if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, s.start, s.stop), "hipEventElapsedTime");

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(WAVE) void k_frame_walk(uint8_t const *__restrict__
 	if (NONE != g)
 	{
 		w = walk_records(U, g, hi, end, [](uint32_t, uint32_t) {});
-		if (w.invalid && 0 != b) { g = NONE; w = walk_result{0, NONE, 0, false}; }		// a guess that led into garbage: no guess
+		if (w.invalid) { g = NONE; w = walk_result{0, NONE, 0, false}; }		// a guess that led into garbage: no guess (k_frame_fix walks from the true place, and reports what it meets there)
 	}
 	guess[b] = (uint32_t) g; cnt[b] = w.cnt; exits[b] = w.exit; tails[b] = w.tail;
 }

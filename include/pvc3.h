@@ -90,8 +90,15 @@ typedef struct pvc3_params
 	int32_t gap_open;			/* --gap-opening-cost, seqan3 open_score (cmdline.ggo:43; default 0) */
 	int32_t gap_ext;			/* --gap-extension-cost, seqan3 extension_score (cmdline.ggo:44; default -1) */
 	int32_t score_mode;			/* PVC3_SCORE_* */
-	int32_t tiebreak_mode;		/* 0 = restated seqan3 order: diagonal > up ('I') > left ('D'), extension > opening */
+	int32_t tiebreak_mode;		/* which of the co-optimal alignments: 2 * p + o, PVC3_TIEBREAK_MODES of them.
+								   p: the order in which equal candidates of a cell are preferred — 0 diagonal > up > left (the restated
+								   seqan3 order, the default), 1 diagonal > left > up, 2 up > diagonal > left, 3 up > left > diagonal,
+								   4 left > diagonal > up, 5 left > up > diagonal (up = gap in the reference = 'I', left = 'D');
+								   o: 0 = a gap that could be extended or opened at the same score is extended, 1 = it is opened.
+								   The scores are the same under every policy.  Other than 0 is for pinning the order against the real
+								   binary (tests/parity_kit/): every run then goes through the one-run-per-wavefront kernel. */
 } pvc3_params;
+#define PVC3_TIEBREAK_MODES 12
 
 /* One realigned indel run (alignment_projector.cc:69-73). */
 typedef struct pvc3_run

@@ -471,12 +471,12 @@ def make_params(gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, tiebreak_mode=0):
 	return Params(gap_open, gap_ext, score_mode, tiebreak_mode)
 
 
-def project_batch(ctx, batch, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, pinned_out=False, out=None):
+def project_batch(ctx, batch, gap_open=0, gap_ext=-1, score_mode=SCORE_FP64, pinned_out=False, out=None, tiebreak_mode=0):
 	"""Host arrays in, host arrays out through pvc3_dbatch_* (upload, kernels, pack, download).  Returns (results, stats).
 	With pinned_out the result arrays live in page-locked memory owned by the returned dict's "_owner"."""
 	db = DeviceBatch(ctx, batch)
 	try:
-		db.project(make_params(gap_open, gap_ext, score_mode))
+		db.project(make_params(gap_open, gap_ext, score_mode, tiebreak_mode))
 		stats = db.finish()
 		res = db.download(pinned=pinned_out, out=out)
 		if pinned_out and out is None:

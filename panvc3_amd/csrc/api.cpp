@@ -87,10 +87,10 @@ int upload_params(pvc3_context *ctx, pvc3_params const &p)
 		return PVC3_OK;
 	if (p.score_mode != PVC3_SCORE_FP64 && p.score_mode != PVC3_SCORE_INT32_TRUNC)
 		return set_error(PVC3_E_INVALID, "pvc3_params.score_mode %d is not a PVC3_SCORE_* value", p.score_mode);
-	if (0 != p.tiebreak_mode)
-		return set_error(PVC3_E_INVALID, "pvc3_params.tiebreak_mode %d: only 0 (restated seqan3 order) is defined", p.tiebreak_mode);
+	if (p.tiebreak_mode < 0 || p.tiebreak_mode >= PVC3_TIEBREAK_MODES)
+		return set_error(PVC3_E_INVALID, "pvc3_params.tiebreak_mode %d: 0 .. %d are defined", p.tiebreak_mode, PVC3_TIEBREAK_MODES - 1);
 	dev_params hp{};
-	hp.gap_open = p.gap_open; hp.gap_ext = p.gap_ext; hp.score_mode = p.score_mode;
+	hp.gap_open = p.gap_open; hp.gap_ext = p.gap_ext; hp.score_mode = p.score_mode; hp.tiebreak_mode = p.tiebreak_mode;
 	for (int q = 0; q <= 41; ++q)
 	{
 		hp.s_match[q] = malde_score(true, 41, q);
@@ -200,7 +200,7 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	if (int const e = launch_reduce_stats(b->n, b->work, s)) return set_error(PVC3_E_HIP, "k_reduce_stats launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
 	uint32_t const lds = ctx->realign_lds_bytes ? ctx->realign_lds_bytes : realign_lds_bytes();
-	if (int const e = launch_realign(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->d_params, ctx->realign_waves, big_wave_count(ctx), lds, ctx->packed_dp, s)) return set_error(PVC3_E_HIP, "k_realign launch: %s", hipGetErrorString((hipError_t) e));
+	if (int const e = launch_realign(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->d_params, ctx->realign_waves, big_wave_count(ctx), lds, (ctx->packed_dp && 0 == b->params.tiebreak_mode) ? 1u : 0u, s)) return set_error(PVC3_E_HIP, "k_realign launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[3], s));
 	if (int const e = launch_pack(b->n, b->work, b->packed, b->scan_tmp, s)) return set_error(PVC3_E_HIP, "pack launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[4], s));

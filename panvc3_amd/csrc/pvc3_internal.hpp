@@ -260,7 +260,7 @@ struct dev_params
 	int32_t gap_open;
 	int32_t gap_ext;
 	int32_t score_mode;
-	int32_t pad;
+	int32_t tiebreak_mode;				// pvc3_params::tiebreak_mode: other than 0 only k_realign_big knows (every run goes there then)
 	double s_match[42];					// Malde scores vs. reference quality 41, indexed by read phred
 	double s_mismatch[42];
 };

@@ -749,11 +749,15 @@ __device__ __forceinline__ dp_memory dp_carve(uint8_t *base, uint32_t m, uint32_
 	return d;
 }
 
+// The order of preference among equal candidates of a cell for tie-break policy p (pvc3_params::tiebreak_mode = 2 p + o).
+__constant__ uint32_t const TIEBREAK_ORDER[6][3] = {{TR_DIAG, TR_UP, TR_LEFT}, {TR_DIAG, TR_LEFT, TR_UP}, {TR_UP, TR_DIAG, TR_LEFT}, {TR_UP, TR_LEFT, TR_DIAG}, {TR_LEFT, TR_DIAG, TR_UP}, {TR_LEFT, TR_UP, TR_DIAG}};
+
 struct dp_scores
 {
 	double open, ext;			// pvc3_params gap costs
 	double const *match;		// LDS copies of dev_params::s_match / s_mismatch
 	double const *mismatch;
+	uint32_t tiebreak;		// pvc3_params::tiebreak_mode
 };
 
 // Global affine alignment of ref[0, m) (horizontal) against query bases [q0, q0 + n) (vertical); writes the operations
@@ -831,15 +835,29 @@ __device__ __forceinline__ uint32_t align_global_striped(
 				double const s = (r_rank == q_rank) ? s_match : s_mismatch;
 				uint32_t tr = 0;
 				double const v_open = up_m + go, v_ext = up_v + ge;
-				double v;
-				if (v_ext < v_open) { v = v_open; tr |= TR_V_OPEN; } else v = v_ext;
 				double const h_open = m_left + go, h_ext = h_left + ge;
-				double h;
-				if (h_ext < h_open) { h = h_open; tr |= TR_H_OPEN; } else h = h_ext;
-				double best = diag + s;
+				double v, h, best = diag + s;
 				uint32_t dir = TR_DIAG;
-				if (best < v) { best = v; dir = TR_UP; }
-				if (best < h) { best = h; dir = TR_LEFT; }
+				if (0 == sc.tiebreak)
+				{
+					if (v_ext < v_open) { v = v_open; tr |= TR_V_OPEN; } else v = v_ext;
+					if (h_ext < h_open) { h = h_open; tr |= TR_H_OPEN; } else h = h_ext;
+					if (best < v) { best = v; dir = TR_UP; }
+					if (best < h) { best = h; dir = TR_LEFT; }
+				}
+				else
+				{
+					// the other tie-break policies (uniform over the launch): the same values, another path among the co-optimal ones
+					bool const open_on_tie = sc.tiebreak & 1;
+					if (open_on_tie ? !(v_open < v_ext) : (v_ext < v_open)) { v = v_open; tr |= TR_V_OPEN; } else v = v_ext;
+					if (open_on_tie ? !(h_open < h_ext) : (h_ext < h_open)) { h = h_open; tr |= TR_H_OPEN; } else h = h_ext;
+					uint32_t const o0 = TIEBREAK_ORDER[sc.tiebreak >> 1][0], o1 = TIEBREAK_ORDER[sc.tiebreak >> 1][1], o2 = TIEBREAK_ORDER[sc.tiebreak >> 1][2];
+					double const dg = best;
+					auto cand = [&](uint32_t d) { return (TR_DIAG == d) ? dg : ((TR_UP == d) ? v : h); };
+					best = cand(o0); dir = o0;
+					if (best < cand(o1)) { best = cand(o1); dir = o1; }
+					if (best < cand(o2)) { best = cand(o2); dir = o2; }
+				}
 				mem.trace[(uint64_t) (i - 1) * m + (j - 1)] = (uint8_t) (tr | dir | ((r_rank == q_rank) ? TR_MATCH : 0));
 				m_left = best; h_left = h; cur_m = best; cur_v = v; diag = up_m;
 				if (lane == nr - 1) { mem.bnd_m[j] = best; mem.bnd_v[j] = v; }
@@ -894,6 +912,7 @@ __global__ __launch_bounds__(64, 8) void k_realign_big(dev_batch_work const W, d
 	dp_scores sc;
 	sc.open = (double) prm->gap_open; sc.ext = (double) prm->gap_ext;
 	sc.match = lds_scores; sc.mismatch = lds_scores + (MAX_PHRED + 1);
+	sc.tiebreak = (uint32_t) prm->tiebreak_mode;
 	wave_lds_fence();
 	uint32_t const count = W.counters->dp_count[DP_CLASS_BIG];
 	uint32_t const *list = W.dp_list + (uint64_t) DP_CLASS_BIG * W.runs_cap;

@@ -686,6 +686,46 @@ def test_indel_run_shapes_and_gap_scores(pvc3, oracle_mod):
 			assert stats["n_failed"] == 0 and stats["n_runs"] >= len(recs)
 
 
+def test_tiebreak_policies(pvc3, oracle_mod):
+	"""pvc3_params::tiebreak_mode 0 .. 11 (which of the co-optimal alignments: the order of preference among equal candidates of
+	a cell x whether a gap that could be extended or opened at the same score is extended or opened): every policy against the
+	oracle's, both score types, on runs with many co-optimal paths; the scores do not depend on the policy, the paths do."""
+	rng = np.random.default_rng(79)
+	seg = lambda k: "".join("ACGT"[x] for x in rng.integers(0, 4, size=k))
+	pairs, recs = [], []
+	for m, n in [(1, 1), (3, 3), (3, 5), (7, 2), (12, 12), (16, 20), (33, 8), (8, 33), (40, 40), (70, 30), (5, 100)]:
+		for variant in range(4):
+			p, s = seg(int(rng.integers(3, 30))), seg(int(rng.integers(3, 30)))
+			q = seg(n)
+			r = [seg(m), (q * (m // max(1, n) + 2))[:m], "".join(c if rng.random() < 0.6 else "ACGT"[rng.integers(4)] for c in (q + seg(m))[:m]), ("AC" * m)[:m]][variant]
+			if 3 == variant:
+				q = ("CA" * n)[:n]
+			src, dst, query = p + q + "-" * m + s, p + "-" * n + r + s, p + q + s
+			qual = [int(x) for x in rng.choice([2, 12, 23, 37, 41], size=len(query))] if variant != 1 else None
+			pairs.append((src, dst, dst.replace("-", "")))
+			recs.append((query, qual))
+	ctx, o, ids = _edge_index(pvc3, oracle_mod, pairs)
+	bb = BatchBuilder()
+	for (s, d), (query, qual) in zip(ids, recs):
+		bb.add(0, s, d, "%dM" % len(query), query, qual=qual)
+	batch = bb.build()
+	different = set()
+	for go, ge in ((0, -1), (-3, -1), (2, -1)):
+		for score_mode in (0, 1):
+			base = None
+			for tb in range(12):
+				got, stats = pvc3.project_batch(ctx, batch, go, ge, score_mode, tiebreak_mode=tb)
+				assert_results_equal(batch, got, o.batch_project(batch, go, ge, score_mode, tiebreak_mode=tb))
+				assert stats["n_failed"] == 0 and stats["n_runs"] >= len(recs)
+				if 0 == tb:
+					base = got["out_cigar"].copy()
+				elif got["out_cigar"].size != base.size or not np.array_equal(got["out_cigar"], base):
+					different.add(tb)
+	assert len(different) >= 8		# (the policies are not the same thing under different names)
+	with pytest.raises(pvc3.Error):
+		pvc3.project_batch(ctx, batch, tiebreak_mode=12)
+
+
 def test_one_large_alignment_among_many_small(pvc3, oracle_mod):
 	"""A run whose alignment needs megabytes of scratch (a 250-base query slice against a 9 kb deletion of the source
 	sequence) among many small ones: the scratch grows, but slots x waves stays within the budget instead of multiplying the

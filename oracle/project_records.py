@@ -54,7 +54,8 @@ def keep_record(rec):
 def project_records(records, in_refs, oracle, src_entries, dst_entries, mapping, out_refs, opts):
 	"""records: bamio.Record list (all input records, in order).  Returns expected SAM lines of the output records.
 
-	opts: dict(preserve=set, rname_tag, pos_tag, rnext_tag, pnext_tag, query_ranges_tag, ref_ranges_tag, rec_idx_tag, gap_open, gap_ext)."""
+	opts: dict(preserve=set, rname_tag, pos_tag, rnext_tag, pnext_tag, query_ranges_tag, ref_ranges_tag, rec_idx_tag, gap_open, gap_ext,
+	score_mode, tiebreak_mode)."""
 	ref_index = {n: i for i, (n, _, _) in enumerate(in_refs)}
 	valid = [(i, r) for i, r in enumerate(records) if keep_record(r)]
 	lines, all_ranges = [], []
@@ -65,7 +66,7 @@ def project_records(records, in_refs, oracle, src_entries, dst_entries, mapping,
 		seq = "".join(c if c in "ACGT" else "N" for c in r.seq.upper())
 		qual = None if r.qual == "*" else [min(41, ord(c) - 33) for c in r.qual]
 		dst_pos, cig, runs = oracle.project_alignment(src_entries[ref_id], dst_entries[mapping[ref_id]], src_pos, r.cigar if r.cigar != "*" else "", seq, qual=qual,
-													   gap_open=opts.get("gap_open", 0), gap_ext=opts.get("gap_ext", -1))
+													   gap_open=opts.get("gap_open", 0), gap_ext=opts.get("gap_ext", -1), score_mode=opts.get("score_mode", 0), tiebreak_mode=opts.get("tiebreak_mode", 0))
 		tags = {}
 		nm = None
 		old_oa = ""

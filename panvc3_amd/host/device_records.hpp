@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <mutex>
 #include <thread>
 
@@ -33,7 +34,8 @@ struct device_records_result
 	uint64_t matched{}, flags_not_matched{}, ref_id_missing{}, seq_missing{}, records{}, batches{}, n_runs{};
 	uint64_t blocks_in{}, blocks_refused{}, bytes_in{}, bytes_out{};
 	double inflate_kernel_s{}, deflate_kernel_s{};
-	double t_wait_read{}, t_inflate_wait{}, t_frame{}, t_project{}, t_rewrite{}, t_wait_writer{}, t_reader{}, t_writer{};
+	double t_setup{}, t_wait_read{}, t_inflate_wait{}, t_frame{}, t_project{}, t_rewrite{}, t_wait_writer{}, t_reader{}, t_writer{}, t_host_inflate{};
+	uint64_t blocks_host{};
 	std::vector <std::pair <uint32_t, uint32_t>> ranges;
 	std::vector <uint64_t> removed_tags;		// [65536]
 };
@@ -47,10 +49,17 @@ struct device_records_options
 	pvc3_params params{};
 	uint64_t header_bytes{};				// uncompressed bytes in front of the first record
 	bool want_ranges{};
-	bool host_inflate{};					// --bgzf-inflate=host: the blocks are inflated by the host's threads and uploaded
+	// Who inflates the blocks of a piece: the GPU as many as it works on at a time (a launch of that many takes as long as a launch
+	// of one) and the host's threads the rest meanwhile (0, the default); the GPU all of them (1); the host's threads all (2).
+	int inflate_mode{0};
 	unsigned threads{1};
-	std::size_t piece_compressed{std::size_t(32) << 20};		// compressed bytes read at a time
+	std::size_t piece_compressed{std::size_t(48) << 20};		// compressed bytes read at a time at most
 	std::size_t piece_stream{std::size_t(160) << 20};		// uncompressed bytes of a piece at most
+	uint32_t gpu_blocks{0};									// blocks of a piece that go to the GPU in mode 0; 0: as many as it works on at a time
+	uint32_t piece_blocks{0};								// BGZF blocks of a piece at most; 0: twice what the GPU inflates at a time (the GPU's share and the host's)
+	// the two codecs, made ahead of time by the caller (they are page-locked memory, which takes a while to get); null: made here
+	std::function <pvc3_bgzf_inflater *()> take_inflater;
+	std::function <pvc3_bgzf_dev *()> take_deflater;
 	std::function <void(void const *, std::size_t)> write_blocks;		// BGZF blocks to the output file, in order
 	std::function <void(uint64_t)> progress;					// records so far (status lines)
 };
@@ -70,6 +79,21 @@ inline void zlib_inflate_block(uint8_t const *src, std::size_t in_len, uint8_t *
 
 }
 
+// What the two codecs are made for, from the sizes of a piece (so that a caller can make them ahead of time).
+struct device_records_sizes
+{
+	std::size_t max_in{};
+	uint32_t max_blocks_in{}, max_blocks_out{};
+	static device_records_sizes of(std::size_t piece_compressed, std::size_t piece_stream)
+	{
+		device_records_sizes s;
+		s.max_in = piece_compressed + (std::size_t(1) << 17);		// what a piece left over of its last block + the next read
+		s.max_blocks_in = (uint32_t) (s.max_in / 28 / 8 + 4096);
+		s.max_blocks_out = (uint32_t) ((piece_stream + piece_stream / 4) / PVC3_BGZF_BLOCK + 64);		// the records grow by their new tags: a quarter is plenty for records of a hundred bases and more
+		return s;
+	}
+};
+
 inline device_records_result run_device_records(device_records_options const &opt)
 {
 	device_records_result res;
@@ -80,25 +104,37 @@ inline device_records_result run_device_records(device_records_options const &op
 	auto rec_check = [](int rc, char const *what) { if (rc) throw io_error(std::string(what) + ": " + pvc3_last_error()); };
 
 	constexpr unsigned IN_SLOTS = PVC3_RECORDS_SLOTS, OUT_SLOTS = 2;
-	std::size_t const max_in = opt.piece_compressed + (std::size_t(1) << 17);		// what a piece left over of its last block + the next read
-	uint32_t const max_blocks_in = (uint32_t) (max_in / 28 / 8 + 4096);
-	uint32_t const max_blocks_out = (uint32_t) ((opt.piece_stream + opt.piece_stream / 2) / PVC3_BGZF_BLOCK + 64);
+	auto const t_begin = now();
+	device_records_sizes const sz = device_records_sizes::of(opt.piece_compressed, opt.piece_stream);
+	std::size_t const max_in = sz.max_in;
+	uint32_t const max_blocks_in = sz.max_blocks_in;
 
 	// ---- the three objects on the GPU ---------------------------------------------------------------------------------------------
 	pvc3_bgzf_inflater *inflater{};
 	pvc3_bgzf_dev *deflater{};
 	pvc3_records *records{};
+	uint8_t *staging[IN_SLOTS]{};		// page-locked: what the host's threads inflate of a piece, one behind the other
 	struct cleanup
 	{
-		pvc3_bgzf_inflater *&i; pvc3_bgzf_dev *&d; pvc3_records *&r;
-		~cleanup() { if (r) pvc3_records_destroy(r); if (d) pvc3_bgzf_dev_destroy(d); if (i) pvc3_bgzf_inflater_destroy(i); }
-	} cleanup_guard{inflater, deflater, records};
-	bgzf_check(pvc3_bgzf_inflater_create(opt.device, max_in, opt.host_inflate ? opt.piece_stream : 1, max_blocks_in, IN_SLOTS, &inflater), "pvc3_bgzf_inflater_create");
-	bgzf_check(pvc3_bgzf_dev_create(opt.device, max_blocks_out, OUT_SLOTS, &deflater), "pvc3_bgzf_dev_create");
+		pvc3_bgzf_inflater *&i; pvc3_bgzf_dev *&d; pvc3_records *&r; uint8_t *(&st)[IN_SLOTS];
+		~cleanup() { if (r) pvc3_records_destroy(r); if (d) pvc3_bgzf_dev_destroy(d); if (i) pvc3_bgzf_inflater_destroy(i); for (auto *p : st) if (p) pvc3_host_free(p); }
+	} cleanup_guard{inflater, deflater, records, staging};
+	if (opt.take_inflater) inflater = opt.take_inflater();
+	else bgzf_check(pvc3_bgzf_inflater_create(opt.device, max_in, 1, max_blocks_in, IN_SLOTS, &inflater), "pvc3_bgzf_inflater_create");
+	if (opt.take_deflater) deflater = opt.take_deflater();
+	else bgzf_check(pvc3_bgzf_dev_create(opt.device, sz.max_blocks_out, OUT_SLOTS, &deflater), "pvc3_bgzf_dev_create");
+	if (!inflater || !deflater) throw io_error("the BGZF codecs on the GPU could not be made");
 	pvc3_records_config cfg = opt.config;
 	cfg.max_stream_bytes = opt.piece_stream;
 	rec_check(pvc3_records_create(opt.ctx, &cfg, &records), "pvc3_records_create");
 	uint64_t const out_capacity = pvc3_bgzf_dev_capacity(deflater);
+	uint32_t const gpu_at_a_time = opt.gpu_blocks ? opt.gpu_blocks : std::max <uint32_t>(1, pvc3_bgzf_inflater_blocks_in_flight(inflater));
+	uint32_t const piece_blocks = std::min <uint32_t>(max_blocks_in, opt.piece_blocks ? opt.piece_blocks : ((0 == opt.inflate_mode) ? 2 * gpu_at_a_time : max_blocks_in));
+	// the host's share of a piece at most (blocks of 64 KiB at most)
+	std::size_t const staging_bytes = (1 == opt.inflate_mode) ? 0 : std::min <std::size_t>(opt.piece_stream, (std::size_t) ((0 == opt.inflate_mode) ? (piece_blocks > gpu_at_a_time ? piece_blocks - gpu_at_a_time : 0) : piece_blocks) * 65536);
+	if (staging_bytes)
+		for (auto &p : staging) { void *q{}; rec_check(pvc3_host_alloc(staging_bytes, &q), "pvc3_host_alloc"); p = (uint8_t *) q; }
+	res.t_setup = since(t_begin);
 
 	// ---- the reader ------------------------------------------------------------------------------------------------------------------
 	struct piece
@@ -109,6 +145,8 @@ inline device_records_result run_device_records(device_records_options const &op
 		std::vector <uint64_t> block_off;		// [n_blocks + 1] where the blocks' bytes begin in the stream buffer, from its front
 		std::vector <uint32_t> crc;
 		bool last{};
+		uint32_t n_gpu{};						// the first n_gpu blocks are the GPU's, the rest the host's threads'
+		std::future <double> host_part;			// (its seconds)
 	};
 	std::mutex m;
 	std::condition_variable cv;
@@ -155,7 +193,7 @@ inline device_records_result run_device_records(device_records_options const &op
 					// the whole blocks at hand, as many as the stream buffer has room for
 					std::size_t off = 0, out = 0;
 					p.n_blocks = 0; p.block_off.clear(); p.crc.clear();
-					while (p.n_blocks < max_blocks_in)
+					while (p.n_blocks < piece_blocks)
 					{
 						std::size_t data_off = 0;
 						std::size_t const bs = byte_reader::bgzf_block_size(in + off, have - off, data_off);
@@ -251,45 +289,75 @@ inline device_records_result run_device_records(device_records_options const &op
 
 	auto start_inflate = [&](piece &p) {
 		if (0 == p.n_blocks) return;
-		if (opt.host_inflate)
+		p.n_gpu = (2 == opt.inflate_mode) ? 0 : ((1 == opt.inflate_mode) ? p.n_blocks : std::min(p.n_blocks, gpu_at_a_time));
+		pvc3_bgzf_block const *blocks = pvc3_bgzf_inflater_blocks(inflater, p.slot);
+		if (p.n_gpu)
 		{
-			// the host's threads inflate into the inflater's page-locked output, which is uploaded as a whole
-			uint8_t const *in = pvc3_bgzf_inflater_input(inflater, p.slot);
-			uint8_t *out = pvc3_bgzf_inflater_output(inflater, p.slot);
-			pvc3_bgzf_block const *blocks = pvc3_bgzf_inflater_blocks(inflater, p.slot);
-			parallel_for(p.n_blocks, opt.threads, [&](std::size_t i) {
-				static thread_local fast_inflater quick;
-				pvc3_bgzf_block const &b = blocks[i];
-				if (!(quick.inflate(in + b.in_off, b.in_len, out + b.out_off, b.out_len) && fast_crc32(0, out + b.out_off, b.out_len) == p.crc[i]))
-				{
-					detail::zlib_inflate_block(in + b.in_off, b.in_len, out + b.out_off, b.out_len);
-					if (fast_crc32(0, out + b.out_off, b.out_len) != p.crc[i]) throw io_error("BGZF block checksum mismatch");
-				}
-			});
-			rec_check(pvc3_records_upload(records, p.slot, 0, out, p.out_bytes), "pvc3_records_upload");
-			return;
+			std::size_t const in_gpu = (p.n_gpu < p.n_blocks) ? (std::size_t) blocks[p.n_gpu].in_off : p.in_bytes;
+			bgzf_check(pvc3_bgzf_inflater_submit_device(inflater, p.slot, p.n_gpu, in_gpu, (uint8_t *) base[p.slot] + front, opt.piece_stream), "pvc3_bgzf_inflater_submit_device");
 		}
-		bgzf_check(pvc3_bgzf_inflater_submit_device(inflater, p.slot, p.n_blocks, p.in_bytes, (uint8_t *) base[p.slot] + front, opt.piece_stream), "pvc3_bgzf_inflater_submit_device");
+		if (p.n_gpu < p.n_blocks)
+		{
+			// the rest on the host's threads meanwhile, into page-locked memory: uploaded in one piece when this thread comes to the piece
+			uint8_t const *in = pvc3_bgzf_inflater_input(inflater, p.slot);
+			uint8_t *out = staging[p.slot];
+			uint64_t const out0 = blocks[p.n_gpu].out_off;
+			if (p.out_bytes - out0 > staging_bytes) throw io_error("the host's share of a piece exceeds its staging buffer");
+			uint32_t const first_host = p.n_gpu, n_host = p.n_blocks - p.n_gpu;
+			uint32_t const *crc = p.crc.data();		// (the vector's storage moves along with the piece)
+			unsigned const threads = opt.threads;
+			p.host_part = std::async(std::launch::async, [in, out, out0, blocks, first_host, n_host, crc, threads]() -> double {
+				auto const t0 = std::chrono::steady_clock::now();
+				parallel_for(n_host, threads, [&](std::size_t k) {
+					static thread_local fast_inflater quick;
+					pvc3_bgzf_block const &b = blocks[first_host + k];
+					uint8_t *dst = out + (b.out_off - out0);
+					uint32_t const want = crc[first_host + k];
+					if (!(quick.inflate(in + b.in_off, b.in_len, dst, b.out_len) && fast_crc32(0, dst, b.out_len) == want))
+					{
+						detail::zlib_inflate_block(in + b.in_off, b.in_len, dst, b.out_len);
+						if (fast_crc32(0, dst, b.out_len) != want) throw io_error("BGZF block checksum mismatch");
+					}
+				});
+				return std::chrono::duration <double>(std::chrono::steady_clock::now() - t0).count();
+			});
+			res.blocks_host += n_host;
+		}
 	};
 	auto finish_inflate = [&](piece &p) {
-		if (0 == p.n_blocks || opt.host_inflate) return;
-		uint32_t const *status{}, *crc{};
-		float ms = 0;
-		bgzf_check(pvc3_bgzf_inflater_wait_device(inflater, p.slot, &status, &crc, &ms), "pvc3_bgzf_inflater_wait_device");
-		res.inflate_kernel_s += 1e-3 * ms;
-		// whatever the GPU refused, or whose checksum is not the file's: inflated here (zlib decides what is corrupt) and put in its place
-		uint8_t const *in = pvc3_bgzf_inflater_input(inflater, p.slot);
+		if (0 == p.n_blocks) return;
 		pvc3_bgzf_block const *blocks = pvc3_bgzf_inflater_blocks(inflater, p.slot);
-		for (uint32_t i = 0; i < p.n_blocks; ++i)
+		std::exception_ptr host_error;
+		if (p.host_part.valid())
 		{
-			if (0 == status[i] && crc[i] == p.crc[i]) continue;
-			++res.blocks_refused;
-			pvc3_bgzf_block const &b = blocks[i];
-			scratch.resize(b.out_len);
-			detail::zlib_inflate_block(in + b.in_off, b.in_len, scratch.data(), b.out_len);
-			if (fast_crc32(0, scratch.data(), b.out_len) != p.crc[i]) throw io_error("BGZF block checksum mismatch");
-			rec_check(pvc3_records_upload(records, p.slot, b.out_off, scratch.data(), b.out_len), "pvc3_records_upload");
+			try { res.t_host_inflate += p.host_part.get(); } catch (...) { host_error = std::current_exception(); }
+			if (!host_error)
+			{
+				uint64_t const out0 = blocks[p.n_gpu].out_off;
+				rec_check(pvc3_records_upload(records, p.slot, out0, staging[p.slot], p.out_bytes - out0), "pvc3_records_upload");
+			}
 		}
+		if (p.n_gpu)
+		{
+			uint32_t const *status{}, *crc{};
+			float ms = 0;
+			bgzf_check(pvc3_bgzf_inflater_wait_device(inflater, p.slot, &status, &crc, &ms), "pvc3_bgzf_inflater_wait_device");		// (also after an error on the host's side: the slot must not stay busy)
+			if (host_error) std::rethrow_exception(host_error);
+			res.inflate_kernel_s += 1e-3 * ms;
+			// whatever the GPU refused, or whose checksum is not the file's: inflated here (zlib decides what is corrupt) and put in its place
+			uint8_t const *in = pvc3_bgzf_inflater_input(inflater, p.slot);
+			for (uint32_t i = 0; i < p.n_gpu; ++i)
+			{
+				if (0 == status[i] && crc[i] == p.crc[i]) continue;
+				++res.blocks_refused;
+				pvc3_bgzf_block const &b = blocks[i];
+				scratch.resize(b.out_len);
+				detail::zlib_inflate_block(in + b.in_off, b.in_len, scratch.data(), b.out_len);
+				if (fast_crc32(0, scratch.data(), b.out_len) != p.crc[i]) throw io_error("BGZF block checksum mismatch");
+				rec_check(pvc3_records_upload(records, p.slot, b.out_off, scratch.data(), b.out_len), "pvc3_records_upload");
+			}
+		}
+		if (host_error) std::rethrow_exception(host_error);
 	};
 
 	for (;;)

@@ -112,6 +112,7 @@ struct options
 	std::vector <std::string> preserve_tags;
 	std::string rname_tag{"XR"}, pos_tag{"XP"}, rnext_tag{"YR"}, pnext_tag{"YP"}, query_ranges_tag{"XB"}, ref_ranges_tag{"YB"}, rec_idx_tag;
 	int gap_open{0}, gap_ext{-1}, compression_level{-1};
+	int score_mode{PVC3_SCORE_FP64}, tiebreak_mode{0};		// --realign-score-type, --realign-tiebreak: what seqan3 does inside align_pairwise and no reference test pins (tests/parity_kit/)
 	long status_interval{5};			// --status-output-interval, minutes; 0 disables
 	std::vector <int> devices{0};		// --device / --devices: batches go to the GPUs in turn, output stays in input order
 	uint64_t batch_size{UINT64_C(1) << 18};		// records per GPU batch: small enough for reading, projecting and writing of consecutive batches to overlap
@@ -171,10 +172,16 @@ void usage()
 		"      --bgzf-deflate=gpu|host          where the built-in encoder runs: on the first GPU (default) or on the host threads\n"
 		"      --bgzf-inflate=gpu|host          where the blocks of BGZF input (BAM, bgzip'ed SAM) are inflated: on the host threads (default)\n"
 		"                                       or on the first GPU once it is up (for hosts with few cores: 7 GB/s)\n"
+		"      --realign-score-type=double|int32, --realign-tiebreak=0..11\n"
+		"                                       the two things seqan3 decides inside the realignment and no test of the reference pins: the\n"
+		"                                       score type (default double) and which of several equally good alignments is returned\n"
+		"                                       (default 0; include/pvc3.h, tests/parity_kit/README.md)\n"
 		"      --record-path=gpu|host           where the records are cut out of the input and written anew: on the GPU (default for a BAM file\n"
 		"                                       in and BAM out on one GPU: the blocks are inflated, the records found, projected, rewritten\n"
-		"                                       and compressed without leaving it; --bgzf-inflate=host then only moves the inflating) or by\n"
-		"                                       the host's threads (every other input and output)\n";
+		"                                       and compressed without leaving it; there the GPU inflates as many blocks of a piece of the\n"
+		"                                       file as it works on at a time and the host's threads the rest meanwhile, --bgzf-inflate=gpu\n"
+		"                                       gives it all blocks and --bgzf-inflate=host none) or by the host's threads (every other\n"
+		"                                       input and output)\n";
 }
 
 // process_headers (project_alignments.cc:1092-1253)
@@ -317,7 +324,7 @@ int main(int argc, char **argv)
 		{"gap-opening-cost", required_argument, nullptr, 'g'}, {"gap-extension-cost", required_argument, nullptr, 'e'},
 		{"print-invocation", no_argument, nullptr, 1009}, {"print-pid", no_argument, nullptr, 1010}, {"debugging-output", no_argument, nullptr, 1011},
 		{"device", required_argument, nullptr, 1012}, {"batch-size", required_argument, nullptr, 1013}, {"io-only", no_argument, nullptr, 1014}, {"threads", required_argument, nullptr, 1015},
-		{"devices", required_argument, nullptr, 1016}, {"compression-level", required_argument, nullptr, 1017}, {"bgzf-deflate", required_argument, nullptr, 1018}, {"bgzf-inflate", required_argument, nullptr, 1019}, {"record-path", required_argument, nullptr, 1020},
+		{"devices", required_argument, nullptr, 1016}, {"compression-level", required_argument, nullptr, 1017}, {"bgzf-deflate", required_argument, nullptr, 1018}, {"bgzf-inflate", required_argument, nullptr, 1019}, {"record-path", required_argument, nullptr, 1020}, {"realign-score-type", required_argument, nullptr, 1021}, {"realign-tiebreak", required_argument, nullptr, 1022},
 		{"help", no_argument, nullptr, 'h'}, {"version", no_argument, nullptr, 'V'}, {nullptr, 0, nullptr, 0}};
 	int c;
 	while (-1 != (c = getopt_long(argc, argv, "a:Bm:r:d:s:u:o:bl:t:qg:e:hV", long_opts, nullptr)))
@@ -374,6 +381,15 @@ int main(int argc, char **argv)
 				if (0 == std::strcmp(optarg, "gpu")) opt.record_path = 1;
 				else if (0 == std::strcmp(optarg, "host")) opt.record_path = 0;
 				else die("--record-path expects gpu or host");
+				break;
+			case 1021:
+				if (0 == std::strcmp(optarg, "double")) opt.score_mode = PVC3_SCORE_FP64;
+				else if (0 == std::strcmp(optarg, "int32")) opt.score_mode = PVC3_SCORE_INT32_TRUNC;
+				else die("--realign-score-type expects double or int32");
+				break;
+			case 1022:
+				opt.tiebreak_mode = std::atoi(optarg);
+				if (opt.tiebreak_mode < 0 || opt.tiebreak_mode >= PVC3_TIEBREAK_MODES) die("--realign-tiebreak expects 0 .. 11");
 				break;
 			case 1013: opt.batch_size = std::strtoull(optarg, nullptr, 10); break;
 			case 1014: opt.io_only = true; break;
@@ -451,6 +467,7 @@ int main(int argc, char **argv)
 		double t_startup = 0.0, t_contexts_up = 0.0, t_deflater_up = 0.0, t_inflater_up = 0.0, t_files_read = 0.0, inflater_kernel_s = 0.0;
 		uint64_t inflater_groups = 0;
 		bool aux_codecs = true;		// the reader's GPU inflater and the writer's GPU compressor (not for the record path on the GPU, which has its own)
+		std::function <void()> after_contexts;		// run on the contexts' thread once they are up (the record path on the GPU makes its codecs there)
 		auto prepare_devices = [&]() {
 			// The GPU contexts come up on a thread of their own (the HIP runtime takes a few tenths of a second to start) while the
 			// index file and the reference are read.
@@ -463,6 +480,7 @@ int main(int argc, char **argv)
 					made.push_back(ctx);
 				}
 				t_contexts_up = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+				if (after_contexts) after_contexts();
 				// The BGZF compressor's page-locked staging takes a while to allocate and is not needed before the first batch has been
 				// rewritten: it comes up on a thread of its own, behind the contexts (the HIP runtime is up by now).
 				// The inflater of the input's blocks likewise; the reader, which has been inflating on the host threads since the process
@@ -545,8 +563,24 @@ int main(int argc, char **argv)
 		{
 			uint64_t const header_bytes = reader.bam_header_bytes();
 			reader.release();		// the header has been read: the file is read anew, raw, by the record path's own reader
-			bool const want_host_inflate = opt.inflate_given && !opt.gpu_inflate;
 			aux_codecs = false;
+			device_records_options dro;
+			dro.inflate_mode = !opt.inflate_given ? 0 : (opt.gpu_inflate ? 1 : 2);
+			if (char const *e = std::getenv("PVC3_BGZF_CHUNK")) { std::size_t const v = (std::size_t) std::strtoull(e, nullptr, 10); if (v >= 1024) dro.piece_compressed = v; }
+			if (char const *e = std::getenv("PVC3_RECORDS_STREAM")) { std::size_t const v = (std::size_t) std::strtoull(e, nullptr, 10); if (v >= 65536) dro.piece_stream = v; }
+			if (char const *e = std::getenv("PVC3_RECORDS_BLOCKS")) { dro.piece_blocks = (uint32_t) std::max(1, std::atoi(e)); }
+			if (char const *e = std::getenv("PVC3_RECORDS_GPU_BLOCKS")) { dro.gpu_blocks = (uint32_t) std::max(1, std::atoi(e)); }		// (tests: a host's share in small files)
+			// The two codecs are mostly page-locked memory, which takes the runtime a tenth of a second or two to hand out: they are made
+			// on threads of their own as soon as the GPU is up, while the index file and the FASTA are read.
+			device_records_sizes const sizes = device_records_sizes::of(dro.piece_compressed, dro.piece_stream);
+			std::future <pvc3_bgzf_inflater *> records_inflater;
+			std::future <pvc3_bgzf_dev *> records_deflater;
+			std::string inflater_message, deflater_message;
+			int const first_device = opt.devices.front();
+			after_contexts = [&]() {
+				records_inflater = std::async(std::launch::async, [&]() { pvc3_bgzf_inflater *h{}; if (pvc3_bgzf_inflater_create(first_device, sizes.max_in, 1, sizes.max_blocks_in, PVC3_RECORDS_SLOTS, &h)) inflater_message = pvc3_bgzf_last_error(); return h; });
+				records_deflater = std::async(std::launch::async, [&]() { pvc3_bgzf_dev *h{}; if (pvc3_bgzf_dev_create(first_device, sizes.max_blocks_out, 2, &h)) deflater_message = pvc3_bgzf_last_error(); return h; });
+			};
 			prepare_devices();
 			check(pvc3_context_set_option(device_contexts[0], "window_read_length", 150), "pvc3_context_set_option");
 			double const t_prepared = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
@@ -564,12 +598,11 @@ int main(int argc, char **argv)
 			if (pvc3_context_upload_index(device_contexts[0], index)) die(std::string("pvc3_context_upload_index: ") + pvc3_last_error());
 			t_startup = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
 
-			device_records_options dro;
 			dro.path = opt.alignments; dro.device = opt.devices.front(); dro.ctx = device_contexts[0];
-			dro.params = pvc3_params{opt.gap_open, opt.gap_ext, PVC3_SCORE_FP64, 0};
-			dro.header_bytes = header_bytes; dro.want_ranges = nullptr != opt.realigned_ranges; dro.host_inflate = want_host_inflate; dro.threads = opt.threads;
-			if (char const *e = std::getenv("PVC3_BGZF_CHUNK")) { std::size_t const v = (std::size_t) std::strtoull(e, nullptr, 10); if (v >= 1024) dro.piece_compressed = v; }
-			if (char const *e = std::getenv("PVC3_RECORDS_STREAM")) { std::size_t const v = (std::size_t) std::strtoull(e, nullptr, 10); if (v >= 65536) dro.piece_stream = v; }
+			dro.take_inflater = [&]() { pvc3_bgzf_inflater *h = records_inflater.get(); if (!h) die("pvc3_bgzf_inflater_create: " + inflater_message); return h; };
+			dro.take_deflater = [&]() { pvc3_bgzf_dev *h = records_deflater.get(); if (!h) die("pvc3_bgzf_dev_create: " + deflater_message); return h; };
+			dro.params = pvc3_params{opt.gap_open, opt.gap_ext, opt.score_mode, opt.tiebreak_mode};
+			dro.header_bytes = header_bytes; dro.want_ranges = nullptr != opt.realigned_ranges; dro.threads = opt.threads;
 			std::vector <uint32_t> r_dst(in_header.refs.size()), name_off(in_header.refs.size() + 1, 0);
 			std::vector <int32_t> r_out(in_header.refs.size());
 			std::string names;
@@ -624,9 +657,9 @@ int main(int argc, char **argv)
 			std::cerr << "\tRe-aligned ranges:     " << dr.n_runs << '\n';
 			if (opt.debugging_output)
 			{
-				std::cerr << "\tRecord path on the GPU: " << dr.records << " records in " << dr.batches << " pieces; " << dr.blocks_in << " blocks in (" << dr.blocks_refused << " inflated on the host instead), "
+				std::cerr << "\tRecord path on the GPU: " << dr.records << " records in " << dr.batches << " pieces; " << dr.blocks_in << " blocks in (" << dr.blocks_host << " of them the host's share, " << dr.blocks_refused << " inflated on the host instead), "
 						  << dr.bytes_in << " bytes of records in, " << dr.bytes_out << " bytes of file out; kernels: inflate " << dr.inflate_kernel_s << " s, deflate " << dr.deflate_kernel_s << " s\n";
-				std::cerr << "\tStages (s): start-up " << t_startup << ", reader thread " << dr.t_reader << ", main: waiting for it " << dr.t_wait_read << ", waiting for the inflater " << dr.t_inflate_wait
+				std::cerr << "\tStages (s): start-up " << t_startup << ", reader thread " << dr.t_reader << ", codecs and buffers " << dr.t_setup << ", main: waiting for the reader " << dr.t_wait_read << ", waiting for the inflaters " << dr.t_inflate_wait << " (host threads at work " << dr.t_host_inflate << ")"
 						  << ", records found and scattered " << dr.t_frame << ", projected " << dr.t_project << ", rewritten " << dr.t_rewrite << ", waiting for the writer " << dr.t_wait_writer << ", writer thread " << dr.t_writer << '\n';
 				std::cerr << "\tTimeline (s): GPU contexts " << t_contexts_up << ", index file and FASTA " << t_files_read << ", both " << t_prepared << ", index on the GPUs (start-up done) " << t_startup
 						  << ", last batch rewritten " << t_batches_done << ", output closed " << t_closed << "; wall clock at the start " << std::fixed << epoch_start << ", now "
@@ -688,7 +721,7 @@ int main(int argc, char **argv)
 		std::map <uint16_t, uint64_t> removed_tag_counts;
 		std::vector <std::pair <uint32_t, uint32_t>> realigned_ranges;
 		uint64_t n_realigned_ranges = 0;
-		pvc3_params const params{opt.gap_open, opt.gap_ext, PVC3_SCORE_FP64, 0};
+		pvc3_params const params{opt.gap_open, opt.gap_ext, opt.score_mode, opt.tiebreak_mode};
 
 		// --debugging-output: where the wall clock goes (seconds, summed over the batches)
 		struct stage_times { double read{}, wait_read{}, fill{}, gpu{}, rewrite{}, wait_write{}, write{}; } tm;

@@ -427,7 +427,8 @@ def test_project_alignments_cli_matches_restatement(tools, built_index, oracle_m
 		want_bytes = records_behind_header(tmp_path / "host_path.bam")
 		want_ranges = open(tmp_path / "ranges_dev.tsv").read()
 		assert b"Record path on the GPU" not in ph.stderr
-		for env, extra in ((None, []), ({"PVC3_BGZF_CHUNK": "3000", "PVC3_RECORDS_STREAM": "65536"}, []), ({"PVC3_BGZF_CHUNK": "70000"}, ["--record-path=gpu"]), (None, ["--bgzf-inflate=host"])):
+		for env, extra in ((None, []), ({"PVC3_BGZF_CHUNK": "3000", "PVC3_RECORDS_STREAM": "65536"}, []), ({"PVC3_BGZF_CHUNK": "70000"}, ["--record-path=gpu", "--bgzf-inflate=gpu"]), (None, ["--bgzf-inflate=host"]),
+						   ({"PVC3_RECORDS_GPU_BLOCKS": "3", "PVC3_RECORDS_BLOCKS": "7"}, []), ({"PVC3_RECORDS_GPU_BLOCKS": "2", "PVC3_BGZF_CHUNK": "9000"}, [])):		# (the last two: the host's threads inflate a share of every piece)
 			pd = _run(base_cmd + ["-a", name, "-o", "dev_path.bam"] + extra, cwd=tmp_path, env=env)
 			assert b"Record path on the GPU" in pd.stderr, (name, env, extra)
 			got_bytes = records_behind_header(tmp_path / "dev_path.bam")

@@ -64,7 +64,7 @@ def parse_args(argv=None):
 	ap.add_argument("--skip-host-buffers", action="store_true", help="leave out the PCIe-inclusive legs (their smaller launches would enter rocprofv3's per-kernel averages)")
 	ap.add_argument("--sorted", action="store_true", help="sort the records by (source entry, position) like a coordinate-sorted BAM (secondary data point; the default is the unsorted worst case)")
 	ap.add_argument("--skip-sorted-leg", action="store_true", help="leave out the second measurement of the same records in coordinate order (the order of a sorted BAM, which is what the workflows feed project_alignments)")
-	ap.add_argument("--other-configs", default="C5,C3G", help="further BASELINE.json configurations measured at full size after the main one (a few steps each, never part of `value`): other_configs in the JSON line; empty disables")
+	ap.add_argument("--other-configs", default="C5,C3G,C3:position_windows=0", help="further configurations measured at full size after the main one (a few steps each, never part of `value`): other_configs in the JSON line; CONFIG or CONFIG:option=value,... (pvc3_context_set_option; C3:position_windows=0 is the index without position windows, i.e. k_project_fast_probes); empty disables")
 	ap.add_argument("--other-steps", type=int, default=5)
 	ap.add_argument("--setup-only", action="store_true", help="run the set-up of every rank (shared genome, this rank's reads, the host side of the index), print its seconds and peak resident set, and stop before anything touches a GPU (ranks then meet over gloo): rehearsal of the N-rank launch on a box without N GPUs")
 	ap.add_argument("--no-build", action="store_true", help="never compile: exit non-zero if a native library is stale (use under rocprofv3, after `python3 -m panvc3_amd.build`)")
@@ -133,12 +133,24 @@ def cli_end_to_end(n_records):
 		n_large = cli_e2e.write_repeated(P, os.path.join(work, "in_large.bam"), 4 * max(1, n_records // unique))
 		cmd_large = cli_e2e.project_command(P, alignments="in_large.bam")
 		dt_large = min(cli_e2e.timed(cmd_large, cwd=work)[0] for _ in range(2))
+		# the records on the host's threads instead (--record-path=host: round 3's path, the comparator of the GPU's record path)
+		dt_host, stages_host = min((cli_e2e.timed(cmd + ["--record-path=host"], cwd=work) for _ in range(2)), key=lambda r: r[0])
+		dt_host_large = min(cli_e2e.timed(cmd_large + ["--record-path=host"], cwd=work)[0] for _ in range(2))
+		# sixteen times the records: what a run costs whatever its size no longer decides
+		n_huge = cli_e2e.write_repeated(P, os.path.join(work, "in_huge.bam"), 16 * max(1, n_records // unique))
+		os.remove(os.path.join(work, "in_large.bam"))
+		dt_huge = cli_e2e.timed(cli_e2e.project_command(P, alignments="in_huge.bam"), cwd=work)[0]
 		return {
 			"value": P["n"] / dt, "unit": "records/s", "records": P["n"], "seconds": dt, "seconds_without_records": t_empty,
 			"cores": usable_cpus(), "stages": stages,
 			"large": {"records": n_large, "seconds": dt_large, "value": n_large / dt_large},
-			"what": "bin/panvc3_project_alignments, BAM file in, BAM file out (BGZF blocks compressed on the GPU), wall clock of the whole process, "
-					"best of 3 (large: best of 2); seconds_without_records: the same command on an input without records (index file, FASTA, GPU start-up)",
+			"huge": {"records": n_huge, "seconds": dt_huge, "value": n_huge / dt_huge},
+			"marginal": {"value": (n_large - P["n"]) / max(1e-9, dt_large - dt), "unit": "records/s", "what": "(records of large - records of the small run) / (their seconds' difference)"},
+			"record_path_host": {"seconds": dt_host, "value": P["n"] / dt_host, "stages": stages_host, "large": {"seconds": dt_host_large, "value": n_large / dt_host_large},
+								 "marginal": (n_large - P["n"]) / max(1e-9, dt_host_large - dt_host)},
+			"what": "bin/panvc3_project_alignments, BAM file in, BAM file out, wall clock of the whole process, best of 3 (large: best of 2, huge: one run): the records are "
+					"inflated, found, projected, written anew and compressed on the GPU (--record-path=gpu, the default; the host's threads inflate a share of the blocks); "
+					"record_path_host: the same with the records on the host's threads; seconds_without_records: the same command on an input without records (index file, FASTA, GPU start-up)",
 		}
 	finally:
 		os.chdir(here)
@@ -161,7 +173,7 @@ def traffic_for(config, scale):
 	return None, None
 
 
-def measure_other_config(config, args, local_rank, threads, cores):
+def measure_other_config(config, args, local_rank, threads, cores, options=()):
 	"""One more BASELINE.json configuration at full size on this GPU: ms per step, kernel times, the whole step against the HBM
 	roofline, and a sample of the results compared with the oracle.  Everything it makes is released again."""
 	import numpy as np
@@ -180,6 +192,8 @@ def measure_other_config(config, args, local_rank, threads, cores):
 	genome.fill_index(index)
 	ctx = panvc3_amd.Context(local_rank)
 	ctx.set_option("window_read_length", int(rp.read_len))
+	for k, v in options:
+		ctx.set_option(k, int(v))
 	ctx.upload_index(index)
 	ctx.set_timing(True)
 	db = panvc3_amd.DeviceBatch(ctx, batch)
@@ -514,11 +528,20 @@ def main():
 		if world == 1 and not args.skip_host_buffers and args.other_configs:
 			batch = reads = genome = index = None
 			result["other_configs"] = {}
-			for oc in [c.strip().upper() for c in args.other_configs.split(",") if c.strip()]:
-				if oc == config:
+			specs, cur = [], None
+			for piece in [c.strip() for c in args.other_configs.split(",") if c.strip()]:		# "C5", "C3:position_windows=0" (further options of the same configuration follow as key=value)
+				if "=" in piece and ":" not in piece and cur is not None:
+					cur[1].append(tuple(piece.split("=", 1)))
+					continue
+				name, _, opt = piece.partition(":")
+				cur = [name.upper(), [tuple(opt.split("=", 1))] if opt else []]
+				specs.append(cur)
+			for name, options in specs:
+				oc = name + "".join(":%s=%s" % kv for kv in options)
+				if name == config and not options:
 					continue
 				try:
-					result["other_configs"][oc] = measure_other_config(oc, args, local_rank, threads, cores)
+					result["other_configs"][oc] = measure_other_config(name, args, local_rank, threads, cores, options)
 					log("%s: %.2f ms per step" % (oc, result["other_configs"][oc]["ms_per_step"]))
 				except SystemExit:
 					raise

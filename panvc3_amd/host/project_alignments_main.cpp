@@ -992,7 +992,7 @@ int main(int argc, char **argv)
 			{
 				// Capacities from the first batch, with room: twice its CIGAR operations and SEQ bytes per record.
 				pipe_caps.max_records = std::max <uint64_t>(n, opt.batch_size + 4);
-				pipe_caps.max_cigar_ops = std::max <uint64_t>(2 * in.cigar_off[n], 8 * pipe_caps.max_records) * pipe_caps.max_records / std::max <uint64_t>(n, 1) + 1024;
+				pipe_caps.max_cigar_ops = std::max <uint64_t>(2 * in.cigar_off[n] * pipe_caps.max_records / std::max <uint64_t>(n, 1), 8 * pipe_caps.max_records) + 1024;		// (the first batch's operations per record, scaled to a full batch — not the full batch's floor scaled again: a first batch of a dozen records asked for 180 GB)
 				pipe_caps.max_seq_bytes = 2 * in.seq_off[n] * pipe_caps.max_records / std::max <uint64_t>(n, 1) + 4096;
 				pipe_caps.max_qual_bytes = 0;		// QUAL stays in the page-locked arrays and is fetched for the realigned records only
 				pipe_caps.depth = 2;

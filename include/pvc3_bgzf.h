@@ -92,7 +92,7 @@ PVC3_BGZF_API int pvc3_bgzf_inflater_wait_device(pvc3_bgzf_inflater *h, uint32_t
 /* The device-resident form of the compressor: the uncompressed bytes are written by kernels of the caller straight into the
  * compressor's device input (byte o of the stream at (o / PVC3_BGZF_BLOCK) * PVC3_BGZF_IN_STRIDE + PVC3_BGZF_IN_PAD + o %
  * PVC3_BGZF_BLOCK of pvc3_bgzf_dev_input(h, slot)), and what comes back is the bytes of the BGZF FILE: every block with its gzip /
- * BC header, stream, CRC-32 (computed on the device) and ISIZE, one behind the other, in page-locked memory.
+ * BC header, stream, CRC-32 (computed on the device) and ISIZE, one behind the other.
  * pvc3_bgzf_dev_submit may only be called when the kernels that wrote the slot's input have finished. */
 typedef struct pvc3_bgzf_dev pvc3_bgzf_dev;
 PVC3_BGZF_API int pvc3_bgzf_dev_create(int device, uint32_t max_blocks, uint32_t n_slots, pvc3_bgzf_dev **out);
@@ -100,7 +100,11 @@ PVC3_BGZF_API void pvc3_bgzf_dev_destroy(pvc3_bgzf_dev *h);
 PVC3_BGZF_API void *pvc3_bgzf_dev_input(pvc3_bgzf_dev *h, uint32_t slot);			/* device pointer */
 PVC3_BGZF_API uint64_t pvc3_bgzf_dev_capacity(pvc3_bgzf_dev const *h);			/* uncompressed bytes per slot */
 PVC3_BGZF_API int pvc3_bgzf_dev_submit(pvc3_bgzf_dev *h, uint32_t slot, uint64_t n_bytes);
-PVC3_BGZF_API int pvc3_bgzf_dev_wait(pvc3_bgzf_dev *h, uint32_t slot, uint8_t const **file_bytes, uint64_t *n_file_bytes, float *kernel_ms);
+/* Waits for the slot's blocks: *n_file_bytes of BGZF file.  They are fetched through page-locked memory in one or more pieces:
+ * pvc3_bgzf_dev_fetch copies the bytes from `offset` on, as many as the staging holds (BAM records fit one fetch), and returns
+ * where they are and how many; the bytes stay valid until the next fetch or submit of the slot. */
+PVC3_BGZF_API int pvc3_bgzf_dev_wait(pvc3_bgzf_dev *h, uint32_t slot, uint64_t *n_file_bytes, float *kernel_ms);
+PVC3_BGZF_API int pvc3_bgzf_dev_fetch(pvc3_bgzf_dev *h, uint32_t slot, uint64_t offset, uint8_t const **bytes, uint64_t *n_bytes);
 
 PVC3_BGZF_API char const *pvc3_bgzf_last_error(void);
 

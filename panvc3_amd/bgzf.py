@@ -16,7 +16,7 @@ SYMBOLS = ("pvc3_bgzf_create", "pvc3_bgzf_destroy", "pvc3_bgzf_max_blocks", "pvc
 		   "pvc3_bgzf_wait", "pvc3_bgzf_deflate", "pvc3_bgzf_last_error",
 		   "pvc3_bgzf_inflater_create", "pvc3_bgzf_inflater_destroy", "pvc3_bgzf_inflater_blocks_in_flight", "pvc3_bgzf_inflater_input", "pvc3_bgzf_inflater_output", "pvc3_bgzf_inflater_blocks",
 		   "pvc3_bgzf_inflater_submit", "pvc3_bgzf_inflater_wait", "pvc3_bgzf_inflater_submit_device", "pvc3_bgzf_inflater_wait_device",
-		   "pvc3_bgzf_dev_create", "pvc3_bgzf_dev_destroy", "pvc3_bgzf_dev_input", "pvc3_bgzf_dev_capacity", "pvc3_bgzf_dev_submit", "pvc3_bgzf_dev_wait")
+		   "pvc3_bgzf_dev_create", "pvc3_bgzf_dev_destroy", "pvc3_bgzf_dev_input", "pvc3_bgzf_dev_capacity", "pvc3_bgzf_dev_submit", "pvc3_bgzf_dev_wait", "pvc3_bgzf_dev_fetch")
 BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8")])
 _L = None
 
@@ -60,7 +60,8 @@ def lib():
 		L.pvc3_bgzf_dev_capacity.argtypes = [C.c_void_p]
 		L.pvc3_bgzf_dev_capacity.restype = C.c_uint64
 		L.pvc3_bgzf_dev_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
-		L.pvc3_bgzf_dev_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+		L.pvc3_bgzf_dev_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+		L.pvc3_bgzf_dev_fetch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
 		_L = L
 	return _L
 
@@ -243,9 +244,15 @@ class DeviceCompressor:
 			chunk = data[b * BLOCK:(b + 1) * BLOCK]
 			assert 0 == H.hipMemcpy(d_in + b * IN_STRIDE + IN_PAD, chunk, len(chunk), H2D)
 		_check(self._L.pvc3_bgzf_dev_submit(self._h, slot, len(data)))
-		out, n, ms = C.c_void_p(), C.c_uint64(), C.c_float()
-		_check(self._L.pvc3_bgzf_dev_wait(self._h, slot, C.byref(out), C.byref(n), C.byref(ms)))
-		return C.string_at(out, n.value), ms.value
+		total, ms = C.c_uint64(), C.c_float()
+		_check(self._L.pvc3_bgzf_dev_wait(self._h, slot, C.byref(total), C.byref(ms)))
+		blob, off = b"", 0
+		while off < total.value:		# (BAM records come back in one piece; incompressible bytes need two)
+			out, n = C.c_void_p(), C.c_uint64()
+			_check(self._L.pvc3_bgzf_dev_fetch(self._h, slot, off, C.byref(out), C.byref(n)))
+			blob += C.string_at(out, n.value)
+			off += n.value
+		return blob, ms.value
 
 
 def bgzf_member(stream, data):

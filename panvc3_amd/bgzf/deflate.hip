@@ -726,7 +726,7 @@ struct pvc3_bgzf_dev
 	uint32_t *d_len{}, *d_out_len{}, *d_tokens{}, *d_crc{};
 	uint64_t *d_file_off{};
 	pvc3_crc::tables *d_crc_tables{};
-	size_t file_cap{};
+	size_t file_cap{}, stage_cap{};		// the framed blocks of a slot on the device at most; the page-locked bytes they are fetched through
 	struct slot
 	{
 		uint8_t *d_in{};				// the caller's kernels write here
@@ -736,6 +736,7 @@ struct pvc3_bgzf_dev
 		uint64_t *h_file_off{};
 		hipEvent_t start{}, stop{}, sizes{}, done{};
 		uint32_t n{};
+		uint64_t total{};
 		bool busy{};
 	} slots[4];
 };
@@ -787,6 +788,9 @@ int pvc3_bgzf_dev_create(int device, uint32_t max_blocks, uint32_t n_slots, pvc3
 	check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
 	size_t const in_bytes = (size_t) max_blocks * PVC3_BGZF_IN_STRIDE, out_bytes = (size_t) max_blocks * PVC3_BGZF_OUT_STRIDE;
 	h->file_cap = (size_t) max_blocks * (PVC3_BGZF_BLOCK + 5 + 26);		// a block that does not shrink is stored: five bytes more
+	// BAM records shrink to a third: the page-locked memory the bytes come back through is sized for that and a margin (what does
+	// not fit one fetch takes another), since page-locked memory costs the process time when it is made and when it ends
+	h->stage_cap = (h->file_cap / 2 > (size_t(16) << 20)) ? h->file_cap / 2 : ((h->file_cap < (size_t(16) << 20)) ? h->file_cap : (size_t(16) << 20));
 	if (0 == rc) check(hipMalloc((void **) &h->d_out, out_bytes), "hipMalloc");
 	if (0 == rc) check(hipMalloc((void **) &h->d_len, max_blocks * sizeof(uint32_t)), "hipMalloc");
 	if (0 == rc) check(hipMalloc((void **) &h->d_out_len, max_blocks * sizeof(uint32_t)), "hipMalloc");
@@ -801,7 +805,7 @@ int pvc3_bgzf_dev_create(int device, uint32_t max_blocks, uint32_t n_slots, pvc3
 		check(hipMalloc((void **) &s.d_in, in_bytes), "hipMalloc");
 		if (0 == rc) check(hipMalloc((void **) &s.d_file, h->file_cap), "hipMalloc");
 		if (0 == rc) check(hipMemset(s.d_in, 0, in_bytes), "hipMemset");		// (the pads in front of the blocks are read)
-		if (0 == rc) check(hipHostMalloc((void **) &s.h_file, h->file_cap, hipHostMallocDefault), "hipHostMalloc");
+		if (0 == rc) check(hipHostMalloc((void **) &s.h_file, h->stage_cap, hipHostMallocDefault), "hipHostMalloc");
 		if (0 == rc) check(hipHostMalloc((void **) &s.h_out_len, max_blocks * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
 		if (0 == rc) check(hipHostMalloc((void **) &s.h_file_off, ((size_t) max_blocks + 1) * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc");
 		if (0 == rc) check(hipEventCreate(&s.start), "hipEventCreate");
@@ -841,24 +845,37 @@ int pvc3_bgzf_dev_submit(pvc3_bgzf_dev *h, uint32_t slot, uint64_t n_bytes)
 	return 0;
 }
 
-int pvc3_bgzf_dev_wait(pvc3_bgzf_dev *h, uint32_t slot, uint8_t const **file_bytes, uint64_t *n_file_bytes, float *kernel_ms)
+int pvc3_bgzf_dev_wait(pvc3_bgzf_dev *h, uint32_t slot, uint64_t *n_file_bytes, float *kernel_ms)
 {
-	if (!h || slot >= h->n_slots || !file_bytes || !n_file_bytes) return fail(E_INVALID, "pvc3_bgzf_dev_wait: bad argument");
+	if (!h || slot >= h->n_slots || !n_file_bytes) return fail(E_INVALID, "pvc3_bgzf_dev_wait: bad argument");
 	auto &s = h->slots[slot];
 	if (!s.busy) return fail(E_STATE, "pvc3_bgzf_dev_wait: nothing was submitted");
 	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
 	s.busy = false;
-	// The sizes first: how many bytes the framed blocks are is known on the device only; then exactly those bytes.
 	HIP_TRY(hipEventSynchronize(s.sizes), "hipEventSynchronize");
+	if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, s.start, s.stop), "hipEventElapsedTime");
 	for (uint32_t i = 0; i < s.n; ++i)
 		if (s.h_out_len[i] & SIZE_MISMATCH) return fail(E_STATE, "k_deflate_blocks: a stream is not as long as computed");
-	uint64_t const total = s.h_file_off[s.n];
-	if (total > h->file_cap) return fail(E_STATE, "pvc3_bgzf_dev_wait: the framed blocks exceed their buffer");
-	HIP_TRY(hipMemcpyAsync(s.h_file, s.d_file, total, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
-	HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
-	HIP_TRY(hipEventSynchronize(s.done), "hipEventSynchronize");
-	if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, s.start, s.stop), "hipEventElapsedTime");
-	*file_bytes = s.h_file; *n_file_bytes = total;
+	s.total = s.h_file_off[s.n];
+	if (s.total > h->file_cap) return fail(E_STATE, "pvc3_bgzf_dev_wait: the framed blocks exceed their buffer");
+	*n_file_bytes = s.total;
+	return 0;
+}
+
+int pvc3_bgzf_dev_fetch(pvc3_bgzf_dev *h, uint32_t slot, uint64_t offset, uint8_t const **bytes, uint64_t *n_bytes)
+{
+	if (!h || slot >= h->n_slots || !bytes || !n_bytes) return fail(E_INVALID, "pvc3_bgzf_dev_fetch: bad argument");
+	auto &s = h->slots[slot];
+	if (s.busy || offset > s.total) return fail(E_STATE, "pvc3_bgzf_dev_fetch: nothing to fetch there");
+	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+	uint64_t const n = (s.total - offset < h->stage_cap) ? (s.total - offset) : h->stage_cap;
+	if (n)
+	{
+		HIP_TRY(hipMemcpyAsync(s.h_file, s.d_file + offset, n, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
+		HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
+		HIP_TRY(hipEventSynchronize(s.done), "hipEventSynchronize");
+	}
+	*bytes = s.h_file; *n_bytes = n;
 	return 0;
 }
 

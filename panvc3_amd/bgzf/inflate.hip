@@ -40,8 +40,16 @@ constexpr unsigned WAVE = 64;
 constexpr unsigned LL_BITS = 10, D_BITS = 9, CL_BITS = 7;
 constexpr unsigned RING_WORDS = 512;		// two halves of 256 dwords
 constexpr unsigned OUT_CAP = 65536;			// ISIZE at most
-constexpr unsigned OUT_RING = 32768;		// the last 32 KB of the output: as far back as a match can reach
+// The output's last 32 KB live in a ring in LDS: as far back as a match can reach.  A smaller ring (-DPVC3_INF_RING=8192: more
+// blocks in flight per CU; a match that begins behind it reads the output in global memory, copy_far below) was measured and is
+// slower by three on BAM records with binned qualities, whose matches lie anywhere in the 32 KB (tools/calib/inf_variants/ring.py,
+// profiles/r04/inflate_ring.txt): 3.0 GB/s with 8 KB and 2 560 blocks in flight against 9.1 with 32 KB and 1 024.
+#ifndef PVC3_INF_RING
+#define PVC3_INF_RING 32768
+#endif
+constexpr unsigned OUT_RING = PVC3_INF_RING;
 constexpr unsigned OUT_HALF = OUT_RING / 2;
+static_assert(OUT_RING >= 2048 && OUT_RING <= 32768 && 0 == (OUT_RING & (OUT_RING - 1)), "the ring is a power of two that holds a match and a run of literals twice over");
 
 enum : uint32_t
 {
@@ -277,6 +285,26 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 		auto make_room = [&]() {		// before up to 322 bytes are written at pos
 			if (pos + 322 > flushed + OUT_RING) { store_region(flushed, OUT_HALF); flushed += OUT_HALF; }
 		};
+		// (Rings smaller than a match's reach only.)  A match that begins behind the ring: a byte whose place in the ring the next 322
+		// bytes may take is read from the output in global memory — make_room() has stored it; the fence orders the stores of all
+		// lanes before the loads, which go past the first-level cache — the others from the ring.  Call after make_room().
+		auto copy_far = [&](uint32_t from, uint32_t dist, uint32_t length) {
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+			for (uint32_t j = lane; j < length; j += WAVE)
+			{
+				uint32_t const s = from + ((dist >= length) ? j : (j % dist));
+				uint8_t v;
+				if (s + OUT_RING >= pos + 322) v = OUTB(s);
+				else
+				{
+					// the aligned dword that holds the byte, past the first-level cache
+					uintptr_t const a = reinterpret_cast <uintptr_t>(dst + s);
+					uint32_t const w = __hip_atomic_load(reinterpret_cast <uint32_t const *>(a & ~uintptr_t(3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					v = (uint8_t) (w >> (8 * (a & 3)));
+				}
+				OUTB(pos + j) = v;
+			}
+		};
 
 		for (bool last = false; !last && ST_OK == st; )
 		{
@@ -442,7 +470,8 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 					uint32_t const from = pos - dist;
 					make_room();
 #ifndef PVC3_INF_SKIP_COPY
-					if (dist >= length)
+					if (OUT_RING < 32768 && from + OUT_RING < pos + 322) copy_far(from, dist, length);
+					else if (dist >= length)
 						for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = OUTB(from + j);
 					else if (1 == dist)
 					{
@@ -502,7 +531,8 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 				if (pos + length > want) { st = ST_OUTPUT_OVERFLOW; break; }
 				uint32_t const from = pos - dist;
 				make_room();
-				if (dist >= length)
+				if (OUT_RING < 32768 && from + OUT_RING < pos + 322) copy_far(from, dist, length);
+				else if (dist >= length)
 					for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = OUTB(from + j);
 				else
 					for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = OUTB(from + j % dist);

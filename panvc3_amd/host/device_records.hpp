@@ -258,10 +258,16 @@ inline device_records_result run_device_records(device_records_options const &op
 					slot = to_write.front(); to_write.pop_front();
 				}
 				auto const t0 = now();
-				uint8_t const *bytes{}; uint64_t n = 0; float ms = 0;
-				bgzf_check(pvc3_bgzf_dev_wait(deflater, slot, &bytes, &n, &ms), "pvc3_bgzf_dev_wait");
-				opt.write_blocks(bytes, n);
-				res.deflate_kernel_s += 1e-3 * ms; res.bytes_out += n;
+				uint64_t total = 0; float ms = 0;
+				bgzf_check(pvc3_bgzf_dev_wait(deflater, slot, &total, &ms), "pvc3_bgzf_dev_wait");
+				for (uint64_t off = 0; off < total; )
+				{
+					uint8_t const *bytes{}; uint64_t n = 0;
+					bgzf_check(pvc3_bgzf_dev_fetch(deflater, slot, off, &bytes, &n), "pvc3_bgzf_dev_fetch");
+					opt.write_blocks(bytes, n);
+					off += n;
+				}
+				res.deflate_kernel_s += 1e-3 * ms; res.bytes_out += total;
 				res.t_writer += since(t0);
 				{
 					std::lock_guard <std::mutex> lock(m);

@@ -172,8 +172,13 @@ public:
 				uint32_t const len = take(16), nlen = take(16);
 				if ((len ^ 0xffffu) != nlen) return false;
 				// the bit buffer holds whole bytes here: give them back
-				ip -= n_bits >> 3;
-				if (overrun) { if (overrun > (n_bits >> 3)) return false; ip += overrun; overrun = 0; }		// (only bytes that exist are given back)
+				{
+					// (only bytes that exist are given back: the pointer never leaves [in, in_end])
+					std::size_t const held = n_bits >> 3;
+					if (overrun > held) return false;
+					ip -= held - overrun;
+					overrun = 0;
+				}
 				bits = 0; n_bits = 0;
 				if ((std::size_t) (in_end - ip) < len || (std::size_t) (out_end - op) < len) return false;
 				std::memcpy(op, ip, len);

@@ -107,7 +107,7 @@ struct options
 	bool bam_input{}, output_bam{}, keep_duplicate_ranges{}, print_invocation{}, print_pid{}, io_only{}, debugging_output{};
 	bool gpu_deflate{true};				// --bgzf-deflate=gpu|host: BAM output with the built-in encoder is compressed on the first GPU
 	int record_path{-1};				// --record-path=gpu|host: -1 = gpu where it applies (BGZF BAM file in, BAM out with the built-in encoder on the GPU, one GPU)
-	bool inflate_given{};				// --bgzf-inflate was given
+	bool inflate_given{}, deflate_given{};		// --bgzf-inflate / --bgzf-deflate was given
 	bool gpu_inflate{false};			// --bgzf-inflate=gpu|host: the blocks of BGZF input are inflated on the first GPU (7 GB/s: sixteen host threads are faster)
 	std::vector <std::string> preserve_tags;
 	std::string rname_tag{"XR"}, pos_tag{"XP"}, rnext_tag{"YR"}, pnext_tag{"YP"}, query_ranges_tag{"XB"}, ref_ranges_tag{"YB"}, rec_idx_tag;
@@ -370,6 +370,7 @@ int main(int argc, char **argv)
 				if (0 == std::strcmp(optarg, "gpu")) opt.gpu_deflate = true;
 				else if (0 == std::strcmp(optarg, "host")) opt.gpu_deflate = false;
 				else die("--bgzf-deflate expects gpu or host");
+				opt.deflate_given = true;
 				break;
 			case 1019:
 				if (0 == std::strcmp(optarg, "gpu")) opt.gpu_inflate = true;
@@ -1188,8 +1189,17 @@ int main(int argc, char **argv)
 			tm.rewrite += since(t_stage); t_stage = now();
 			if (deflater_coming.valid())		// the first batch for the writer thread: from here on the GPU compresses the blocks
 			{
-				block_deflater = deflater_coming.get();
-				writer.attach(block_deflater.get());
+				try
+				{
+					block_deflater = deflater_coming.get();
+					writer.attach(block_deflater.get());
+				}
+				catch (std::exception const &e)
+				{
+					// asked for: an error; the default: the host's encoder writes the same records
+					if (opt.deflate_given) throw;
+					std::cerr << "WARNING: the BGZF compressor on the GPU could not be made (" << e.what() << "); the output's blocks are compressed by the host's threads.\n";
+				}
 			}
 			{
 				std::unique_lock <std::mutex> lock(wq_mutex);
@@ -1222,6 +1232,8 @@ int main(int argc, char **argv)
 			if (reader_error) std::rethrow_exception(reader_error);
 			tm.wait_read += since(t_stage);
 			if (!bs) break;
+			// (--bgzf-inflate=gpu and no inflater: an error as soon as it is known, not after the last batch)
+			if (inflater_coming.valid() && std::future_status::ready == inflater_coming.wait_for(std::chrono::seconds(0))) inflater_coming.get();
 			slot_state &sl = slot_states[batch_no % slot_states.size()];
 			if (sl.in_flight) retire(sl);		// batch_no - 2 x GPUs: the same GPU's older batch
 			// The reference's periodic status line (project_alignments.cc:446-481): time spent, records processed, µs per record.

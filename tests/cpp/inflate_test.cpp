@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -26,8 +27,64 @@ static std::vector <uint8_t> deflate_raw(std::vector <uint8_t> const &in, int le
 	return out;
 }
 
-int main()
+// `fuzz`: streams with flipped bits, random bytes, random cuts and wrong output sizes, from and into heap buffers of exactly
+// the sizes given (built with -fsanitize=address,undefined by tests/test_host_io_cpu.py: a read or write outside them, or a
+// pointer that leaves its array, ends the program).  Whatever the decoder accepts must be what zlib makes of the same bytes.
+static int fuzz(unsigned rounds)
 {
+	std::mt19937_64 rng(11);
+	pvc3host::fast_inflater inf;
+	std::vector <std::vector <uint8_t>> plain;
+	for (std::size_t sz : {0u, 1u, 5u, 300u, 4000u, 40000u, 65280u})
+	{
+		std::vector <uint8_t> d(sz);
+		for (std::size_t i = 0; i < sz; ++i) d[i] = (uint8_t) ((i % 11 < 4) ? ('a' + i % 3) : (rng() & ((i & 64) ? 0xff : 0x03)));
+		plain.push_back(d);
+	}
+	int bad = 0;
+	unsigned accepted = 0;
+	for (unsigned r = 0; r < rounds; ++r)
+	{
+		auto const &data = plain[rng() % plain.size()];
+		static int const levels[4] = {0, 1, 6, 9};
+		static int const strategies[4] = {Z_DEFAULT_STRATEGY, Z_FIXED, Z_HUFFMAN_ONLY, Z_RLE};
+		std::vector <uint8_t> comp = deflate_raw(data, levels[rng() % 4], strategies[rng() % 4]);
+		std::size_t out_len = data.size();
+		switch (rng() % 6)
+		{
+			case 0: for (int k = 0; k < 1 + (int) (rng() % 4) && !comp.empty(); ++k) comp[rng() % comp.size()] ^= (uint8_t) (1u << (rng() % 8)); break;
+			case 1: for (auto &b : comp) if (0 == rng() % 50) b = (uint8_t) rng(); break;
+			case 2: comp.resize(rng() % (comp.size() + 1)); break;
+			case 3: comp.resize(rng() % 600); for (auto &b : comp) b = (uint8_t) rng(); break;
+			case 4: out_len = rng() % (data.size() + 300); break;
+			default: break;		// as it is
+		}
+		// exact-size heap buffers (a vector's capacity may be larger than its size)
+		uint8_t *in = new uint8_t[comp.size() ? comp.size() : 1], *out = new uint8_t[out_len ? out_len : 1];
+		if (!comp.empty()) std::memcpy(in, comp.data(), comp.size());
+		bool const ok = inf.inflate(comp.empty() ? in + 1 : in, comp.size(), out_len ? out : out + 1, out_len);
+		if (ok)
+		{
+			++accepted;
+			// zlib must make the same bytes of it
+			std::vector <uint8_t> ref(out_len + 1);
+			z_stream zs{};
+			inflateInit2(&zs, -15);
+			zs.next_in = in; zs.avail_in = (uInt) comp.size(); zs.next_out = ref.data(); zs.avail_out = (uInt) ref.size();
+			int const rc = inflate(&zs, Z_FINISH);
+			bool const same = Z_STREAM_END == rc && zs.total_out == out_len && 0 == std::memcmp(ref.data(), out, out_len);
+			inflateEnd(&zs);
+			if (!same && bad++ < 10) std::printf("FAIL round %u: accepted what zlib does not make the same bytes of (rc %d, %lu of %zu)\n", r, rc, (unsigned long) zs.total_out, out_len);
+		}
+		delete[] in; delete[] out;
+	}
+	std::printf("%u rounds, %u accepted, %d failures\n", rounds, accepted, bad);
+	return bad ? 1 : 0;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc > 1 && 0 == std::strcmp(argv[1], "fuzz")) return fuzz(argc > 2 ? (unsigned) std::atoi(argv[2]) : 20000u);
 	std::mt19937_64 rng(3);
 	pvc3host::fast_inflater inf;
 	int bad = 0, n = 0;

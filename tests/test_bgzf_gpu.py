@@ -245,6 +245,36 @@ def test_inflate_zlib_streams(gpu_inflater):
 
 
 @pytest.mark.gpu
+def test_inflate_matches_that_reach_behind_the_ring(gpu_inflater):
+	"""The inflater keeps the output's last 8 KB in LDS; a match whose source begins further back reads the output in global memory,
+	and one that begins behind the ring and reaches into it reads both.  zlib's level 9 finds a copy of a block of random bytes at
+	every distance up to 32 KB: distances around the ring's size and its half, a few bytes and whole blocks past it, the longest
+	match at the largest distance, copies that overlap their own output, several far copies in a row, in the pinned-output form and
+	in the device-resident one."""
+	rng = np.random.default_rng(41)
+	cases = []
+	for dist in (4000, 4095, 4096, 4097, 7800, 8000, 8191, 8192, 8193, 8450, 12000, 16384, 20000, 32000, 32768):
+		for length in (3, 50, 258, 700):
+			block = bytes(rng.integers(0, 256, size=length, dtype=np.uint8))
+			filler = bytes(rng.integers(0, 256, size=dist - length if dist > length else 1, dtype=np.uint8))
+			head = bytes(rng.integers(0, 256, size=int(rng.integers(0, 5000)), dtype=np.uint8))
+			cases.append(head + block + filler + block + bytes(rng.integers(0, 4, size=100, dtype=np.uint8)))
+	# the same 300 bytes again and again, 9 KB apart, with text in between that compresses (literal runs and near matches mixed in)
+	block = bytes(rng.integers(0, 256, size=300, dtype=np.uint8))
+	text = _bam_like(rng, 40)
+	cases.append((block + text[:8900]) * 6)
+	cases.append((block + text[:16000]) * 3 + block)
+	streams = [_raw_deflate(c[:65536], 9) for c in cases]
+	sizes = [len(c[:65536]) for c in cases]
+	got, status, _ = gpu_inflater.inflate(streams, sizes, gap=1)
+	bad = [i for i in range(len(cases)) if status[i] != 0 or got[i] != cases[i][:65536]]
+	assert not bad, (bad[:5], [int(status[i]) for i in bad[:5]])
+	dev, st2, crcs = gpu_inflater.inflate_to_device(streams, sizes, slot=1)
+	assert not st2.any() and dev == b"".join(c[:65536] for c in cases)
+	assert [int(x) for x in crcs] == [zlib.crc32(c[:65536]) & 0xffffffff for c in cases]
+
+
+@pytest.mark.gpu
 def test_inflate_what_the_gpu_deflated(gpu, gpu_inflater):
 	rng = np.random.default_rng(31)
 	data = _bam_like(rng, 6000)
@@ -318,6 +348,15 @@ def test_device_resident_compressor_makes_the_file_bytes():
 			assert p == len(blob) and total == n
 	finally:
 		comp.close()
+	# bytes that do not shrink: the blocks are stored, the file is larger than the page-locked memory it comes back through, and is
+	# fetched in more than one piece
+	big = bgzf.DeviceCompressor(0, max_blocks=600, n_slots=1)
+	try:
+		data = bytes(rng.integers(0, 256, size=600 * 65280 - 1234, dtype=np.uint8))
+		blob, _ = big.deflate(data)
+		assert len(blob) > len(data) and gzip.decompress(blob) == data
+	finally:
+		big.close()
 
 
 @pytest.mark.gpu

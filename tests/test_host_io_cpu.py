@@ -92,6 +92,18 @@ def test_fast_inflate_against_zlib_streams(tool):
 	assert out.returncode == 0, out.stdout
 
 
+def test_fast_inflate_fuzz_under_sanitizers(tmp_path):
+	"""fast_inflate.hpp parses bytes of the input file before zlib does: damaged, cut and random streams, from and into heap buffers
+	of exactly the sizes given, with AddressSanitizer and UndefinedBehaviorSanitizer (CPU only: the GPU boxes refuse sanitizers)."""
+	exe = str(tmp_path / "inflate_fuzz")
+	cmd = [os.environ.get("CXX", "g++"), "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+		   os.path.join(ROOT, "tests", "cpp", "inflate_test.cpp"), "-o", exe, "-lz"]
+	subprocess.check_call(cmd)
+	out = subprocess.run([exe, "fuzz", "6000"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+	assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+	assert "0 failures" in out.stdout
+
+
 def test_writer_with_a_group_deflater(tmp_path):
 	"""byte_writer's group path (the GPU compressor's slot interface) with a host stand-in: the same bytes, cut into the same
 	blocks, whether the groups are attached from the start, after some output, or not at all; one slot or several."""

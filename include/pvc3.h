@@ -179,6 +179,12 @@ PVC3_API int pvc3_index_add_bits(pvc3_index *idx, uint64_t const *gap_words, uin
 /* Unaligned text (raw FASTA bytes, case preserved) of an entry used as a destination; len >= number of non-gap columns.
  * The bytes are copied. */
 PVC3_API int pvc3_index_set_reference(pvc3_index *idx, uint32_t entry, char const *text, uint64_t len);
+/* The entry that `entry`'s records are projected to (the destination row of its chromosome; it must have as many columns).  The
+ * paired blocks and the position windows of `entry` are made towards it.  Without this call the nearest entry with a text and as
+ * many columns is taken, which is right for one MSA per column count; with several MSAs of one length a caller that knows the
+ * pairs (project_alignments.cc:1271-1316 does) should name them: records whose destination is another entry than the one the
+ * windows were made for are projected correctly, but by the slower kernels. */
+PVC3_API int pvc3_index_set_destination(pvc3_index *idx, uint32_t entry, uint32_t dst_entry);
 PVC3_API int pvc3_index_entry_count(pvc3_index const *idx, uint32_t *count);
 PVC3_API int pvc3_index_entry_info(pvc3_index const *idx, uint32_t entry, uint64_t *n_cols, uint64_t *n_non_gap);
 /* Host view of the HBM layout of one entry (for inspection and host-logic tests):

@@ -93,6 +93,7 @@ def lib():
 		"pvc3_index_add_aligned": ([vp, C.c_char_p, u64, P(u32)], i32),
 		"pvc3_index_add_bits": ([vp, vp, u64, P(u32)], i32),
 		"pvc3_index_set_reference": ([vp, u32, vp, u64], i32),
+		"pvc3_index_set_destination": ([vp, u32, u32], i32),
 		"pvc3_index_entry_count": ([vp, P(u32)], i32),
 		"pvc3_index_entry_info": ([vp, u32, P(u64), P(u64)], i32),
 		"pvc3_index_entry_layout": ([vp, u32, P(vp), P(u64), P(vp), P(u64)], i32),

@@ -86,6 +86,10 @@ class Index:
 		buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, dtype=np.uint8)
 		check(self._L.pvc3_index_set_reference(self._h, entry, buf.ctypes.data, buf.size))
 
+	def set_destination(self, entry, dst_entry):
+		"""pvc3_index_set_destination: the entry that `entry`'s records are projected to."""
+		check(self._L.pvc3_index_set_destination(self._h, entry, dst_entry))
+
 	def entry_count(self):
 		n = C.c_uint32()
 		check(self._L.pvc3_index_entry_count(self._h, C.byref(n)))

@@ -272,6 +272,15 @@ int pvc3_index_set_reference(pvc3_index *idx, uint32_t entry, char const *text, 
 	catch (std::bad_alloc const &) { return set_error(PVC3_E_NOMEM, "pvc3_index_set_reference: out of memory"); }
 }
 
+int pvc3_index_set_destination(pvc3_index *idx, uint32_t entry, uint32_t dst_entry)
+{
+	if (!idx || entry >= idx->entries.size() || dst_entry >= idx->entries.size()) return set_error(PVC3_E_INVALID, "pvc3_index_set_destination: no such entry");
+	if (idx->entries[entry].n_cols != idx->entries[dst_entry].n_cols)
+		return set_error(PVC3_E_INVALID, "pvc3_index_set_destination: entries %u and %u have different numbers of columns", entry, dst_entry);
+	idx->entries[entry].destination = dst_entry;
+	return PVC3_OK;
+}
+
 int pvc3_index_entry_count(pvc3_index const *idx, uint32_t *count)
 {
 	if (!idx || !count) return set_error(PVC3_E_INVALID, "pvc3_index_entry_count: null argument");
@@ -405,6 +414,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 	uint32_t const pwin_shift = (ctx->window_read_length <= 158) ? 6 : 7;
 	auto partner_of = [&](size_t i) -> size_t {
 		host_entry const &e = idx->entries[i];
+		if (NO_PARTNER != e.destination && !idx->entries[e.destination].text.empty()) return e.destination;		// named by the caller (pvc3_index_set_destination)
 		if (!e.text.empty()) return i;			// an entry with a text is its own destination (reads aligned to the reference row)
 		size_t best = idx->entries.size();
 		for (size_t j = 0; j < idx->entries.size(); ++j)
@@ -482,7 +492,9 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 		if (ctx->paired_blocks)
 		{
 			size_t best = idx->entries.size();
-			for (size_t j = 0; j < idx->entries.size(); ++j)
+			bool const named = NO_PARTNER != e.destination && e.destination != i && !idx->entries[e.destination].text.empty();		// pvc3_index_set_destination
+			if (named) best = e.destination;
+			for (size_t j = 0; !named && j < idx->entries.size(); ++j)
 			{
 				host_entry const &o = idx->entries[j];
 				if (j == i || o.text.empty() || o.n_cols != e.n_cols) continue;

@@ -44,6 +44,7 @@ struct host_entry
 	std::vector <uint64_t> blocks;		// (n_blocks + PAD_BLOCKS) * 8
 	std::vector <uint32_t> sel;			// ceil(n_zeros / 64) + 1
 	std::vector <char> text;			// unaligned text, may be empty
+	uint32_t destination{0xFFFFFFFFu};	// pvc3_index_set_destination: the entry this one's records are projected to (none: the nearest entry with a text and as many columns)
 };
 
 struct dev_entry

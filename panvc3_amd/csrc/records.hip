@@ -430,24 +430,63 @@ struct write_sink
 		*p++ = (uint8_t) v;
 		if (0 == --left) { p += gap; left = block_bytes; }
 	}
-	__device__ void copy(uint8_t const *s, uint32_t k) { for (uint32_t x = 0; x < k; ++x) byte(s[x]); }
+	// Four bytes at a time where the output allows it: the bytes in front of a dword boundary of the output one by one, then
+	// whole dwords (the source read as two aligned dwords shifted into place), then the rest; f transforms four bytes.
+	template <typename t_fn>
+	__device__ void copy4(uint8_t const *s, uint32_t k, t_fn &&f)
+	{
+		uint32_t x = 0;
+		while (x < k && (((uintptr_t) p) & 3)) { byte(f((uint32_t) s[x]) & 0xff); ++x; }
+		while (x + 4 <= k)
+		{
+			if (left < 4) { byte(f((uint32_t) s[x]) & 0xff); ++x; continue; }		// (a block of the output ends inside these four bytes; the next block's data begin on a dword boundary again or the loop above takes over)
+			if (((uintptr_t) p) & 3) { byte(f((uint32_t) s[x]) & 0xff); ++x; continue; }
+			*(uint32_t *) p = f(ld32(s + x));
+			p += 4; left -= 4; x += 4;
+			if (0 == left) { p += gap; left = block_bytes; }
+		}
+		for (; x < k; ++x) byte(f((uint32_t) s[x]) & 0xff);
+	}
+	__device__ void copy(uint8_t const *s, uint32_t k) { copy4(s, k, [](uint32_t v) { return v; }); }
 	// SEQ through seqan3::dna5: a code that is not A, C, G or T becomes N; the unused low nibble of an odd-length SEQ stays as it was
 	__device__ void copy_seq(uint8_t const *s, uint32_t l_seq)
 	{
 		uint32_t const nb = (l_seq + 1) / 2;
-		for (uint32_t x = 0; x < nb; ++x)
+		// every nibble of the (up to four) bytes: one-hot (1, 2, 4, 8) stays, anything else becomes 15
+		auto canon = [](uint32_t v) {
+			uint32_t out = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < 8; ++k)
+			{
+				uint32_t const c = (v >> (4 * k)) & 15;
+				out |= ((1 == c || 2 == c || 4 == c || 8 == c) ? c : 15u) << (4 * k);
+			}
+			return out;
+		};
+		if (l_seq & 1)
 		{
-			uint32_t const v = s[x], hi = v >> 4, lo = v & 15;
-			uint32_t const ch = (1 == hi || 2 == hi || 4 == hi || 8 == hi) ? hi : 15u;
-			uint32_t cl = (1 == lo || 2 == lo || 4 == lo || 8 == lo) ? lo : 15u;
-			if ((l_seq & 1) && x + 1 == nb) cl = lo;
-			byte((ch << 4) | cl);
+			// all but the last byte, then the last one with its low nibble untouched
+			copy4(s, nb - 1, canon);
+			uint32_t const v = s[nb - 1], hi = v >> 4;
+			byte((((1 == hi || 2 == hi || 4 == hi || 8 == hi) ? hi : 15u) << 4) | (v & 15));
 		}
+		else
+			copy4(s, nb, canon);
 	}
 	// QUAL through seqan3::phred42: values beyond 41 saturate (a missing QUAL, 0xff ..., is copied as it is)
 	__device__ void copy_qual(uint8_t const *s, uint32_t l_seq, bool has_qual)
 	{
-		for (uint32_t x = 0; x < l_seq; ++x) { uint32_t const v = s[x]; byte((has_qual && v > 41) ? 41u : v); }
+		if (!has_qual) { copy(s, l_seq); return; }
+		copy4(s, l_seq, [](uint32_t v) {
+			uint32_t out = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k)
+			{
+				uint32_t const q = (v >> (8 * k)) & 0xff;
+				out |= ((q > 41) ? 41u : q) << (8 * k);
+			}
+			return out;
+		});
 	}
 };
 

@@ -152,7 +152,12 @@ int pvc3_records_create(pvc3_context *ctx, pvc3_records_config const *c, pvc3_re
 	PVC3_TRY(upload(r, &r->T.dst_entry, c->dst_entry, c->n_refs));
 	PVC3_TRY(upload(r, &r->T.out_ref_id, c->out_ref_id, c->n_refs));
 	PVC3_TRY(upload(r, &r->T.ref_name_off, c->ref_name_off, (uint64_t) c->n_refs + 1));
-	PVC3_TRY(upload(r, &r->T.ref_names, c->ref_names, c->ref_name_off[c->n_refs]));
+	{
+		// (the names are copied a dword at a time: a few bytes of room behind the last one)
+		std::vector <char> names(c->ref_names, c->ref_names + c->ref_name_off[c->n_refs]);
+		names.resize(names.size() + 16, 0);
+		PVC3_TRY(upload(r, &r->T.ref_names, names.data(), names.size()));
+	}
 	{
 		std::vector <uint32_t> bits(2048, 0);
 		for (uint32_t i = 0; i < c->n_preserved_tags; ++i) bits[c->preserved_tags[i] >> 5] |= 1u << (c->preserved_tags[i] & 31);
@@ -247,9 +252,14 @@ int pvc3_records_frame(pvc3_records *r, uint32_t slot, uint64_t n_bytes, uint64_
 
 	LAUNCH_TRY(rec_launch_reset(r->d_state, s));
 	LAUNCH_TRY(rec_launch_frame(U, r->d_blk_off, nb, start0, end, r->n_refs, r->W, r->d_state, s));
-	LAUNCH_TRY(rec_launch_filter(U, r->rec_cap, r->W, r->d_state, r->n_refs, r->n_pending, r->parity, r->seen, s));
-	LAUNCH_TRY(rec_launch_scan(r->W.keep, &r->d_state->n_records, r->rec_cap, r->W.kept_pos, r->d_tile_sums, r->d_tile_base, s));
-	LAUNCH_TRY(rec_launch_compact(r->rec_cap, r->W, r->d_state, r->n_pending, r->parity, r->seen, last, s));
+	// how many records there are decides the grids of what follows (the arrays are made for the most a piece can hold, forty
+	// times what it usually holds: grids of that size cost a millisecond a piece)
+	PVC3_TRY(read_state(r));
+	uint32_t const n_found = r->h_state->n_records;
+	if (n_found > r->rec_cap) return set_error(PVC3_E_STATE, "pvc3_records_frame: more records than a piece can hold");
+	LAUNCH_TRY(rec_launch_filter(U, n_found, r->W, r->d_state, r->n_refs, r->n_pending, r->parity, r->seen, s));
+	LAUNCH_TRY(rec_launch_scan(r->W.keep, nullptr, n_found, r->W.kept_pos, r->d_tile_sums, r->d_tile_base, s));
+	LAUNCH_TRY(rec_launch_compact(n_found, r->W, r->d_state, r->n_pending, r->parity, r->seen, last, s));
 	LAUNCH_TRY(rec_launch_carry(U, end, r->d_state, r->d_carry, (uint32_t) FRONT, s));
 	PVC3_TRY(read_state(r));
 	rec_state const &st = *r->h_state;

@@ -529,6 +529,8 @@ int main(int argc, char **argv)
 				std::size_t const out_idx = ref_id_mapping[i];
 				if (UINT32_MAX == dst_entries[out_idx]) dst_entries[out_idx] = entry_for(chr_id, opt.reference_msa_id);
 				src_entries[i] = entry_for(chr_id, seq_id);
+				// (the pairs are known here: the replicas' paired blocks and position windows are made for exactly them)
+				check(pvc3_index_set_destination(index, src_entries[i], dst_entries[out_idx]), "pvc3_index_set_destination");
 			}
 			{
 				// The destination contigs only, through <reference>.fai (+ .gzi) when the indexes are there
@@ -676,6 +678,7 @@ int main(int argc, char **argv)
 					if (dr.removed_tags[key]) std::cerr << "\t\t" << (char) (key >> 8) << (char) (key & 0xff) << ": " << dr.removed_tags[key] << '\n';
 			}
 			std::cout.flush(); std::cerr.flush(); std::fflush(nullptr);
+			if (std::getenv("PVC3_EXIT_PROFILE")) std::exit(0);		// (under rocprofv3: its output is written by an exit handler, which _Exit would skip)
 			std::_Exit(0);
 		}
 

@@ -580,6 +580,48 @@ def test_plain_index_layout_matches_oracle(pvc3, oracle_mod, synth):
 		ctx.close(); ctx2.close()
 
 
+def test_destinations_named_by_the_caller(pvc3, oracle_mod, synth):
+	"""Two chromosomes whose MSAs have the same number of columns: the replica's paired blocks and position windows of a row are made
+	towards the nearest row with a text, which for half of the first chromosome's founders is the other chromosome's reference —
+	their records are then projected correctly, but by the walk kernels.  pvc3_index_set_destination names the pairs (the command
+	line knows them): the same results, and the records are finished by k_project_fast again."""
+	gp, rp, _ = synth.config("C3", scale=0.002)
+	gp.n_contigs = 1
+	genome = synth.Genome(gp)
+	reads = synth.Reads(genome, rp)
+	batch = reads.batch()
+	per = genome.n_entries		# REF + founders of the one contig
+	def fill(index, name_pairs):
+		for copy in range(2):		# the same MSA as two chromosomes: entries 0 .. per - 1 and per .. 2 per - 1
+			for e in range(per):
+				words, n_cols, text = genome.entry(e)
+				got = index.add_bits(words, n_cols)
+				assert got == copy * per + e
+				if 0 == e:
+					index.set_reference(got, text)
+		if name_pairs:
+			for copy in range(2):
+				for e in range(per):
+					index.set_destination(copy * per + e, copy * per)
+	o = oracle_mod.Oracle()
+	fill(o, False)
+	want = o.batch_project(batch, n_threads=4)
+	fast = {}
+	for named in (False, True):
+		index = pvc3.Index()
+		fill(index, named)
+		ctx = pvc3.Context(0)
+		ctx.upload_index(index)
+		got, stats = pvc3.project_batch(ctx, batch)
+		assert_results_equal(batch, got, want)
+		fast[named] = stats["n_fast_path"]
+		ctx.close()
+	if "default" == pvc3.paths_mode:
+		assert fast[True] > 0.9 * reads.n and fast[False] < 0.8 * fast[True], fast
+	with pytest.raises(pvc3.Error):
+		index.set_destination(0, 2 * per)
+
+
 @pytest.mark.parametrize("name", ["C3", "C4", "C5"])
 def test_full_size_properties(pvc3, oracle_mod, synth, name):
 	"""BASELINE.json configs[2] and configs[4] at full size (20 M pairs, 8 founders, 1 Gbp; 2x150 and 2x250 bp with long

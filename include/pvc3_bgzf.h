@@ -74,6 +74,8 @@ PVC3_BGZF_API int pvc3_bgzf_inflater_create(int device, size_t max_in_bytes, siz
 PVC3_BGZF_API void pvc3_bgzf_inflater_destroy(pvc3_bgzf_inflater *h);
 /* How many blocks the GPU works on at the same time (one wave each): a launch of that many takes as long as a launch of one. */
 PVC3_BGZF_API uint32_t pvc3_bgzf_inflater_blocks_in_flight(pvc3_bgzf_inflater const *h);
+/* Fewer blocks at a time (0: as many as the chip holds again), for a caller whose other kernels run next to the inflater's. */
+PVC3_BGZF_API int pvc3_bgzf_inflater_limit_in_flight(pvc3_bgzf_inflater *h, uint32_t blocks);
 PVC3_BGZF_API uint8_t *pvc3_bgzf_inflater_input(pvc3_bgzf_inflater *h, uint32_t slot);
 PVC3_BGZF_API uint8_t *pvc3_bgzf_inflater_output(pvc3_bgzf_inflater *h, uint32_t slot);
 PVC3_BGZF_API pvc3_bgzf_block *pvc3_bgzf_inflater_blocks(pvc3_bgzf_inflater *h, uint32_t slot);

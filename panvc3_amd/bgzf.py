@@ -14,7 +14,7 @@ IN_STRIDE = 65536
 OUT_STRIDE = 65536
 SYMBOLS = ("pvc3_bgzf_create", "pvc3_bgzf_destroy", "pvc3_bgzf_max_blocks", "pvc3_bgzf_slot_input", "pvc3_bgzf_slot_lengths", "pvc3_bgzf_submit",
 		   "pvc3_bgzf_wait", "pvc3_bgzf_deflate", "pvc3_bgzf_last_error",
-		   "pvc3_bgzf_inflater_create", "pvc3_bgzf_inflater_destroy", "pvc3_bgzf_inflater_blocks_in_flight", "pvc3_bgzf_inflater_input", "pvc3_bgzf_inflater_output", "pvc3_bgzf_inflater_blocks",
+		   "pvc3_bgzf_inflater_create", "pvc3_bgzf_inflater_destroy", "pvc3_bgzf_inflater_blocks_in_flight", "pvc3_bgzf_inflater_limit_in_flight", "pvc3_bgzf_inflater_input", "pvc3_bgzf_inflater_output", "pvc3_bgzf_inflater_blocks",
 		   "pvc3_bgzf_inflater_submit", "pvc3_bgzf_inflater_wait", "pvc3_bgzf_inflater_submit_device", "pvc3_bgzf_inflater_wait_device",
 		   "pvc3_bgzf_dev_create", "pvc3_bgzf_dev_destroy", "pvc3_bgzf_dev_input", "pvc3_bgzf_dev_capacity", "pvc3_bgzf_dev_submit", "pvc3_bgzf_dev_wait", "pvc3_bgzf_dev_fetch")
 BLOCK_DTYPE = np.dtype([("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8")])
@@ -50,6 +50,9 @@ def lib():
 			getattr(L, name).restype = C.c_void_p
 		L.pvc3_bgzf_inflater_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t]
 		L.pvc3_bgzf_inflater_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_float)]
+		L.pvc3_bgzf_inflater_limit_in_flight.argtypes = [C.c_void_p, C.c_uint32]
+		L.pvc3_bgzf_inflater_blocks_in_flight.argtypes = [C.c_void_p]
+		L.pvc3_bgzf_inflater_blocks_in_flight.restype = C.c_uint32
 		L.pvc3_bgzf_inflater_submit_device.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p, C.c_size_t]
 		L.pvc3_bgzf_inflater_wait_device.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float)]
 		L.pvc3_bgzf_dev_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]

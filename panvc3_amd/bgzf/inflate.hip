@@ -26,6 +26,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -62,9 +63,12 @@ struct code_info		// canonical decoding of the codes longer than the table's ind
 	uint32_t count[16], first[16], offset[16];
 };
 
+// t_ring: the single-kernel form keeps the output's last 32 KB here; the decoding kernel of the two-phase form (below) has no
+// output window at all, and 7 KB of LDS instead of 39.
+template <bool t_ring>
 struct lds_t
 {
-	uint8_t out[OUT_RING];
+	uint8_t out[t_ring ? OUT_RING : 16];
 	uint32_t ring[RING_WORDS];
 	uint16_t t_ll[1u << LL_BITS];		// symbol | length << 12; length 0: not in the table
 	uint16_t t_d[1u << D_BITS];
@@ -242,10 +246,29 @@ __device__ __forceinline__ bool long_code(uint32_t low_bits, uint32_t from_len, 
 	return false;
 }
 
+// ---- two phases (round 4) -----------------------------------------------------------------------------------------------------------
+// What makes a block slow is the symbol-by-symbol decoding, a chain of dependent scalar instructions that one wave per SIMD cannot
+// hide; what makes it expensive is the 32 KB window every block in flight holds in LDS while it is decoded — four blocks per CU,
+// and nothing else of a caller's fits next to them.  The two do not need each other: decoding needs the bit stream and the code
+// tables, the window is only needed to COPY.  So
+//   k_inflate_decode  (this kernel with t_tokens)   decodes; a literal goes straight to its place in the output in global memory,
+//                     a match becomes a token (position, length, distance) in global memory.  7 KB of LDS: twenty blocks per CU, whose
+//                     waves hide each other's latency;
+//   k_inflate_resolve takes a block's output — the literals are in place — into LDS whole, copies the matches in order, and stores
+//                     it back: a few instructions per match, the window held for a fraction of the time.
+// The single-kernel form stays (t_tokens = false; PVC3_BGZF_INFLATE_SINGLE=1 selects it) as the comparator.
+typedef unsigned long long token_t;		// position | length << 17 | distance << 32
+__device__ __forceinline__ token_t make_token(uint32_t pos, uint32_t length, uint32_t dist) { return (token_t) pos | ((token_t) length << 17) | ((token_t) dist << 32); }
+// Tokens of the block whose bytes are out[off, off + len): a match makes at least three bytes, so floor(len / 3) tokens at most, and
+// ranges of bytes that do not overlap get ranges of tokens that do not overlap.
+__device__ __forceinline__ size_t token_base(uint64_t out_off) { return (size_t) ((out_off + 2) / 3); }
+
+template <bool t_tokens>
 __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
-	uint8_t const *__restrict__ in, pvc3_bgzf_block const *__restrict__ blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t n_blocks)
+	uint8_t const *__restrict__ in, pvc3_bgzf_block const *__restrict__ blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t n_blocks,
+	token_t *__restrict__ tokens, uint32_t *__restrict__ n_tokens)
 {
-	__shared__ lds_t L;
+	__shared__ lds_t <!t_tokens> L;
 	unsigned const lane = threadIdx.x;
 
 	for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x)
@@ -264,6 +287,8 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 		// ring at a time, before the bytes that will take its place are written.
 		uint32_t flushed = 0;
 		uint8_t *const dst = out + blk.out_off;
+		token_t *const tok = t_tokens ? (tokens + token_base(blk.out_off)) : nullptr;
+		uint32_t n_tok = 0;
 		auto store_region = [&](uint32_t start, uint32_t n) {		// output bytes start .. start + n from the ring (they do not wrap)
 			uint8_t *g = dst + start;
 			uint32_t const ro = start & (OUT_RING - 1);
@@ -283,6 +308,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 			if (tail + lane < n) g[tail + lane] = L.out[ro + tail + lane];
 		};
 		auto make_room = [&]() {		// before up to 322 bytes are written at pos
+			if (t_tokens) return;
 			if (pos + 322 > flushed + OUT_RING) { store_region(flushed, OUT_HALF); flushed += OUT_HALF; }
 		};
 		// (Rings smaller than a match's reach only.)  A match that begins behind the ring: a byte whose place in the ring the next 322
@@ -324,7 +350,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 					br.refill();
 					uint32_t const v = br.take(8);
 					make_room();
-					if (0 == lane) OUTB(pos) = (uint8_t) v;
+					if (0 == lane) { if (t_tokens) dst[pos] = (uint8_t) v; else OUTB(pos) = (uint8_t) v; }
 					++pos;
 				}
 				continue;
@@ -427,7 +453,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 					if (pos + n_lit > want) { st = ST_OUTPUT_OVERFLOW; return; }
 					make_room();
 #ifndef PVC3_INF_SKIP_LIT
-					if (lane < n_lit) OUTB(pos + lane) = (uint8_t) lits;
+					if (lane < n_lit) { if (t_tokens) dst[pos + lane] = (uint8_t) lits; else OUTB(pos + lane) = (uint8_t) lits; }
 #endif
 #ifdef PVC3_INF_COUNT
 					c_lit += n_lit;
@@ -470,7 +496,8 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 					uint32_t const from = pos - dist;
 					make_room();
 #ifndef PVC3_INF_SKIP_COPY
-					if (OUT_RING < 32768 && from + OUT_RING < pos + 322) copy_far(from, dist, length);
+					if (t_tokens) { if (0 == lane) tok[n_tok] = make_token(pos, length, dist); ++n_tok; }
+					else if (OUT_RING < 32768 && from + OUT_RING < pos + 322) copy_far(from, dist, length);
 					else if (dist >= length)
 						for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = OUTB(from + j);
 					else if (1 == dist)
@@ -507,7 +534,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 				{
 					if (pos >= want) { st = ST_OUTPUT_OVERFLOW; break; }
 					make_room();
-					if (0 == lane) OUTB(pos) = (uint8_t) sym;
+					if (0 == lane) { if (t_tokens) dst[pos] = (uint8_t) sym; else OUTB(pos) = (uint8_t) sym; }
 					++pos;
 					continue;
 				}
@@ -531,7 +558,8 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 				if (pos + length > want) { st = ST_OUTPUT_OVERFLOW; break; }
 				uint32_t const from = pos - dist;
 				make_room();
-				if (OUT_RING < 32768 && from + OUT_RING < pos + 322) copy_far(from, dist, length);
+				if (t_tokens) { if (0 == lane) tok[n_tok] = make_token(pos, length, dist); ++n_tok; }
+				else if (OUT_RING < 32768 && from + OUT_RING < pos + 322) copy_far(from, dist, length);
 				else if (dist >= length)
 					for (uint32_t j = lane; j < length; j += WAVE) OUTB(pos + j) = OUTB(from + j);
 				else
@@ -542,7 +570,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 		if (ST_OK == st && br.consumed_bits() > uint64_t(8) * blk.in_len) st = ST_INPUT_OVERRUN;
 		if (ST_OK == st && pos != want) st = ST_LENGTH_MISMATCH;
 		__syncthreads();
-		if (ST_OK == st)
+		if (ST_OK == st && !t_tokens)
 		{
 			while (want - flushed > OUT_HALF) { store_region(flushed, OUT_HALF); flushed += OUT_HALF; }
 			store_region(flushed, want - flushed);
@@ -551,7 +579,72 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 		__threadfence();
 		if (0 == lane && want >= 20) { uint32_t const c[5] = {c_pass, c_slow, c_lit, c_match, c_tables}; for (int k = 0; k < 20; ++k) dst[k] = (uint8_t) (c[k / 4] >> (8 * (k & 3))); }
 #endif
-		if (0 == lane) status[b] = st;
+		if (0 == lane) { status[b] = st; if (t_tokens) n_tokens[b] = (ST_OK == st) ? n_tok : 0; }
+	}
+}
+
+// The second phase: a block's output, literals in place, into LDS whole; its matches copied in the order of the stream (a match may
+// copy what an earlier one made, and may overlap its own output); then back.  Tokens come 64 at a time through the lanes.
+constexpr unsigned RESOLVE_BYTES = 65536;
+__global__ __launch_bounds__(WAVE) void k_inflate_resolve(pvc3_bgzf_block const *__restrict__ blocks, uint8_t *__restrict__ out, uint32_t const *__restrict__ status, uint32_t n_blocks,
+	token_t const *__restrict__ tokens, uint32_t const *__restrict__ n_tokens)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t buf[RESOLVE_BYTES + 16];
+	unsigned const lane = threadIdx.x;
+	for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x)
+	{
+		uint32_t const n = uni(n_tokens[b]);
+		if (0 == n || ST_OK != uni(status[b])) continue;		// no match: the literals are the output
+		pvc3_bgzf_block const blk = blocks[b];
+		uint32_t const want = blk.out_len;
+		uint8_t *const dst = out + blk.out_off;
+		token_t const *tok = tokens + token_base(blk.out_off);
+		__syncthreads();
+		// in: bytes up to a dword boundary of the address, whole dwords, the rest.  Output byte i lies at B[i] = buf[a + i] with a
+		// chosen so that the dwords are dwords in LDS too.
+		uint32_t const head = (uint32_t) ((4 - (reinterpret_cast <uintptr_t>(dst) & 3)) & 3);
+		uint32_t const h = (head < want) ? head : want;
+		uint8_t *const B = buf + ((4 - h) & 3);
+		if (lane < h) B[lane] = dst[lane];
+		uint32_t const n_dw = (want - h) / 4;
+		{
+			uint32_t const *g32 = reinterpret_cast <uint32_t const *>(dst + h);
+			uint32_t *l32 = reinterpret_cast <uint32_t *>(B + h);
+			for (uint32_t i = lane; i < n_dw; i += WAVE) l32[i] = g32[i];
+		}
+		uint32_t const tail = h + 4 * n_dw;
+		if (tail + lane < want) B[tail + lane] = dst[tail + lane];
+		__syncthreads();
+		for (uint32_t t0 = 0; t0 < n; t0 += WAVE)
+		{
+			token_t const mine = (t0 + lane < n) ? tok[t0 + lane] : 0;
+			uint32_t const m_lo = (uint32_t) mine, m_hi = (uint32_t) (mine >> 32);
+			uint32_t const cnt = (n - t0 < WAVE) ? (n - t0) : WAVE;
+			for (uint32_t k = 0; k < cnt; ++k)
+			{
+				uint32_t const lo = (uint32_t) __builtin_amdgcn_readlane((int) m_lo, (int) k), dist = (uint32_t) __builtin_amdgcn_readlane((int) m_hi, (int) k);
+				uint32_t const pos = lo & 0x1ffffu, length = lo >> 17, from = pos - dist;
+				if (dist >= length)
+					for (uint32_t j = lane; j < length; j += WAVE) B[pos + j] = B[from + j];
+				else if (1 == dist)
+				{
+					uint8_t const v = B[from];
+					for (uint32_t j = lane; j < length; j += WAVE) B[pos + j] = v;
+				}
+				else
+					for (uint32_t j = lane; j < length; j += WAVE) B[pos + j] = B[from + j % dist];
+				__builtin_amdgcn_wave_barrier();		// (a wave's LDS operations are executed in order; the compiler must not move the next match's reads up)
+			}
+		}
+		__syncthreads();
+		// out
+		if (lane < h) dst[lane] = B[lane];
+		{
+			uint32_t *g32 = reinterpret_cast <uint32_t *>(dst + h);
+			uint32_t const *l32 = reinterpret_cast <uint32_t const *>(B + h);
+			for (uint32_t i = lane; i < n_dw; i += WAVE) g32[i] = l32[i];
+		}
+		if (tail + lane < want) dst[tail + lane] = B[tail + lane];
 	}
 }
 
@@ -576,11 +669,17 @@ struct pvc3_bgzf_inflater
 {
 	int device{};
 	size_t max_in{}, max_out{};
-	uint32_t max_blocks{}, n_slots{}, grid_max{};
+	uint32_t max_blocks{}, n_slots{}, grid_max{}, grid_full{};
 	hipStream_t stream{};
 	uint8_t *d_in{}, *d_out{};
 	pvc3_bgzf_block *d_blocks{};
 	uint32_t *d_status{};
+	// the two-phase form: the matches of every block between the two kernels
+	token_t *d_tokens{};
+	size_t tokens_cap{};				// in tokens
+	uint32_t *d_ntok{};
+	uint32_t grid_resolve{};
+	bool single{};						// PVC3_BGZF_INFLATE_SINGLE=1: the one-kernel form
 	// the device-resident form (pvc3_bgzf_inflater_submit_device): where the blocks' bytes went and their checksums
 	uint64_t *d_off{};
 	uint32_t *d_lens{}, *d_crc{};
@@ -597,6 +696,39 @@ struct pvc3_bgzf_inflater
 		bool busy{};
 	} slots[4];
 };
+
+namespace {
+
+// The kernels of one group of blocks on the handle's stream: the two phases (tokens for out_bytes of output), or the single kernel.
+int launch_inflate(pvc3_bgzf_inflater *h, uint8_t *d_out, size_t out_bytes, uint32_t n_blocks, hipEvent_t start, hipEvent_t stop)
+{
+	uint32_t const grid = (n_blocks < h->grid_max) ? n_blocks : h->grid_max;
+	if (!h->single)
+	{
+		size_t const need = out_bytes / 3 + n_blocks + 64;
+		if (need > h->tokens_cap)
+		{
+			HIP_TRY(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
+			if (h->d_tokens) { (void) hipFree(h->d_tokens); h->d_tokens = nullptr; h->tokens_cap = 0; }
+			HIP_TRY(hipMalloc((void **) &h->d_tokens, (need + need / 8) * sizeof(token_t)), "hipMalloc");
+			h->tokens_cap = need + need / 8;
+		}
+	}
+	HIP_TRY(hipEventRecord(start, h->stream), "hipEventRecord");
+	if (h->single)
+		hipLaunchKernelGGL(k_inflate_blocks <false>, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, d_out, h->d_status, n_blocks, (token_t *) nullptr, (uint32_t *) nullptr);
+	else
+	{
+		hipLaunchKernelGGL(k_inflate_blocks <true>, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
+		uint32_t const grid_b = (n_blocks < h->grid_resolve) ? n_blocks : h->grid_resolve;
+		hipLaunchKernelGGL(k_inflate_resolve, dim3(grid_b), dim3(WAVE), 0, h->stream, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
+	}
+	HIP_TRY(hipGetLastError(), "k_inflate_blocks");
+	HIP_TRY(hipEventRecord(stop, h->stream), "hipEventRecord");
+	return 0;
+}
+
+}
 
 extern "C" {
 
@@ -622,7 +754,7 @@ void pvc3_bgzf_inflater_destroy(pvc3_bgzf_inflater *h)
 	if (h->d_out) (void) hipFree(h->d_out);
 	if (h->d_blocks) (void) hipFree(h->d_blocks);
 	if (h->d_status) (void) hipFree(h->d_status);
-	for (void *p : {(void *) h->d_off, (void *) h->d_lens, (void *) h->d_crc, (void *) h->d_crc_tables}) if (p) (void) hipFree(p);
+	for (void *p : {(void *) h->d_off, (void *) h->d_lens, (void *) h->d_crc, (void *) h->d_crc_tables, (void *) h->d_tokens, (void *) h->d_ntok}) if (p) (void) hipFree(p);
 	if (h->stream) (void) hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -645,15 +777,23 @@ int pvc3_bgzf_inflater_create(int device, size_t max_in_bytes, size_t max_out_by
 	if (0 == rc)
 	{
 		int per_cu = 0;
-		check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_blocks, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+		char const *e = std::getenv("PVC3_BGZF_INFLATE_SINGLE");
+		h->single = e && '1' == e[0];
+		if (h->single) check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_blocks <false>, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+		else check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_blocks <true>, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
 		if (per_cu < 1) per_cu = 1;
 		h->grid_max = (uint32_t) prop.multiProcessorCount * (uint32_t) per_cu;
+		h->grid_full = h->grid_max;
+		int per_cu_b = 0;
+		check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, k_inflate_resolve, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+		h->grid_resolve = (uint32_t) prop.multiProcessorCount * (uint32_t) ((per_cu_b < 1) ? 1 : per_cu_b);
 	}
 	check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
 	if (0 == rc) check(hipMalloc((void **) &h->d_in, max_in_bytes + IN_SLACK), "hipMalloc");
 	if (0 == rc) check(hipMalloc((void **) &h->d_out, max_out_bytes), "hipMalloc");
 	if (0 == rc) check(hipMalloc((void **) &h->d_blocks, max_blocks * sizeof(pvc3_bgzf_block)), "hipMalloc");
 	if (0 == rc) check(hipMalloc((void **) &h->d_status, max_blocks * sizeof(uint32_t)), "hipMalloc");
+	if (0 == rc) check(hipMalloc((void **) &h->d_ntok, max_blocks * sizeof(uint32_t)), "hipMalloc");
 	for (uint32_t i = 0; i < n_slots && 0 == rc; ++i)
 	{
 		auto &s = h->slots[i];
@@ -671,6 +811,16 @@ int pvc3_bgzf_inflater_create(int device, size_t max_in_bytes, size_t max_out_by
 }
 
 uint32_t pvc3_bgzf_inflater_blocks_in_flight(pvc3_bgzf_inflater const *h) { return h ? h->grid_max : 0; }
+
+// Fewer blocks at a time than the chip's LDS holds (0: as many as it holds again): a caller whose other kernels run next to the
+// inflater's leaves them room — a block being inflated keeps 39 KB of its CU's LDS for milliseconds.
+int pvc3_bgzf_inflater_limit_in_flight(pvc3_bgzf_inflater *h, uint32_t blocks)
+{
+	if (!h) return fail(E_INVALID, "pvc3_bgzf_inflater_limit_in_flight: null argument");
+	if (0 == blocks || blocks > h->grid_full) blocks = h->grid_full;
+	h->grid_max = blocks;
+	return 0;
+}
 uint8_t *pvc3_bgzf_inflater_input(pvc3_bgzf_inflater *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].h_in : nullptr; }
 uint8_t *pvc3_bgzf_inflater_output(pvc3_bgzf_inflater *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].h_out : nullptr; }
 pvc3_bgzf_block *pvc3_bgzf_inflater_blocks(pvc3_bgzf_inflater *h, uint32_t slot) { return (h && slot < h->n_slots) ? h->slots[slot].h_blocks : nullptr; }
@@ -690,11 +840,7 @@ int pvc3_bgzf_inflater_submit(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t n_b
 	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
 	HIP_TRY(hipMemcpyAsync(h->d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
 	HIP_TRY(hipMemcpyAsync(h->d_blocks, s.h_blocks, n_blocks * sizeof(pvc3_bgzf_block), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
-	uint32_t const grid = (n_blocks < h->grid_max) ? n_blocks : h->grid_max;
-	HIP_TRY(hipEventRecord(s.start, h->stream), "hipEventRecord");
-	hipLaunchKernelGGL(k_inflate_blocks, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, h->d_out, h->d_status, n_blocks);
-	HIP_TRY(hipGetLastError(), "k_inflate_blocks");
-	HIP_TRY(hipEventRecord(s.stop, h->stream), "hipEventRecord");
+	if (int const rc = launch_inflate(h, h->d_out, h->max_out, n_blocks, s.start, s.stop)) return rc;
 	HIP_TRY(hipMemcpyAsync(s.h_status, h->d_status, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
 	if (out_bytes) HIP_TRY(hipMemcpyAsync(s.h_out, h->d_out, out_bytes, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
 	HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
@@ -739,11 +885,7 @@ int pvc3_bgzf_inflater_submit_device(pvc3_bgzf_inflater *h, uint32_t slot, uint3
 	HIP_TRY(hipMemcpyAsync(h->d_blocks, s.h_blocks, n_blocks * sizeof(pvc3_bgzf_block), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
 	HIP_TRY(hipMemcpyAsync(h->d_off, s.h_off, n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
 	HIP_TRY(hipMemcpyAsync(h->d_lens, s.h_lens, n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
-	uint32_t const grid = (n_blocks < h->grid_max) ? n_blocks : h->grid_max;
-	HIP_TRY(hipEventRecord(s.start, h->stream), "hipEventRecord");
-	hipLaunchKernelGGL(k_inflate_blocks, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, (uint8_t *) d_out, h->d_status, n_blocks);
-	HIP_TRY(hipGetLastError(), "k_inflate_blocks");
-	HIP_TRY(hipEventRecord(s.stop, h->stream), "hipEventRecord");
+	if (int const rc = launch_inflate(h, (uint8_t *) d_out, d_out_bytes, n_blocks, s.start, s.stop)) return rc;
 	hipLaunchKernelGGL(pvc3_crc::k_crc32_ranges, dim3((n_blocks < 4096) ? n_blocks : 4096), dim3(64), 0, h->stream, (uint8_t const *) d_out, h->d_off, h->d_lens, 0u, 0u, n_blocks, h->d_crc_tables, h->d_crc);
 	HIP_TRY(hipGetLastError(), "k_crc32_ranges");
 	HIP_TRY(hipMemcpyAsync(s.h_status, h->d_status, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");

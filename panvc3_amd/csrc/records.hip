@@ -24,14 +24,12 @@ constexpr uint32_t MAX_BLOCK_SIZE = 1u << 28;	// a record's block_size beyond th
 
 __device__ inline uint32_t ld32(uint8_t const *p)
 {
-	// two aligned dwords shifted into place (the buffers have slack behind their last byte)
+	// two aligned dwords shifted into place (the buffers have slack behind their last byte); both are requested at once, whatever
+	// the alignment: a second load that waits for a branch on the first doubles the latency of a hop along a chain of records
 	uintptr_t const a = (uintptr_t) p;
 	uint32_t const *q = (uint32_t const *) (a & ~(uintptr_t) 3);
-	uint32_t const sh = (uint32_t) (a & 3);
-	uint32_t const lo = q[0];
-	if (0 == sh) return lo;
-	uint32_t const hi = q[1];
-	return (lo >> (8 * sh)) | (hi << (32 - 8 * sh));
+	uint32_t const lo = q[0], hi = q[1];
+	return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t) (a & 3));
 }
 
 __device__ inline uint32_t ld16(uint8_t const *p) { return (uint32_t) p[0] | ((uint32_t) p[1] << 8); }
@@ -246,7 +244,9 @@ __global__ __launch_bounds__(256) void k_filter(uint8_t const *__restrict__ U, u
 }
 
 // ---- exclusive prefix sums (uint32 in, uint64 out, out[n] = total) ---------------------------------------------------------------------
-constexpr uint32_t SCAN_BLOCK = 1024, SCAN_PER_THREAD = 4, SCAN_TILE = SCAN_BLOCK * SCAN_PER_THREAD;
+// (Blocks of 256 threads: next to the two BGZF codecs' waves, which hold most of a CU's registers and LDS for milliseconds, a block
+// of sixteen waves waits until a CU is nearly empty — a scan of half a million numbers took a third of a millisecond that way.)
+constexpr uint32_t SCAN_BLOCK = 256, SCAN_PER_THREAD = 16, SCAN_TILE = SCAN_BLOCK * SCAN_PER_THREAD;
 
 __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t &block_total)
 {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t const *__restrict__ re
 }
 
 // What the next piece begins with: the (up to three) kept records that wait for their chunk of four, then the incomplete last record.
-__global__ __launch_bounds__(1024) void k_carry(uint8_t const *__restrict__ U, uint32_t end, rec_state *__restrict__ st, uint8_t *__restrict__ carry, uint32_t carry_cap)
+__global__ __launch_bounds__(256) void k_carry(uint8_t const *__restrict__ U, uint32_t end, rec_state *__restrict__ st, uint8_t *__restrict__ carry, uint32_t carry_cap)
 {
 	__shared__ uint32_t src[4], len[4], dst[5];
 	if (0 == threadIdx.x)
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(1024) void k_carry(uint8_t const *__restrict__ U, u
 	__syncthreads();
 	if (dst[4] > carry_cap) return;		// (the host reports PVC3_REC_E_CARRY)
 	for (uint32_t k = 0; k < 4; ++k)
-		for (uint32_t x = threadIdx.x; x < len[k]; x += 1024)
+		for (uint32_t x = threadIdx.x; x < len[k]; x += 256)
 			carry[dst[k] + x] = U[src[k] + x];
 }
 
@@ -837,7 +837,7 @@ int rec_launch_compact(uint32_t n_max, rec_frame_work const &w, rec_state *st, u
 
 int rec_launch_carry(uint8_t const *U, uint32_t end, rec_state *st, uint8_t *carry, uint32_t carry_cap, void *stream)
 {
-	hipLaunchKernelGGL(k_carry, dim3(1), dim3(1024), 0, (hipStream_t) stream, U, end, st, carry, carry_cap);
+	hipLaunchKernelGGL(k_carry, dim3(1), dim3(256), 0, (hipStream_t) stream, U, end, st, carry, carry_cap);
 	return (int) hipGetLastError();
 }
 

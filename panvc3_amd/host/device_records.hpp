@@ -56,6 +56,7 @@ struct device_records_options
 	std::size_t piece_compressed{std::size_t(48) << 20};		// compressed bytes read at a time at most
 	std::size_t piece_stream{std::size_t(160) << 20};		// uncompressed bytes of a piece at most
 	uint32_t gpu_blocks{0};									// blocks of a piece that go to the GPU in mode 0; 0: as many as it works on at a time
+	uint32_t inflate_in_flight{0};							// blocks the inflater works on at a time; 0: as many as the chip's LDS holds
 	uint32_t piece_blocks{0};								// BGZF blocks of a piece at most; 0: twice what the GPU inflates at a time (the GPU's share and the host's)
 	// the two codecs, made ahead of time by the caller (they are page-locked memory, which takes a while to get); null: made here
 	std::function <pvc3_bgzf_inflater *()> take_inflater;
@@ -128,6 +129,7 @@ inline device_records_result run_device_records(device_records_options const &op
 	cfg.max_stream_bytes = opt.piece_stream;
 	rec_check(pvc3_records_create(opt.ctx, &cfg, &records), "pvc3_records_create");
 	uint64_t const out_capacity = pvc3_bgzf_dev_capacity(deflater);
+	if (opt.inflate_in_flight) bgzf_check(pvc3_bgzf_inflater_limit_in_flight(inflater, opt.inflate_in_flight), "pvc3_bgzf_inflater_limit_in_flight");
 	uint32_t const gpu_at_a_time = opt.gpu_blocks ? opt.gpu_blocks : std::max <uint32_t>(1, pvc3_bgzf_inflater_blocks_in_flight(inflater));
 	uint32_t const piece_blocks = std::min <uint32_t>(max_blocks_in, opt.piece_blocks ? opt.piece_blocks : ((0 == opt.inflate_mode) ? 2 * gpu_at_a_time : max_blocks_in));
 	// the host's share of a piece at most (blocks of 64 KiB at most)

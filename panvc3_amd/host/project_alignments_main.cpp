@@ -572,6 +572,7 @@ int main(int argc, char **argv)
 			if (char const *e = std::getenv("PVC3_BGZF_CHUNK")) { std::size_t const v = (std::size_t) std::strtoull(e, nullptr, 10); if (v >= 1024) dro.piece_compressed = v; }
 			if (char const *e = std::getenv("PVC3_RECORDS_STREAM")) { std::size_t const v = (std::size_t) std::strtoull(e, nullptr, 10); if (v >= 65536) dro.piece_stream = v; }
 			if (char const *e = std::getenv("PVC3_RECORDS_BLOCKS")) { dro.piece_blocks = (uint32_t) std::max(1, std::atoi(e)); }
+			if (char const *e = std::getenv("PVC3_RECORDS_INFLATE_IN_FLIGHT")) { dro.inflate_in_flight = (uint32_t) std::max(1, std::atoi(e)); }		// (experiments: room for the other kernels next to the inflater's waves)
 			if (char const *e = std::getenv("PVC3_RECORDS_GPU_BLOCKS")) { dro.gpu_blocks = (uint32_t) std::max(1, std::atoi(e)); }		// (tests: a host's share in small files)
 			// The two codecs are mostly page-locked memory, which takes the runtime a tenth of a second or two to hand out: they are made
 			// on threads of their own as soon as the GPU is up, while the index file and the FASTA are read.

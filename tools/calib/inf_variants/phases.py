@@ -1,0 +1,36 @@
+"""k_inflate_blocks in one kernel (PVC3_BGZF_INFLATE_SINGLE=1: the block's last 32 KB of output in LDS) against the two phases
+(k_inflate_blocks<tokens> + k_inflate_resolve).  Timed on zlib level-6 streams of BAM records, 1 024 to 4 096 blocks a launch.
+usage (on the GPU box): python tools/calib/inf_variants/phases.py"""
+import os, subprocess, sys
+here = os.path.dirname(os.path.abspath(__file__))
+root = os.path.dirname(os.path.dirname(os.path.dirname(here)))
+code = r'''
+import sys, zlib, gzip, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tools"))
+from panvc3_amd import bgzf
+raw = gzip.open("/tmp/pvc3_bgzf_bench/in.bam","rb").read()
+have = [raw[i*65280:(i+1)*65280] for i in range(len(raw)//65280)]
+cache = {}
+def z(p):
+    if p not in cache:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15); cache[p] = c.compress(p) + c.flush()
+    return cache[p]
+n_max = 4096
+pieces = [have[i %% len(have)] for i in range(n_max)]
+streams = [z(p) for p in pieces]
+inf = bgzf.BlockInflater(0, max_in=n_max*30000, max_out=n_max*65280, max_blocks=n_max, n_slots=1)
+L = bgzf.lib()
+line = ["single" if os.environ.get("PVC3_BGZF_INFLATE_SINGLE") else "two phases", "in flight %%d" %% L.pvc3_bgzf_inflater_blocks_in_flight(inf._h)]
+for count in (256, 1024, 2048, 2560, 4096):
+    got, status, ms = inf.inflate(streams[:count], [len(p) for p in pieces[:count]], repeats=3)
+    ok = (not status.any()) and got == pieces[:count]
+    line.append("%%d blocks %%.2f ms = %%.1f GB/s%%s" %% (count, ms, sum(len(p) for p in pieces[:count]) / ms / 1e6, "" if ok else " MISMATCH"))
+print("; ".join(line), flush=True)
+''' % (root, root)
+sys.path.insert(0, os.path.join(root, "tools"))
+import cli_e2e
+cli_e2e.prepare("/tmp/pvc3_bgzf_bench", 0.05, 1)
+for single in (("",) if "two" in sys.argv[1:] else ("", "1")):
+	env = dict(os.environ)
+	if single: env["PVC3_BGZF_INFLATE_SINGLE"] = single
+	subprocess.run([sys.executable, "-c", code], env=env)

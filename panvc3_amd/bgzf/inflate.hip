@@ -182,8 +182,8 @@ __device__ __forceinline__ void litlen_decode(uint32_t e, uint32_t &sym, uint32_
 // Canonical codes of lens[0 .. n) (RFC 1951 3.2.2) into a look-up table indexed by the next `bits` bits of the stream
 // (entry = symbol | length << 12, or litlen_entry) and, for longer codes, the symbols sorted by (length, symbol) with the first code and the
 // count of every length.  Returns false for an over-subscribed code.  Called by the whole wave.
-template <bool t_litlen>
-__device__ bool build_table(uint8_t const *lens, uint32_t n, uint32_t bits, uint16_t *table, uint16_t *sorted, code_info &ci, uint32_t *flag)
+template <typename t_entry, typename t_make>
+__device__ bool build_table(uint8_t const *lens, uint32_t n, uint32_t bits, t_entry *table, uint16_t *sorted, code_info &ci, uint32_t *flag, t_make const &make_entry)
 {
 	unsigned const lane = threadIdx.x;
 	for (uint32_t i = lane; i < (1u << bits); i += WAVE) table[i] = 0;
@@ -221,7 +221,7 @@ __device__ bool build_table(uint8_t const *lens, uint32_t n, uint32_t bits, uint
 		if (l <= bits)
 		{
 			uint32_t const r = __brev(code) >> (32 - l);
-			uint16_t const e = t_litlen ? litlen_entry(s, l) : (uint16_t) (s | (l << 12));
+			t_entry const e = (t_entry) make_entry(s, l);
 			for (uint32_t j = r; j < (1u << bits); j += (1u << l)) table[j] = e;
 		}
 	}
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 #ifdef PVC3_INF_COUNT
 			++c_tables;
 #endif
-			if (!build_table <true>(L.lens, n_ll, LL_BITS, L.t_ll, L.sorted_ll, L.ll, &L.flag) || !build_table <false>(lens_d, n_d, D_BITS, L.t_d, L.sorted_d, L.d, &L.flag))
+			if (!build_table(L.lens, n_ll, LL_BITS, L.t_ll, L.sorted_ll, L.ll, &L.flag, [](uint32_t sy, uint32_t le) { return litlen_entry(sy, le); }) || !build_table(lens_d, n_d, D_BITS, L.t_d, L.sorted_d, L.d, &L.flag, [](uint32_t sy, uint32_t le) { return (uint16_t) (sy | (le << 12)); }))
 			{ st = ST_BAD_CODE_LENGTHS; break; }
 
 			// ---- the symbols -----------------------------------------------------------------------------------------------------------
@@ -583,6 +583,258 @@ __global__ __launch_bounds__(WAVE) void k_inflate_blocks(
 	}
 }
 
+// ---- the decoding kernel, second form ------------------------------------------------------------------------------------------------
+// Table entries that hold everything a lane needs to decode its symbol without a branch.
+//   literal / length: value (the literal's byte | the length's base) | code length << 9 | extra bits << 13 | kind << 16
+//   distance:         base | code length << 15 | extra bits << 19 | 1 << 23
+// 0: no such code in the table (longer than its index, or not a symbol of the format).
+enum : uint32_t { K_NONE = 0, K_LITERAL = 1, K_MATCH = 2, K_END = 3 };
+struct { __device__ __forceinline__ uint32_t operator()(uint32_t sym, uint32_t len) const
+{
+	if (sym < 256) return sym | (len << 9) | (K_LITERAL << 16);
+	if (256 == sym) return (len << 9) | (K_END << 16);
+	if (sym > 285) return 0;
+	uint32_t const ls = sym - 257;
+	uint32_t const x = (ls < 8 || 28 == ls) ? 0 : ((ls - 4) >> 2);
+	uint32_t const base = (ls < 8) ? (3 + ls) : (28 == ls) ? 258 : (3 + ((4 + ((ls - 4) & 3)) << x));		// RFC 1951 3.2.5
+	return base | (len << 9) | (x << 13) | (K_MATCH << 16);
+} } const litlen_entry32;
+struct { __device__ __forceinline__ uint32_t operator()(uint32_t ds, uint32_t len) const
+{
+	if (ds > 29) return 0;
+	uint32_t const x = (ds < 4) ? 0 : ((ds >> 1) - 1);
+	uint32_t const base = (ds < 4) ? (1 + ds) : (1 + ((2 + (ds & 1)) << x));
+	return base | (len << 15) | (x << 19) | (1u << 23);
+} } const dist_entry32;
+
+struct lds_decode
+{
+	uint32_t ring[RING_WORDS];
+	uint32_t t_ll[1u << LL_BITS];
+	uint32_t t_d[1u << D_BITS];
+	uint16_t t_cl[1u << CL_BITS];
+	uint16_t sorted_ll[288], sorted_d[32];
+	uint8_t lens[320];
+	code_info ll, d;
+	uint32_t flag;
+};
+
+// A symbol takes 10 + 5 + 9 + 13 = 37 bits at most through the tables and the window holds 97: the walk goes on while a symbol
+// begins at bit 60 or before.
+constexpr unsigned WALK_LAST = 60;
+
+__global__ __launch_bounds__(WAVE) void k_inflate_decode(
+	uint8_t const *__restrict__ in, pvc3_bgzf_block const *__restrict__ blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t n_blocks,
+	token_t *__restrict__ tokens, uint32_t *__restrict__ n_tokens)
+{
+	__shared__ lds_decode L;
+	unsigned const lane = threadIdx.x;
+
+	for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x)
+	{
+		pvc3_bgzf_block const blk = blocks[b];
+		uint32_t const want = blk.out_len;
+		if (want > OUT_CAP) { if (0 == lane) status[b] = ST_TOO_LARGE; continue; }
+		bit_reader br;
+		br.start(in + blk.in_off, blk.in_len, L.ring);
+		uint32_t pos = 0, st = ST_OK;
+		uint8_t *const dst = out + blk.out_off;
+		token_t *const tok = tokens + token_base(blk.out_off);
+		uint32_t n_tok = 0;
+
+		for (bool last = false; !last && ST_OK == st; )
+		{
+			br.refill();
+			last = 0 != br.take(1);
+			uint32_t const type = br.take(2);
+			if (0 == type)
+			{
+				// stored (RFC 1951 3.2.4): to the next byte boundary, LEN, NLEN, the bytes
+				br.drop((uint32_t) ((0 - br.consumed_bits()) & 7));
+				br.refill();
+				uint32_t const len = br.take(16), nlen = br.take(16);
+				if ((len ^ nlen) != 0xffff) { st = ST_BAD_STORED; break; }
+				if (pos + len > want) { st = ST_OUTPUT_OVERFLOW; break; }
+				for (uint32_t i = 0; i < len; ++i)
+				{
+					br.refill();
+					uint32_t const v = br.take(8);
+					if (0 == lane) dst[pos] = (uint8_t) v;
+					++pos;
+				}
+				continue;
+			}
+			if (3 == type) { st = ST_BAD_BLOCK_TYPE; break; }
+			uint32_t n_ll, n_d;
+			if (1 == type)
+			{
+				// fixed codes (3.2.6)
+				n_ll = 288; n_d = 30;
+				for (uint32_t s = lane; s < 288; s += WAVE) L.lens[s] = (uint8_t) ((s < 144) ? 8 : (s < 256) ? 9 : (s < 280) ? 7 : 8);
+				if (lane < 30) L.lens[288 + lane] = 5;
+				__syncthreads();
+			}
+			else
+			{
+				// dynamic codes (3.2.7)
+				br.refill();
+				n_ll = br.take(5) + 257; n_d = br.take(5) + 1;
+				uint32_t const n_cl = br.take(4) + 4;
+				uint64_t cl_lens = 0;		// three bits per symbol of the code length alphabet
+				for (uint32_t i = 0; i < n_cl; ++i)
+				{
+					br.refill();
+					cl_lens |= uint64_t(br.take(3)) << (3 * c_cl_order[i]);
+				}
+				if (n_ll > 286 || n_d > 30) { st = ST_BAD_CODE_LENGTHS; break; }
+				{
+					// the code length code: 19 symbols, one per lane
+					uint32_t const l = (lane < 19) ? (uint32_t) ((cl_lens >> (3 * lane)) & 7) : 0;
+					for (uint32_t i = lane; i < (1u << CL_BITS); i += WAVE) L.t_cl[i] = 0;
+					__syncthreads();
+					uint32_t code = 0, left = 1, mine = 0;
+					bool ok = true;
+					for (uint32_t k = 1; k < 8; ++k)
+					{
+						uint64_t const same = __ballot(l == k);
+						uint32_t const c = (uint32_t) __popcll(same);
+						left <<= 1;
+						if (c > left) ok = false;
+						left -= (c > left) ? left : c;
+						if (l == k) mine = code + (uint32_t) __popcll(same & ((uint64_t(1) << lane) - 1));
+						code = (code + c) << 1;
+					}
+					if (!ok) { st = ST_BAD_CODE_LENGTHS; break; }
+					if (l)
+					{
+						uint32_t const r = __brev(mine) >> (32 - l);
+						uint16_t const e = (uint16_t) (lane | (l << 12));
+						for (uint32_t j = r; j < (1u << CL_BITS); j += (1u << l)) L.t_cl[j] = e;
+					}
+					__syncthreads();
+				}
+				uint32_t const n = n_ll + n_d;
+				uint32_t i = 0, prev = 0;
+				while (i < n && ST_OK == st)
+				{
+					br.refill();
+					uint32_t const e = uni(L.t_cl[br.peek(CL_BITS)]);
+					uint32_t const l = e >> 12, sym = e & 0xfff;
+					if (0 == l) { st = ST_BAD_CODE_LENGTHS; break; }
+					br.drop(l);
+					uint32_t rep = 1, v = sym;
+					if (16 == sym) { if (0 == i) { st = ST_BAD_CODE_LENGTHS; break; } rep = 3 + br.take(2); v = prev; }
+					else if (17 == sym) { rep = 3 + br.take(3); v = 0; }
+					else if (18 == sym) { rep = 11 + br.take(7); v = 0; }
+					if (i + rep > n) { st = ST_BAD_CODE_LENGTHS; break; }
+					for (uint32_t r = lane; r < rep; r += WAVE) L.lens[i + r] = (uint8_t) v;
+					i += rep; prev = v;
+				}
+				if (ST_OK != st) break;
+				__syncthreads();
+				if (0 == L.lens[256]) { st = ST_BAD_CODE_LENGTHS; break; }		// no end-of-block code
+			}
+			uint8_t const *lens_d = L.lens + ((1 == type) ? 288 : n_ll);
+			if (!build_table(L.lens, n_ll, LL_BITS, L.t_ll, L.sorted_ll, L.ll, &L.flag, litlen_entry32) || !build_table(lens_d, n_d, D_BITS, L.t_d, L.sorted_d, L.d, &L.flag, dist_entry32))
+			{ st = ST_BAD_CODE_LENGTHS; break; }
+
+			// ---- the symbols -----------------------------------------------------------------------------------------------------------
+			// One pass: lane k decodes the symbol that would begin at bit k of the window WHOLE — the literal, or the length with
+			// its extra bits, the distance code behind them (a second look-up) and its extra bits: 37 bits at most, and the window
+			// holds 97 — and says how many bits it takes and how many bytes it makes.  A scalar walk then only follows the chain
+			// (o, o + bits of the symbol at o, ...: one v_readlane and a few scalar instructions per symbol) and hands every symbol
+			// on it the place of its output; after the walk the lanes on the chain store — a literal its byte, a match its token.
+			// Codes longer than the tables' index (rare) go through the one-symbol path behind the walk.
+			for (bool end_of_block = false; !end_of_block && ST_OK == st; )
+			{
+				br.refill();
+				uint64_t const mine = br.from_bit(lane);
+				uint32_t const e = L.t_ll[(uint32_t) mine & ((1u << LL_BITS) - 1)];
+				uint32_t const l = (e >> 9) & 15, x = (e >> 13) & 7, kind = e >> 16;
+				uint32_t const length = (e & 0x1ff) + __builtin_amdgcn_ubfe((uint32_t) (mine >> l), 0, x);		// (a literal's byte, for a literal)
+				uint32_t const behind = (uint32_t) (mine >> (l + x));
+				uint32_t const ed = L.t_d[behind & ((1u << D_BITS) - 1)];
+				uint32_t const ld = (ed >> 15) & 15, xd = (ed >> 19) & 15;
+				uint32_t const dist = (ed & 0x7fff) + __builtin_amdgcn_ubfe(behind >> ld, 0, xd);
+				bool const is_match = K_MATCH == kind && 0 != (ed >> 23);
+				// bits | end of block << 7 | bytes << 8; no bits: the walk stops here
+				uint32_t const packed = (K_LITERAL == kind) ? (l | (1u << 8)) : is_match ? ((l + x + ld + xd) | (length << 8)) : (K_END == kind) ? (l | 0x80u) : 0u;
+				uint32_t o = 0, made = 0;
+				uint64_t chain = 0;
+				uint32_t place = 0;
+				bool slow = false;
+				while (o <= WALK_LAST)
+				{
+					uint32_t const p = (uint32_t) __builtin_amdgcn_readlane((int) packed, (int) o);
+					if (0 == (p & 0x7f)) { slow = true; break; }
+					place = (lane == o) ? made : place;
+					chain |= uint64_t(1) << o;
+					made += p >> 8;
+					o += p & 0x7f;
+					if (p & 0x80) { end_of_block = true; break; }
+				}
+				if (pos + made > want) { st = ST_OUTPUT_OVERFLOW; break; }
+				bool const on_chain = 0 != ((chain >> lane) & 1);
+				uint32_t const at = pos + place;
+				if (on_chain && K_LITERAL == kind) dst[at] = (uint8_t) e;
+				uint64_t const matches = __ballot(on_chain && is_match);
+				if (matches)
+				{
+					if (__ballot(on_chain && is_match && dist > at)) { st = ST_BAD_DISTANCE; break; }
+					if (on_chain && is_match)
+						tok[n_tok + __builtin_amdgcn_mbcnt_hi((uint32_t) (matches >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) matches, 0))] = make_token(at, length, dist);
+					n_tok += (uint32_t) __popcll(matches);
+				}
+				pos += made;
+				br.drop(o);
+				if (!slow) continue;
+
+				// one symbol the long way: a code longer than the table's index, or one that does not exist
+				br.refill();
+				uint32_t e1 = uni(L.t_ll[br.peek(LL_BITS)]);
+				if (0 == e1)
+				{
+					uint32_t sym = 0, l1 = 0;
+					if (!long_code(br.low32(), LL_BITS + 1, L.sorted_ll, L.ll, sym, l1)) { st = ST_BAD_SYMBOL; break; }
+					e1 = litlen_entry32(sym, l1);
+					if (0 == e1) { st = ST_BAD_SYMBOL; break; }
+				}
+				br.drop((e1 >> 9) & 15);
+				uint32_t const kind1 = e1 >> 16;
+				if (K_LITERAL == kind1)
+				{
+					if (pos >= want) { st = ST_OUTPUT_OVERFLOW; break; }
+					if (0 == lane) dst[pos] = (uint8_t) e1;
+					++pos;
+					continue;
+				}
+				if (K_END == kind1) { end_of_block = true; break; }
+				uint32_t const length1 = (e1 & 0x1ff) + br.take((e1 >> 13) & 7);
+				br.refill();
+				uint32_t ed1 = uni(L.t_d[br.peek(D_BITS)]);
+				if (0 == ed1)
+				{
+					uint32_t ds = 0, l1 = 0;
+					if (!long_code(br.low32(), D_BITS + 1, L.sorted_d, L.d, ds, l1)) { st = ST_BAD_SYMBOL; break; }
+					ed1 = dist_entry32(ds, l1);
+					if (0 == ed1) { st = ST_BAD_SYMBOL; break; }
+				}
+				br.drop((ed1 >> 15) & 15);
+				uint32_t const dist1 = (ed1 & 0x7fff) + br.take((ed1 >> 19) & 15);
+				if (dist1 > pos) { st = ST_BAD_DISTANCE; break; }
+				if (pos + length1 > want) { st = ST_OUTPUT_OVERFLOW; break; }
+				if (0 == lane) tok[n_tok] = make_token(pos, length1, dist1);
+				++n_tok;
+				pos += length1;
+			}
+		}
+		if (ST_OK == st && br.consumed_bits() > uint64_t(8) * blk.in_len) st = ST_INPUT_OVERRUN;
+		if (ST_OK == st && pos != want) st = ST_LENGTH_MISMATCH;
+		if (0 == lane) { status[b] = st; n_tokens[b] = (ST_OK == st) ? n_tok : 0; }
+		__syncthreads();		// the tables are the next block's from here
+	}
+}
+
 // The second phase: a block's output, literals in place, into LDS whole; its matches copied in the order of the stream (a match may
 // copy what an earlier one made, and may overlap its own output); then back.  Tokens come 64 at a time through the lanes.
 constexpr unsigned RESOLVE_BYTES = 65536;
@@ -648,6 +900,121 @@ __global__ __launch_bounds__(WAVE) void k_inflate_resolve(pvc3_bgzf_block const 
 	}
 }
 
+// The second phase, second form.  What the first form spends per match is the latency of LDS — read, wait, write — 64 lanes wide for
+// a dozen bytes.  Most matches of a stretch do not depend on each other (they copy from a record or two back), so: the matches come
+// 64 at a time, one per lane; a lane finds the earlier matches of the 64 whose output it reads (their places ascend: two binary
+// searches through ds_bpermute, and none at all when every source lies before the first place of the 64 — the usual case); then, in
+// rounds, every match whose sources are all written copies at once — each lane its own, five aligned dwords in and up to 16
+// bytes out — and the few that are long, or repeat a pattern of their own output, go one at a time across the lanes as before.
+constexpr unsigned RESOLVE_SLACK = 48;		// the block may begin 15 bytes in, and a lane reads 19 bytes past its match's first
+constexpr unsigned LANE_COPY_MAX = 16;
+__global__ __launch_bounds__(WAVE) void k_inflate_resolve_lanes(pvc3_bgzf_block const *__restrict__ blocks, uint8_t *__restrict__ out, uint32_t const *__restrict__ status, uint32_t n_blocks,
+	token_t const *__restrict__ tokens, uint32_t const *__restrict__ n_tokens)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t buf[RESOLVE_BYTES + RESOLVE_SLACK];
+	unsigned const lane = threadIdx.x;
+	for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x)
+	{
+		uint32_t const n = uni(n_tokens[b]);
+		if (0 == n || ST_OK != uni(status[b])) continue;		// no match: the literals are the output
+		pvc3_bgzf_block const blk = blocks[b];
+		uint32_t const want = blk.out_len;
+		uint8_t *const dst = out + blk.out_off;
+		token_t const *tok = tokens + token_base(blk.out_off);
+		token_t mine = (lane < n) ? tok[lane] : 0;
+		__syncthreads();
+		// in: bytes up to a 16-byte boundary of the address, whole 16 bytes, the rest.  Output byte i lies at B[i] = buf[a + i] with a
+		// chosen so that the boundary is one in LDS too.
+		uint32_t const head = (uint32_t) ((16 - (reinterpret_cast <uintptr_t>(dst) & 15)) & 15);
+		uint32_t const h = (head < want) ? head : want;
+		uint32_t const b_off = (16 - head) & 15;
+		uint8_t *const B = buf + b_off;
+		if (lane < h) B[lane] = dst[lane];
+		uint32_t const n_q = (want - h) / 16;
+		{
+			uint4 const *g = reinterpret_cast <uint4 const *>(dst + h);
+			uint4 *l = reinterpret_cast <uint4 *>(B + h);
+			for (uint32_t i = lane; i < n_q; i += WAVE) l[i] = g[i];
+		}
+		uint32_t const tail = h + 16 * n_q;
+		if (tail + lane < want) B[tail + lane] = dst[tail + lane];
+		__syncthreads();
+		uint32_t const *const words = reinterpret_cast <uint32_t const *>(buf);
+		for (uint32_t t0 = 0; t0 < n; t0 += WAVE)
+		{
+			bool const valid = t0 + lane < n;
+			uint32_t const m_lo = (uint32_t) mine, dist = (uint32_t) (mine >> 32);
+			uint32_t const pos = valid ? (m_lo & 0x1ffffu) : 0xffffffffu, length = valid ? (m_lo >> 17) : 0, from = pos - dist;
+			uint32_t const end = valid ? (pos + length) : 0xffffffffu;
+			uint32_t const src_end = from + ((dist < length) ? dist : length);
+			if (t0 + WAVE < n) mine = (t0 + WAVE + lane < n) ? tok[t0 + WAVE + lane] : 0;		// the next 64 on their way
+			// the earlier matches of these 64 whose output this one reads: q .. p - 1, as a mask
+			uint64_t needs = 0;
+			uint32_t const first_pos = (uint32_t) __builtin_amdgcn_readfirstlane((int) pos);
+			if (__ballot(valid && src_end > first_pos))
+			{
+				uint32_t q = 0, p_ = 0;		// how many ends lie at or before my source's first byte; how many places lie before my source's end
+				for (uint32_t step = 32; step; step >>= 1)
+				{
+					uint32_t const e_q = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (4 * (q + step - 1)), (int) end);
+					uint32_t const p_p = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (4 * (p_ + step - 1)), (int) pos);
+					if (e_q <= from) q += step;
+					if (p_p < src_end) p_ += step;
+				}
+				uint32_t const hi = (p_ < lane) ? p_ : lane;
+				if (valid && q < hi) needs = ((uint64_t(1) << hi) - 1) & ~((uint64_t(1) << q) - 1);
+			}
+			bool const by_lane = valid && length <= LANE_COPY_MAX && (dist >= length || 1 == dist);
+			uint64_t undone = __ballot(valid);
+			while (undone)
+			{
+				bool const ready = 0 != ((undone >> lane) & 1) && 0 == (undone & needs);
+				uint64_t const round = __ballot(ready);
+				if (__ballot(ready && by_lane))
+				{
+					if (ready && by_lane)
+					{
+						uint32_t const a = b_off + from;
+						uint32_t const *w = words + (a >> 2);
+						uint32_t const w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+						uint32_t d[4] = {__builtin_amdgcn_alignbyte(w1, w0, a & 3), __builtin_amdgcn_alignbyte(w2, w1, a & 3), __builtin_amdgcn_alignbyte(w3, w2, a & 3), __builtin_amdgcn_alignbyte(w4, w3, a & 3)};
+						if (1 == dist) d[0] = d[1] = d[2] = d[3] = (d[0] & 0xff) * 0x01010101u;
+#pragma unroll
+						for (uint32_t j = 0; j < LANE_COPY_MAX; ++j)
+							if (j < length) B[pos + j] = (uint8_t) (d[j / 4] >> (8 * (j % 4)));
+					}
+				}
+				for (uint64_t rest = round & ~__ballot(ready && by_lane); rest; rest &= rest - 1)
+				{
+					uint32_t const k = (uint32_t) __builtin_ctzll(rest);
+					uint32_t const k_lo = (uint32_t) __builtin_amdgcn_readlane((int) m_lo, (int) k), k_dist = (uint32_t) __builtin_amdgcn_readlane((int) dist, (int) k);
+					uint32_t const k_pos = k_lo & 0x1ffffu, k_len = k_lo >> 17, k_from = k_pos - k_dist;
+					if (k_dist >= k_len)
+						for (uint32_t j = lane; j < k_len; j += WAVE) B[k_pos + j] = B[k_from + j];
+					else if (1 == k_dist)
+					{
+						uint8_t const v = B[k_from];
+						for (uint32_t j = lane; j < k_len; j += WAVE) B[k_pos + j] = v;
+					}
+					else
+						for (uint32_t j = lane; j < k_len; j += WAVE) B[k_pos + j] = B[k_from + j % k_dist];
+				}
+				undone &= ~round;
+				__builtin_amdgcn_wave_barrier();		// (a wave's LDS operations are executed in order; the compiler must not move the next round's reads up)
+			}
+		}
+		__syncthreads();
+		// out
+		if (lane < h) dst[lane] = B[lane];
+		{
+			uint4 *g = reinterpret_cast <uint4 *>(dst + h);
+			uint4 const *l = reinterpret_cast <uint4 const *>(B + h);
+			for (uint32_t i = lane; i < n_q; i += WAVE) g[i] = l[i];
+		}
+		if (tail + lane < want) dst[tail + lane] = B[tail + lane];
+	}
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------
 
 int fail(int code, char const *what, hipError_t e = hipSuccess)
@@ -680,6 +1047,7 @@ struct pvc3_bgzf_inflater
 	uint32_t *d_ntok{};
 	uint32_t grid_resolve{};
 	bool single{};						// PVC3_BGZF_INFLATE_SINGLE=1: the one-kernel form
+	bool decode_v1{}, resolve_v1{};		// PVC3_BGZF_INFLATE_DECODE=1, PVC3_BGZF_INFLATE_RESOLVE=1: the first forms of the two phases
 	// the device-resident form (pvc3_bgzf_inflater_submit_device): where the blocks' bytes went and their checksums
 	uint64_t *d_off{};
 	uint32_t *d_lens{}, *d_crc{};
@@ -719,9 +1087,11 @@ int launch_inflate(pvc3_bgzf_inflater *h, uint8_t *d_out, size_t out_bytes, uint
 		hipLaunchKernelGGL(k_inflate_blocks <false>, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, d_out, h->d_status, n_blocks, (token_t *) nullptr, (uint32_t *) nullptr);
 	else
 	{
-		hipLaunchKernelGGL(k_inflate_blocks <true>, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
+		if (h->decode_v1) hipLaunchKernelGGL(k_inflate_blocks <true>, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
+		else hipLaunchKernelGGL(k_inflate_decode, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
 		uint32_t const grid_b = (n_blocks < h->grid_resolve) ? n_blocks : h->grid_resolve;
-		hipLaunchKernelGGL(k_inflate_resolve, dim3(grid_b), dim3(WAVE), 0, h->stream, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
+		if (h->resolve_v1) hipLaunchKernelGGL(k_inflate_resolve, dim3(grid_b), dim3(WAVE), 0, h->stream, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
+		else hipLaunchKernelGGL(k_inflate_resolve_lanes, dim3(grid_b), dim3(WAVE), 0, h->stream, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
 	}
 	HIP_TRY(hipGetLastError(), "k_inflate_blocks");
 	HIP_TRY(hipEventRecord(stop, h->stream), "hipEventRecord");
@@ -779,8 +1149,12 @@ int pvc3_bgzf_inflater_create(int device, size_t max_in_bytes, size_t max_out_by
 		int per_cu = 0;
 		char const *e = std::getenv("PVC3_BGZF_INFLATE_SINGLE");
 		h->single = e && '1' == e[0];
+		char const *e1 = std::getenv("PVC3_BGZF_INFLATE_DECODE"), *e2 = std::getenv("PVC3_BGZF_INFLATE_RESOLVE");
+		h->decode_v1 = e1 && '1' == e1[0];
+		h->resolve_v1 = e2 && '1' == e2[0];
 		if (h->single) check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_blocks <false>, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-		else check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_blocks <true>, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+		else if (h->decode_v1) check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_blocks <true>, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+		else check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate_decode, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
 		if (per_cu < 1) per_cu = 1;
 		h->grid_max = (uint32_t) prop.multiProcessorCount * (uint32_t) per_cu;
 		h->grid_full = h->grid_max;

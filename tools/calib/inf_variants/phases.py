@@ -1,5 +1,5 @@
-"""k_inflate_blocks in one kernel (PVC3_BGZF_INFLATE_SINGLE=1: the block's last 32 KB of output in LDS) against the two phases
-(k_inflate_blocks<tokens> + k_inflate_resolve).  Timed on zlib level-6 streams of BAM records, 1 024 to 4 096 blocks a launch.
+"""k_inflate_blocks in one kernel (PVC3_BGZF_INFLATE_SINGLE=1: the block's last 32 KB of output in LDS) against the two phases,
+first forms (k_inflate_blocks<tokens>, k_inflate_resolve) and second (k_inflate_decode, k_inflate_resolve_lanes).  Timed on zlib level-6 streams of BAM records, 1 024 to 4 096 blocks a launch.
 usage (on the GPU box): python tools/calib/inf_variants/phases.py"""
 import os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
@@ -20,7 +20,7 @@ pieces = [have[i %% len(have)] for i in range(n_max)]
 streams = [z(p) for p in pieces]
 inf = bgzf.BlockInflater(0, max_in=n_max*30000, max_out=n_max*65280, max_blocks=n_max, n_slots=1)
 L = bgzf.lib()
-line = ["single" if os.environ.get("PVC3_BGZF_INFLATE_SINGLE") else "two phases", "in flight %%d" %% L.pvc3_bgzf_inflater_blocks_in_flight(inf._h)]
+line = [os.environ.get("PVC3_VARIANT", ""), "in flight %%d" %% L.pvc3_bgzf_inflater_blocks_in_flight(inf._h)]
 for count in (256, 1024, 2048, 2560, 4096):
     got, status, ms = inf.inflate(streams[:count], [len(p) for p in pieces[:count]], repeats=3)
     ok = (not status.any()) and got == pieces[:count]
@@ -30,7 +30,8 @@ print("; ".join(line), flush=True)
 sys.path.insert(0, os.path.join(root, "tools"))
 import cli_e2e
 cli_e2e.prepare("/tmp/pvc3_bgzf_bench", 0.05, 1)
-for single in (("",) if "two" in sys.argv[1:] else ("", "1")):
-	env = dict(os.environ)
-	if single: env["PVC3_BGZF_INFLATE_SINGLE"] = single
-	subprocess.run([sys.executable, "-c", code], env=env)
+variants = [("second forms", {}), ("decode 1, resolve 2", {"PVC3_BGZF_INFLATE_DECODE": "1"}), ("decode 2, resolve 1", {"PVC3_BGZF_INFLATE_RESOLVE": "1"}),
+			("first forms", {"PVC3_BGZF_INFLATE_DECODE": "1", "PVC3_BGZF_INFLATE_RESOLVE": "1"}), ("single kernel", {"PVC3_BGZF_INFLATE_SINGLE": "1"})]
+if "two" in sys.argv[1:]: variants = variants[:1]
+for name, extra in variants:
+	subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PVC3_VARIANT=name, **extra))

@@ -4,7 +4,9 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <type_traits>
@@ -404,8 +406,13 @@ int pvc3_context_synchronize(pvc3_context *ctx)
 int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 {
 	if (!ctx || !idx) return set_error(PVC3_E_INVALID, "pvc3_context_upload_index: null argument");
+	bool const trace_ = nullptr != std::getenv("PVC3_UPLOAD_TRACE");
+	auto const t0_ = std::chrono::steady_clock::now();
 	PVC3_TRY(check_device(ctx));
+	if (trace_) std::fprintf(stderr, "upload_index: device set at %.4f s\n", std::chrono::duration <double>(std::chrono::steady_clock::now() - t0_).count());
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if (trace_) std::fprintf(stderr, "upload_index: stream idle at %.4f s\n", std::chrono::duration <double>(std::chrono::steady_clock::now() - t0_).count());
+	auto mark_ = [&](char const *what) { if (trace_) { (void) hipStreamSynchronize(ctx->stream); std::fprintf(stderr, "upload_index: %s at %.4f s\n", what, std::chrono::duration <double>(std::chrono::steady_clock::now() - t0_).count()); } };
 	free_index_replica(ctx);
 	std::vector <dev_entry> table(idx->entries.size());
 	// Position windows: two bytes per source position of every entry that has a destination.  Built when they leave
@@ -441,6 +448,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 		windows = need && (need + plain + ctx->window_reserve <= free_b);
 	}
+	mark_("sizes");
 	ctx->have_windows = false;
 	ctx->wide_windows = pwin_shift > 6;
 	for (size_t i = 0; i < idx->entries.size(); ++i)
@@ -450,6 +458,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 		d.pwin = nullptr; d.pwin_partner = NO_PARTNER; d.pwin_shift = pwin_shift;
 		PVC3_TRY(dev_upload(&d.blocks, e.blocks.data(), e.blocks.size(), 0, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
 		PVC3_TRY(dev_upload(&d.sel, e.sel.data(), e.sel.size(), 64, ctx->stream, &ctx->index_allocs, &ctx->index_bytes));
+		if (0 == i) mark_("first entry's blocks and samples");
 		d.text = nullptr;
 		d.text4 = nullptr;
 		d.text4w = nullptr;
@@ -467,8 +476,10 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 			uint64_t const bytes4 = (TEXT4_FRONT + e.text.size() + 1) / 2 + TEXT_PAD;
 			PVC3_TRY(dev_alloc(&p4, bytes4, &ctx->index_allocs, &ctx->index_bytes));
 			HIP_TRY(hipMemsetAsync(p4, 0, bytes4, ctx->stream));
+			if (trace_) mark_("a text uploaded");
 			HIP_TRY((hipError_t) launch_pack_text4(d.text, e.text.size(), p4, ctx->stream));
 			d.text4 = p4;
+			if (trace_) mark_("a text packed");
 			if (ctx->text_window && !windows)
 			{
 				// Every line the kernel can address: line k for a run that starts at nibble n has k = n / STEP <= nibbles / STEP.
@@ -516,6 +527,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 			}
 		}
 	}
+	mark_("entries");
 	if (ctx->paired_blocks && PAIRED_STEP == BLOCK_COLS)
 	{
 		// The paired copies, interleaved on the device from the blocks uploaded above.
@@ -531,6 +543,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 			table[i].paired = both;
 		}
 	}
+	mark_("paired");
 	if (windows)
 	{
 		for (size_t i = 0; i < idx->entries.size(); ++i)
@@ -553,6 +566,7 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	ctx->d_entries = const_cast <dev_entry *>(d_table);
 	ctx->n_entries = (uint32_t) table.size();
+	mark_("windows");
 	return PVC3_OK;
 }
 

@@ -15,6 +15,7 @@
 
 #include <zlib.h>
 
+#include <array>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -37,7 +38,11 @@ struct device_records_result
 	double t_setup{}, t_wait_read{}, t_inflate_wait{}, t_frame{}, t_project{}, t_rewrite{}, t_wait_writer{}, t_reader{}, t_writer{}, t_host_inflate{};
 	uint64_t blocks_host{};
 	std::vector <std::pair <uint32_t, uint32_t>> ranges;
+	double rss_setup_mb{};
+	double t_drain{}, t_total{};				// the writer's last pieces after the main thread's last; the whole call but for the objects' destruction
 	std::vector <uint64_t> removed_tags;		// [65536]
+	// per piece, seconds since the path began: handed to the inflater, taken up by the main thread, inflated, records found, projected, rewritten (and handed to the compressor)
+	std::vector <std::array <double, 6>> piece_times;
 };
 
 struct device_records_options
@@ -49,20 +54,26 @@ struct device_records_options
 	pvc3_params params{};
 	uint64_t header_bytes{};				// uncompressed bytes in front of the first record
 	bool want_ranges{};
-	// Who inflates the blocks of a piece: the GPU as many as it works on at a time (a launch of that many takes as long as a launch
-	// of one) and the host's threads the rest meanwhile (0, the default); the GPU all of them (1); the host's threads all (2).
+	// Who inflates the blocks of a piece: the GPU (0, the default, and 1) — with gpu_blocks set in mode 0, the GPU that many and the
+	// host's threads the rest meanwhile, which was the default while the GPU's inflater did 12 GB/s — or the host's threads all (2).
 	int inflate_mode{0};
 	unsigned threads{1};
-	std::size_t piece_compressed{std::size_t(48) << 20};		// compressed bytes read at a time at most
-	std::size_t piece_stream{std::size_t(160) << 20};		// uncompressed bytes of a piece at most
-	uint32_t gpu_blocks{0};									// blocks of a piece that go to the GPU in mode 0; 0: as many as it works on at a time
+	// Pieces of 24 MB of the file / 80 MB of records: 1 200 blocks a launch keep the inflater near its rate, and the buffers (three
+	// of each on the input's side, page-locked memory among them, which costs the process time when it is made and when it ends) are
+	// half of what 48 / 160 MB take: 16 M records in 0.67 s instead of 0.74; with 12 / 40 MB the launches are too small (0.77 s).
+	std::size_t piece_compressed{std::size_t(24) << 20};		// compressed bytes read at a time at most
+	std::size_t piece_stream{std::size_t(80) << 20};		// uncompressed bytes of a piece at most
+	uint32_t gpu_blocks{0};									// blocks of a piece that go to the GPU in mode 0; 0: all
 	uint32_t inflate_in_flight{0};							// blocks the inflater works on at a time; 0: as many as the chip's LDS holds
-	uint32_t piece_blocks{0};								// BGZF blocks of a piece at most; 0: twice what the GPU inflates at a time (the GPU's share and the host's)
+	uint32_t piece_blocks{0};								// BGZF blocks of a piece at most; 0: what the sizes above allow
 	// the two codecs, made ahead of time by the caller (they are page-locked memory, which takes a while to get); null: made here
 	std::function <pvc3_bgzf_inflater *()> take_inflater;
 	std::function <pvc3_bgzf_dev *()> take_deflater;
 	std::function <void(void const *, std::size_t)> write_blocks;		// BGZF blocks to the output file, in order
 	std::function <void(uint64_t)> progress;					// records so far (status lines)
+	// The process ends right after the call (the command line): the three objects on the GPU are left to the operating system, which
+	// takes back gigabytes of page-locked memory faster than the runtime hands them back one by one.
+	bool leave_objects{};
 };
 
 namespace detail {
@@ -118,25 +129,33 @@ inline device_records_result run_device_records(device_records_options const &op
 	struct cleanup
 	{
 		pvc3_bgzf_inflater *&i; pvc3_bgzf_dev *&d; pvc3_records *&r; uint8_t *(&st)[IN_SLOTS];
-		~cleanup() { if (r) pvc3_records_destroy(r); if (d) pvc3_bgzf_dev_destroy(d); if (i) pvc3_bgzf_inflater_destroy(i); for (auto *p : st) if (p) pvc3_host_free(p); }
+		bool leave{};
+		~cleanup() { if (leave) return; if (r) pvc3_records_destroy(r); if (d) pvc3_bgzf_dev_destroy(d); if (i) pvc3_bgzf_inflater_destroy(i); for (auto *p : st) if (p) pvc3_host_free(p); }
 	} cleanup_guard{inflater, deflater, records, staging};
+	auto rss_now = []() { double mb = 0; if (FILE *f = std::fopen("/proc/self/statm", "r")) { long pages = 0, resident = 0; if (2 == std::fscanf(f, "%ld %ld", &pages, &resident)) mb = (double) resident * (double) sysconf(_SC_PAGESIZE) / 1048576.0; std::fclose(f); } return mb; };
+	bool const rss_trace = nullptr != std::getenv("PVC3_RECORDS_TRACE");
+	if (rss_trace) std::fprintf(stderr, "record path: resident %.0f MB at its start\n", rss_now());
 	if (opt.take_inflater) inflater = opt.take_inflater();
 	else bgzf_check(pvc3_bgzf_inflater_create(opt.device, max_in, 1, max_blocks_in, IN_SLOTS, &inflater), "pvc3_bgzf_inflater_create");
 	if (opt.take_deflater) deflater = opt.take_deflater();
 	else bgzf_check(pvc3_bgzf_dev_create(opt.device, sz.max_blocks_out, OUT_SLOTS, &deflater), "pvc3_bgzf_dev_create");
 	if (!inflater || !deflater) throw io_error("the BGZF codecs on the GPU could not be made");
+	if (rss_trace) std::fprintf(stderr, "record path: resident %.0f MB with the codecs\n", rss_now());
 	pvc3_records_config cfg = opt.config;
 	cfg.max_stream_bytes = opt.piece_stream;
 	rec_check(pvc3_records_create(opt.ctx, &cfg, &records), "pvc3_records_create");
+	if (rss_trace) std::fprintf(stderr, "record path: resident %.0f MB with the records object\n", rss_now());
 	uint64_t const out_capacity = pvc3_bgzf_dev_capacity(deflater);
 	if (opt.inflate_in_flight) bgzf_check(pvc3_bgzf_inflater_limit_in_flight(inflater, opt.inflate_in_flight), "pvc3_bgzf_inflater_limit_in_flight");
-	uint32_t const gpu_at_a_time = opt.gpu_blocks ? opt.gpu_blocks : std::max <uint32_t>(1, pvc3_bgzf_inflater_blocks_in_flight(inflater));
-	uint32_t const piece_blocks = std::min <uint32_t>(max_blocks_in, opt.piece_blocks ? opt.piece_blocks : ((0 == opt.inflate_mode) ? 2 * gpu_at_a_time : max_blocks_in));
+	bool const shared = 0 == opt.inflate_mode && 0 != opt.gpu_blocks;		// a piece's blocks shared between the GPU and the host's threads
+	uint32_t const piece_blocks = std::min <uint32_t>(max_blocks_in, opt.piece_blocks ? opt.piece_blocks : max_blocks_in);
 	// the host's share of a piece at most (blocks of 64 KiB at most)
-	std::size_t const staging_bytes = (1 == opt.inflate_mode) ? 0 : std::min <std::size_t>(opt.piece_stream, (std::size_t) ((0 == opt.inflate_mode) ? (piece_blocks > gpu_at_a_time ? piece_blocks - gpu_at_a_time : 0) : piece_blocks) * 65536);
+	std::size_t const staging_bytes = (2 == opt.inflate_mode) ? std::min <std::size_t>(opt.piece_stream, std::size_t(piece_blocks) * 65536)
+		: (shared && piece_blocks > opt.gpu_blocks) ? std::min <std::size_t>(opt.piece_stream, std::size_t(piece_blocks - opt.gpu_blocks) * 65536) : 0;
 	if (staging_bytes)
 		for (auto &p : staging) { void *q{}; rec_check(pvc3_host_alloc(staging_bytes, &q), "pvc3_host_alloc"); p = (uint8_t *) q; }
 	res.t_setup = since(t_begin);
+	if (FILE *f = std::fopen("/proc/self/statm", "r")) { long pages = 0, resident = 0; if (2 == std::fscanf(f, "%ld %ld", &pages, &resident)) res.rss_setup_mb = (double) resident * (double) sysconf(_SC_PAGESIZE) / 1048576.0; std::fclose(f); }
 
 	// ---- the reader ------------------------------------------------------------------------------------------------------------------
 	struct piece
@@ -147,6 +166,7 @@ inline device_records_result run_device_records(device_records_options const &op
 		std::vector <uint64_t> block_off;		// [n_blocks + 1] where the blocks' bytes begin in the stream buffer, from its front
 		std::vector <uint32_t> crc;
 		bool last{};
+		double t_submitted{};
 		uint32_t n_gpu{};						// the first n_gpu blocks are the GPU's, the rest the host's threads'
 		std::future <double> host_part;			// (its seconds)
 	};
@@ -297,7 +317,7 @@ inline device_records_result run_device_records(device_records_options const &op
 
 	auto start_inflate = [&](piece &p) {
 		if (0 == p.n_blocks) return;
-		p.n_gpu = (2 == opt.inflate_mode) ? 0 : ((1 == opt.inflate_mode) ? p.n_blocks : std::min(p.n_blocks, gpu_at_a_time));
+		p.n_gpu = (2 == opt.inflate_mode) ? 0 : (shared ? std::min(p.n_blocks, opt.gpu_blocks) : p.n_blocks);
 		pvc3_bgzf_block const *blocks = pvc3_bgzf_inflater_blocks(inflater, p.slot);
 		if (p.n_gpu)
 		{
@@ -386,6 +406,7 @@ inline device_records_result run_device_records(device_records_options const &op
 			piece p = std::move(ready.front()); ready.pop_front();
 			lock.unlock();
 			seen_last = p.last;
+			p.t_submitted = since(t_begin);
 			start_inflate(p);
 			inflating.push_back(std::move(p));
 		}
@@ -395,7 +416,9 @@ inline device_records_result run_device_records(device_records_options const &op
 		if (inflating.empty()) break;
 		piece p = std::move(inflating.front()); inflating.pop_front();
 		t0 = now();
+		std::array <double, 6> times{p.t_submitted, since(t_begin), 0, 0, 0, 0};
 		finish_inflate(p);
+		times[2] = since(t_begin);
 		res.t_inflate_wait += since(t0); t0 = now();
 		res.blocks_in += p.n_blocks; res.bytes_in += p.out_bytes;
 		// the compressed bytes are no longer needed: the reader may fill the slot again (the stream buffer of the same number
@@ -413,6 +436,7 @@ inline device_records_result run_device_records(device_records_options const &op
 		rec_check(rc, "pvc3_records_frame");
 		res.matched += fr.matched; res.flags_not_matched += fr.flags_not_matched; res.ref_id_missing += fr.ref_id_missing; res.seq_missing += fr.seq_missing;
 		res.t_frame += since(t0); t0 = now();
+		times[3] = since(t_begin);
 		{
 			std::lock_guard <std::mutex> lock(m);
 			slot_free[p.slot] = true;		// (its input; see above)
@@ -423,6 +447,7 @@ inline device_records_result run_device_records(device_records_options const &op
 			pvc3_batch_stats stats{};
 			rec_check(pvc3_records_project(records, &opt.params, &stats), "pvc3_records_project");
 			res.t_project += since(t0); t0 = now();
+			times[4] = since(t_begin);
 			{
 				std::unique_lock <std::mutex> lock(m);
 				cv.wait(lock, [&]() { return writer_done || out_free[out_slot]; });
@@ -451,9 +476,11 @@ inline device_records_result run_device_records(device_records_options const &op
 			cv.notify_all();
 			out_slot = (out_slot + 1) % OUT_SLOTS;
 			res.t_rewrite += since(t0);
+			times[5] = since(t_begin);
 			res.records += fr.n_batch; ++res.batches;
 			if (opt.progress) opt.progress(res.records);
 		}
+		res.piece_times.push_back(times);
 		if (p.last) break;
 	}
 	{
@@ -461,11 +488,15 @@ inline device_records_result run_device_records(device_records_options const &op
 		writer_done = true;
 	}
 	cv.notify_all();
+	auto const t_drain = now();
 	writer.join();
 	if (writer_error) std::rethrow_exception(writer_error);
 	reader.join();
 	if (reader_error) std::rethrow_exception(reader_error);
 	rec_check(pvc3_records_removed_tags(records, res.removed_tags.data()), "pvc3_records_removed_tags");
+	res.t_drain = since(t_drain);
+	res.t_total = since(t_begin);
+	cleanup_guard.leave = opt.leave_objects;
 	return res;
 }
 

@@ -133,6 +133,28 @@ double cpu_seconds()		// user + system time of the whole process so far
 	return (double) ru.ru_utime.tv_sec + (double) ru.ru_stime.tv_sec + 1e-6 * ((double) ru.ru_utime.tv_usec + (double) ru.ru_stime.tv_usec);
 }
 
+std::string rss_kinds()		// resident now, by kind (/proc/self/status), and the CPU time split
+{
+	std::string out;
+	if (FILE *f = std::fopen("/proc/self/status", "r"))
+	{
+		char line[256];
+		while (std::fgets(line, sizeof(line), f))
+			if (0 == std::strncmp(line, "RssAnon", 7) || 0 == std::strncmp(line, "RssFile", 7) || 0 == std::strncmp(line, "RssShmem", 8) || 0 == std::strncmp(line, "VmLck", 5) || 0 == std::strncmp(line, "VmPin", 5))
+			{
+				std::string l(line);
+				while (!l.empty() && ('\n' == l.back() || ' ' == l.back())) l.pop_back();
+				for (auto &c : l) if ('\t' == c) c = ' ';
+				out += (out.empty() ? "" : ", ") + l;
+			}
+		std::fclose(f);
+	}
+	struct rusage ru{};
+	getrusage(RUSAGE_SELF, &ru);
+	out += "; user " + std::to_string((double) ru.ru_utime.tv_sec + 1e-6 * (double) ru.ru_utime.tv_usec) + " s, system " + std::to_string((double) ru.ru_stime.tv_sec + 1e-6 * (double) ru.ru_stime.tv_usec) + " s";
+	return out;
+}
+
 double rss_mb()		// resident now (/proc/self/statm, pages)
 {
 	double mb = 0.0;
@@ -434,6 +456,19 @@ int main(int argc, char **argv)
 				std::string const p(opt.alignments);
 				is_bam = p.size() >= 4 && 0 == p.compare(p.size() - 4, 4, ".bam");
 			}
+			// Where the record path on the GPU may apply the file is read anew, raw, by that path's own reader: this one is then only
+			// there for the header, and reads little of the file (pieces of 1 MB on one thread, not of 32 MB on all).
+			bool header_only = is_bam && opt.alignments && 0 != opt.record_path && opt.output_bam && opt.compression_level < 0 && opt.gpu_deflate && 1 == opt.devices.size() && !opt.io_only;
+			if (header_only)
+			{
+				// (what byte_reader::open takes for a BGZF file: a gzip member whose only extra field is BC)
+				uint8_t first[18]{};
+				FILE *f = std::fopen(opt.alignments, "rb");
+				header_only = f && sizeof(first) == std::fread(first, 1, sizeof(first), f) && 0x1f == first[0] && 0x8b == first[1] && 8 == first[2] && 4 == first[3] && 6 == first[10] && 0 == first[11]
+					&& 'B' == first[12] && 'C' == first[13] && 2 == first[14] && 0 == first[15];
+				if (f) std::fclose(f);
+			}
+			if (header_only) { reader.set_threads(1); reader.set_piece_bytes(std::size_t(1) << 20); }
 			reader.open(opt.alignments, is_bam);
 		}
 		sam_header const &in_header = reader.header;
@@ -468,6 +503,7 @@ int main(int argc, char **argv)
 		double t_startup = 0.0, t_contexts_up = 0.0, t_deflater_up = 0.0, t_inflater_up = 0.0, t_files_read = 0.0, inflater_kernel_s = 0.0;
 		uint64_t inflater_groups = 0;
 		bool aux_codecs = true;		// the reader's GPU inflater and the writer's GPU compressor (not for the record path on the GPU, which has its own)
+		std::function <void()> while_contexts_come;		// run on this thread once the files are read, before the contexts are waited for
 		std::function <void()> after_contexts;		// run on the contexts' thread once they are up (the record path on the GPU makes its codecs there)
 		auto prepare_devices = [&]() {
 			// The GPU contexts come up on a thread of their own (the HIP runtime takes a few tenths of a second to start) while the
@@ -551,6 +587,7 @@ int main(int argc, char **argv)
 				}
 			}
 			t_files_read = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+			if (while_contexts_come) while_contexts_come();
 			device_contexts = contexts_coming.get();
 		};
 
@@ -585,22 +622,26 @@ int main(int argc, char **argv)
 				records_inflater = std::async(std::launch::async, [&]() { pvc3_bgzf_inflater *h{}; if (pvc3_bgzf_inflater_create(first_device, sizes.max_in, 1, sizes.max_blocks_in, PVC3_RECORDS_SLOTS, &h)) inflater_message = pvc3_bgzf_last_error(); return h; });
 				records_deflater = std::async(std::launch::async, [&]() { pvc3_bgzf_dev *h{}; if (pvc3_bgzf_dev_create(first_device, sizes.max_blocks_out, 2, &h)) deflater_message = pvc3_bgzf_last_error(); return h; });
 			};
-			prepare_devices();
-			check(pvc3_context_set_option(device_contexts[0], "window_read_length", 150), "pvc3_context_set_option");
-			double const t_prepared = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
-			{
-				// the longest read decides between 128- and 256-byte position windows: the first records of the file are looked at on the host
-				uint32_t longest = 0;
+			// the longest read decides between 128- and 256-byte position windows: the first records of the file are looked at on the host
+			// (while the HIP runtime is still starting)
+			uint32_t longest = 0;
+			while_contexts_come = [&]() {
 				alignment_reader peek;
 				peek.set_threads(1);
 				peek.set_piece_bytes(std::size_t(1) << 20);
 				peek.open(opt.alignments, true);
 				bam_record rec;
 				for (unsigned k = 0; k < 2000 && peek.next(rec); ++k) longest = std::max(longest, rec.l_seq());
-				if (longest) check(pvc3_context_set_option(device_contexts[0], "window_read_length", longest), "pvc3_context_set_option");
-			}
+			};
+			prepare_devices();
+			double const t_prepared = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+			double const rss_prepared = rss_mb();
+			check(pvc3_context_set_option(device_contexts[0], "window_read_length", longest ? longest : 150), "pvc3_context_set_option");
+			double const t_peeked = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+			if (std::getenv("PVC3_RECORDS_TRACE")) std::cerr << "resident " << rss_mb() << " MB before the index goes to the GPU\n";
 			if (pvc3_context_upload_index(device_contexts[0], index)) die(std::string("pvc3_context_upload_index: ") + pvc3_last_error());
 			t_startup = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
+			if (std::getenv("PVC3_RECORDS_TRACE")) std::cerr << "resident " << rss_mb() << " MB with the index on the GPU\n";
 
 			dro.path = opt.alignments; dro.device = opt.devices.front(); dro.ctx = device_contexts[0];
 			dro.take_inflater = [&]() { pvc3_bgzf_inflater *h = records_inflater.get(); if (!h) die("pvc3_bgzf_inflater_create: " + inflater_message); return h; };
@@ -634,6 +675,9 @@ int main(int argc, char **argv)
 				std::cerr << ".\n";
 				next_status = running + 60.0 * (double) opt.status_interval;
 			};
+			dro.leave_objects = true;		// (this function ends in _Exit)
+			double const rss_begin = rss_mb();
+			double const t_records_begin = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
 			device_records_result const dr = run_device_records(dro);
 			double const t_batches_done = std::chrono::duration <double>(std::chrono::steady_clock::now() - t_start).count();
 			writer.close();
@@ -665,10 +709,15 @@ int main(int argc, char **argv)
 						  << dr.bytes_in << " bytes of records in, " << dr.bytes_out << " bytes of file out; kernels: inflate " << dr.inflate_kernel_s << " s, deflate " << dr.deflate_kernel_s << " s\n";
 				std::cerr << "\tStages (s): start-up " << t_startup << ", reader thread " << dr.t_reader << ", codecs and buffers " << dr.t_setup << ", main: waiting for the reader " << dr.t_wait_read << ", waiting for the inflaters " << dr.t_inflate_wait << " (host threads at work " << dr.t_host_inflate << ")"
 						  << ", records found and scattered " << dr.t_frame << ", projected " << dr.t_project << ", rewritten " << dr.t_rewrite << ", waiting for the writer " << dr.t_wait_writer << ", writer thread " << dr.t_writer << '\n';
-				std::cerr << "\tTimeline (s): GPU contexts " << t_contexts_up << ", index file and FASTA " << t_files_read << ", both " << t_prepared << ", index on the GPUs (start-up done) " << t_startup
-						  << ", last batch rewritten " << t_batches_done << ", output closed " << t_closed << "; wall clock at the start " << std::fixed << epoch_start << ", now "
+				std::cerr << "\tTimeline (s): GPU contexts " << t_contexts_up << ", index file and FASTA " << t_files_read << ", both " << t_prepared << ", first reads looked at " << t_peeked << ", index on the GPUs (start-up done) " << t_startup
+						  << ", record path begun " << t_records_begin << " (its last pieces written in " << dr.t_drain << ", all of it " << dr.t_total << "), last batch rewritten " << t_batches_done << ", output closed " << t_closed << "; wall clock at the start " << std::fixed << epoch_start << ", now "
 						  << std::chrono::duration <double>(std::chrono::system_clock::now().time_since_epoch()).count() << std::defaultfloat
-						  << "; resident set (MB): peak " << peak_rss_mb() << "; CPU time (s): " << cpu_seconds() << '\n';
+						  << "; resident set (MB): with the contexts up " << rss_prepared << ", before the record path " << rss_begin << ", with its objects made " << dr.rss_setup_mb << ", peak " << peak_rss_mb() << "; CPU time (s): " << cpu_seconds() << " (" << rss_kinds() << ")\n";
+			}
+			if (opt.debugging_output && std::getenv("PVC3_RECORDS_TRACE"))
+			{
+				std::cerr << "\tPieces (s since the record path began: to the inflater, taken up, inflated, records found, projected, rewritten):\n";
+				for (auto const &t : dr.piece_times) std::cerr << "\t\t" << t[0] << ' ' << t[1] << ' ' << t[2] << ' ' << t[3] << ' ' << t[4] << ' ' << t[5] << '\n';
 			}
 			bool any_removed = false;
 			for (auto const c : dr.removed_tags) any_removed = any_removed || c;

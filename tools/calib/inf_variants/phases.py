@@ -1,5 +1,6 @@
-"""k_inflate_blocks in one kernel (PVC3_BGZF_INFLATE_SINGLE=1: the block's last 32 KB of output in LDS) against the two phases,
-first forms (k_inflate_blocks<tokens>, k_inflate_resolve) and second (k_inflate_decode, k_inflate_resolve_lanes).  Timed on zlib level-6 streams of BAM records, 1 024 to 4 096 blocks a launch.
+"""The two kernels of the BGZF inflater (k_inflate_decode, k_inflate_resolve_lanes) timed on zlib level-6 streams of BAM records,
+256 to 4 096 blocks a launch.  profiles/r04/inflate_phases.txt is this script at the commit that still held the earlier forms
+(one kernel with 32 KB of output in LDS; the first decode and resolve kernels) behind environment switches.
 usage (on the GPU box): python tools/calib/inf_variants/phases.py"""
 import os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
@@ -30,8 +31,4 @@ print("; ".join(line), flush=True)
 sys.path.insert(0, os.path.join(root, "tools"))
 import cli_e2e
 cli_e2e.prepare("/tmp/pvc3_bgzf_bench", 0.05, 1)
-variants = [("second forms", {}), ("decode 1, resolve 2", {"PVC3_BGZF_INFLATE_DECODE": "1"}), ("decode 2, resolve 1", {"PVC3_BGZF_INFLATE_RESOLVE": "1"}),
-			("first forms", {"PVC3_BGZF_INFLATE_DECODE": "1", "PVC3_BGZF_INFLATE_RESOLVE": "1"}), ("single kernel", {"PVC3_BGZF_INFLATE_SINGLE": "1"})]
-if "two" in sys.argv[1:]: variants = variants[:1]
-for name, extra in variants:
-	subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PVC3_VARIANT=name, **extra))
+subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PVC3_VARIANT="decode + resolve"))

@@ -112,8 +112,17 @@ def project_command(P, alignments="in.bam", output="out.bam", bam=True):
 	return cmd + (["-b"] if bam else [])
 
 
+def fresh_output(cmd, cwd=None):
+	if "-o" in cmd:
+		path = os.path.join(cwd or ".", cmd[cmd.index("-o") + 1])
+		if os.path.exists(path): os.remove(path)
+
+
 def timed(cmd, cwd=None):
-	"""(seconds, the tool's --debugging-output stage line or None)"""
+	"""(seconds, the tool's --debugging-output stage line or None).  The output is a new file every time: a file that exists is
+	truncated, and closing a truncated and rewritten file makes the file system write it out there and then (ext4's
+	auto_da_alloc) — 0.19 s of the 1.24 of a run with 2 GB of output, none of it the tool's."""
+	fresh_output(cmd, cwd)
 	t = time.perf_counter()
 	p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=cwd)
 	dt = time.perf_counter() - t

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The command line's record path on the GPU with the inflater limited to fewer blocks at a time (PVC3_RECORDS_INFLATE_IN_FLIGHT) and
-pieces of other sizes (PVC3_RECORDS_BLOCKS): room in the CUs' LDS for the other kernels against inflater throughput.
+"""The command line's record path on the GPU with the GPU's share of a piece's blocks (PVC3_RECORDS_GPU_BLOCKS; the host's threads inflate
+the rest) and the inflater limited to fewer blocks at a time (PVC3_RECORDS_INFLATE_IN_FLIGHT): room in the CUs' LDS for the other kernels against inflater throughput.
 usage: tools/cli_inflight_sweep.py [--workdir DIR]"""
 import argparse, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,10 +16,11 @@ def main():
 	n = cli_e2e.write_repeated(P, os.path.join(args.workdir, "in_large.bam"), 64)
 	cmd = cli_e2e.project_command(P, alignments="in_large.bam", output="out_large.bam")
 	subprocess.run(cmd, cwd=args.workdir, capture_output=True)
-	for env in ({}, {"PVC3_RECORDS_INFLATE_IN_FLIGHT": "768"}, {"PVC3_RECORDS_INFLATE_IN_FLIGHT": "512"}, {"PVC3_RECORDS_INFLATE_IN_FLIGHT": "768", "PVC3_RECORDS_BLOCKS": "2048"},
-				{"PVC3_RECORDS_INFLATE_IN_FLIGHT": "512", "PVC3_RECORDS_BLOCKS": "1536"}, {"PVC3_RECORDS_BLOCKS": "3072"}, {"PVC3_RECORDS_BLOCKS": "1536"}, {"PVC3_RECORDS_GPU_BLOCKS": "1024", "PVC3_RECORDS_BLOCKS": "2560"}):
+	for env in ({}, {"PVC3_RECORDS_GPU_BLOCKS": "2048"}, {"PVC3_RECORDS_GPU_BLOCKS": "1536"}, {"PVC3_RECORDS_GPU_BLOCKS": "1024"}, {"PVC3_RECORDS_GPU_BLOCKS": "1024", "PVC3_RECORDS_INFLATE_IN_FLIGHT": "1024"},
+				{"PVC3_RECORDS_GPU_BLOCKS": "2048", "PVC3_RECORDS_INFLATE_IN_FLIGHT": "2048"}, {"PVC3_RECORDS_INFLATE_IN_FLIGHT": "2048"}):
 		best, line = None, ""
 		for _ in range(2):
+			cli_e2e.fresh_output(cmd, args.workdir)
 			t = time.perf_counter()
 			p = subprocess.run(cmd, cwd=args.workdir, capture_output=True, env=dict(os.environ, **env))
 			dt = time.perf_counter() - t

@@ -26,6 +26,7 @@ def main():
 		cmd = cli_e2e.project_command(P, alignments=alignments, output=out) + extra
 		best, lines = None, []
 		for _ in range(times):
+			cli_e2e.fresh_output(cmd, args.workdir)
 			t = time.perf_counter()
 			p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=args.workdir)
 			dt = time.perf_counter() - t

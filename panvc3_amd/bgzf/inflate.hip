@@ -74,6 +74,7 @@ struct bit_reader
 	uint32_t next_word{};		// the next dword for the window
 	uint32_t batch_first{};		// lane j holds dword batch_first + j
 	uint32_t batch{};
+	uint32_t staged_until{};	// dwords of the input in the ring so far
 	uint64_t lo{}, hi{};		// bits 0 .. 63 and 64 .. 127 of the window
 	uint32_t valid{};
 	uint32_t lead_bits{};
@@ -88,10 +89,14 @@ struct bit_reader
 		__syncthreads();
 	}
 
-	__device__ __forceinline__ void load_batch()
+	// Lane j gets dword first + j; the ring is filled up to there first, half a ring at a time (it then holds the 512 dwords
+	// before staged_until, `first` among them: staging stops less than 320 dwords past it, and a batch that begins a few dwords
+	// before the last one — the fast path after the one-symbol path has read ahead — is still there).
+	__device__ __forceinline__ void load_batch(uint32_t first)
 	{
-		batch_first = next_word;
-		batch = ring[(next_word + threadIdx.x) & (RING_WORDS - 1)];		// staged: the ring holds 256 dwords from next_word on at least
+		while (staged_until < first + WAVE) { stage(staged_until); staged_until += RING_WORDS / 2; }
+		batch_first = first;
+		batch = ring[(first + threadIdx.x) & (RING_WORDS - 1)];
 	}
 
 	__device__ void start(uint8_t const *data, uint32_t n_bytes, uint32_t *ring_)
@@ -101,11 +106,9 @@ struct bit_reader
 		src = reinterpret_cast <uint32_t const *>(a & ~uintptr_t(3));
 		uint32_t const lead = (uint32_t) (a & 3);
 		n_words = (lead + n_bytes + 3) / 4;
-		next_word = 0; lo = 0; hi = 0; valid = 0; lead_bits = 8 * lead;
+		next_word = 0; lo = 0; hi = 0; valid = 0; lead_bits = 8 * lead; staged_until = 0;
 		__syncthreads();
-		stage(0);
-		stage(RING_WORDS / 2);
-		load_batch();
+		load_batch(0);
 		refill();
 		drop(lead_bits);
 		refill();
@@ -116,15 +119,23 @@ struct bit_reader
 	{
 		while (valid <= 96)
 		{
-			if (next_word - batch_first >= WAVE) load_batch();
+			if (next_word - batch_first >= WAVE) load_batch(next_word);
 			uint64_t const w = (uint32_t) __builtin_amdgcn_readlane((int) batch, (int) (next_word - batch_first));
 			if (valid >= 64) hi |= w << (valid - 64);
 			else { lo |= w << valid; if (valid > 32) hi |= w >> (64 - valid); }
 			valid += 32;
 			++next_word;
-			if (0 == (next_word & (RING_WORDS / 2 - 1)))		// entered a half: the one behind it is free for what follows this one
-				stage(next_word + RING_WORDS / 2);
 		}
+	}
+
+	// Where the window begins, in bits from the first staged dword; and the window moved there (forwards).
+	__device__ __forceinline__ uint32_t position() const { return 32 * next_word - valid; }
+	__device__ __forceinline__ void seek(uint32_t bit)
+	{
+		next_word = bit >> 5; lo = 0; hi = 0; valid = 0;
+		refill();
+		drop(bit & 31);
+		refill();
 	}
 
 	__device__ __forceinline__ uint32_t low32() const { return (uint32_t) lo; }
@@ -257,9 +268,22 @@ struct lds_decode
 	uint32_t flag;
 };
 
-// A symbol takes 10 + 5 + 9 + 13 = 37 bits at most through the tables and the window holds 97: the walk goes on while a symbol
-// begins at bit 60 or before.
-constexpr unsigned WALK_LAST = 60;
+// Sum of v over the lanes up to and including this one: within rows of 16 lanes by DPP shifts, then lane 15 of a row to the next row,
+// lane 31 to the upper two (the sequence LLVM's atomic optimizer emits for gfx9).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);		// row_shr:1
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);		// row_shr:2
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);		// row_shr:4
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);		// row_shr:8
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);		// row_bcast:15 to rows 1 and 3
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);		// row_bcast:31 to rows 2 and 3
+	return v;
+}
+
+// A symbol takes 10 + 5 + 9 + 13 = 37 bits at most through the tables, and every lane looks at 64 of its own: the walk goes on
+// while a symbol begins in the lanes.
+constexpr unsigned WALK_LAST = 63;
 
 __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 	uint8_t const *__restrict__ in, pvc3_bgzf_block const *__restrict__ blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t n_blocks,
@@ -377,16 +401,27 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 			{ st = ST_BAD_CODE_LENGTHS; break; }
 
 			// ---- the symbols -----------------------------------------------------------------------------------------------------------
-			// One pass: lane k decodes the symbol that would begin at bit k of the window WHOLE — the literal, or the length with
-			// its extra bits, the distance code behind them (a second look-up) and its extra bits: 37 bits at most, and the window
-			// holds 97 — and says how many bits it takes and how many bytes it makes.  A scalar walk then only follows the chain
-			// (o, o + bits of the symbol at o, ...: one v_readlane and a few scalar instructions per symbol) and hands every symbol
-			// on it the place of its output; after the walk the lanes on the chain store — a literal its byte, a match its token.
-			// Codes longer than the tables' index (rare) go through the one-symbol path behind the walk.
+			// One pass: lane k decodes the symbol that would begin at bit k WHOLE — the literal, or the length with its extra bits,
+			// the distance code behind them (a second look-up) and its extra bits: 37 bits at most of the 64 it looks at — and says
+			// how many bits it takes and how many bytes it makes.  A scalar walk then only follows the chain (o, o + bits of the
+			// symbol at o, ...: one v_readlane and seven scalar instructions per symbol); the lanes on the chain get the places of
+			// their output from a prefix sum across the wave and store — a literal its byte, a match its token.
+			// The bits come straight from the staged dwords here (five of them, out of the lanes, hold every lane's 64 bits): the
+			// scalar window is only set up again for what the lanes do not decode — codes longer than the tables' index (rare)
+			// and the end of the block go through the one-symbol path behind the walk.
+			uint32_t at_bit = br.position();
 			for (bool end_of_block = false; !end_of_block && ST_OK == st; )
 			{
-				br.refill();
-				uint64_t const mine = br.from_bit(lane);
+				uint32_t const w0 = at_bit >> 5;
+				if (w0 < br.batch_first || w0 + 5 > br.batch_first + WAVE) br.load_batch(w0);		// (before: the one-symbol path has read ahead)
+				uint32_t const i0 = w0 - br.batch_first;
+				uint32_t const s0 = (uint32_t) __builtin_amdgcn_readlane((int) br.batch, (int) i0), s1 = (uint32_t) __builtin_amdgcn_readlane((int) br.batch, (int) (i0 + 1)),
+					s2 = (uint32_t) __builtin_amdgcn_readlane((int) br.batch, (int) (i0 + 2)), s3 = (uint32_t) __builtin_amdgcn_readlane((int) br.batch, (int) (i0 + 3)),
+					s4 = (uint32_t) __builtin_amdgcn_readlane((int) br.batch, (int) (i0 + 4));
+				uint32_t const q = (at_bit & 31) + lane;		// 0 .. 94
+				bool const z0 = q < 32, z1 = q < 64;
+				uint32_t const d0 = z0 ? s0 : z1 ? s1 : s2, d1 = z0 ? s1 : z1 ? s2 : s3, d2 = z0 ? s2 : z1 ? s3 : s4;
+				uint64_t const mine = (uint64_t) __builtin_amdgcn_alignbit(d1, d0, q & 31) | ((uint64_t) __builtin_amdgcn_alignbit(d2, d1, q & 31) << 32);
 				uint32_t const e = L.t_ll[(uint32_t) mine & ((1u << LL_BITS) - 1)];
 				uint32_t const l = (e >> 9) & 15, x = (e >> 13) & 7, kind = e >> 16;
 				uint32_t const length = (e & 0x1ff) + __builtin_amdgcn_ubfe((uint32_t) (mine >> l), 0, x);		// (a literal's byte, for a literal)
@@ -395,25 +430,24 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 				uint32_t const ld = (ed >> 15) & 15, xd = (ed >> 19) & 15;
 				uint32_t const dist = (ed & 0x7fff) + __builtin_amdgcn_ubfe(behind >> ld, 0, xd);
 				bool const is_match = K_MATCH == kind && 0 != (ed >> 23);
-				// bits | end of block << 7 | bytes << 8; no bits: the walk stops here
-				uint32_t const packed = (K_LITERAL == kind) ? (l | (1u << 8)) : is_match ? ((l + x + ld + xd) | (length << 8)) : (K_END == kind) ? (l | 0x80u) : 0u;
-				uint32_t o = 0, made = 0;
+				uint32_t const bits = (K_LITERAL == kind) ? l : is_match ? (l + x + ld + xd) : 0u;		// none: the walk stops here
+				uint32_t o = 0;
 				uint64_t chain = 0;
-				uint32_t place = 0;
-				bool slow = false;
-				while (o <= WALK_LAST)
+				uint32_t t = (uint32_t) __builtin_amdgcn_readlane((int) bits, 0);
+				while (t)
 				{
-					uint32_t const p = (uint32_t) __builtin_amdgcn_readlane((int) packed, (int) o);
-					if (0 == (p & 0x7f)) { slow = true; break; }
-					place = (lane == o) ? made : place;
 					chain |= uint64_t(1) << o;
-					made += p >> 8;
-					o += p & 0x7f;
-					if (p & 0x80) { end_of_block = true; break; }
+					o += t;
+					if (o > WALK_LAST) break;
+					t = (uint32_t) __builtin_amdgcn_readlane((int) bits, (int) o);
 				}
-				if (pos + made > want) { st = ST_OUTPUT_OVERFLOW; break; }
+				bool const stopped = 0 == t;
 				bool const on_chain = 0 != ((chain >> lane) & 1);
-				uint32_t const at = pos + place;
+				uint32_t const makes = !on_chain ? 0u : (K_LITERAL == kind) ? 1u : length;
+				uint32_t const upto = wave_inclusive_sum(makes);
+				uint32_t const made = (uint32_t) __builtin_amdgcn_readlane((int) upto, 63);
+				if (pos + made > want) { st = ST_OUTPUT_OVERFLOW; break; }
+				uint32_t const at = pos + upto - makes;
 				if (on_chain && K_LITERAL == kind) dst[at] = (uint8_t) e;
 				uint64_t const matches = __ballot(on_chain && is_match);
 				if (matches)
@@ -424,11 +458,11 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 					n_tok += (uint32_t) __popcll(matches);
 				}
 				pos += made;
-				br.drop(o);
-				if (!slow) continue;
+				at_bit += o;
+				if (!stopped) continue;
 
-				// one symbol the long way: a code longer than the table's index, or one that does not exist
-				br.refill();
+				// one symbol the long way: a code longer than the table's index, the end of the block, or a code that does not exist
+				br.seek(at_bit);
 				uint32_t e1 = uni(L.t_ll[br.peek(LL_BITS)]);
 				if (0 == e1)
 				{
@@ -444,6 +478,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 					if (pos >= want) { st = ST_OUTPUT_OVERFLOW; break; }
 					if (0 == lane) dst[pos] = (uint8_t) e1;
 					++pos;
+					at_bit = br.position();
 					continue;
 				}
 				if (K_END == kind1) { end_of_block = true; break; }
@@ -464,6 +499,7 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 				if (0 == lane) tok[n_tok] = make_token(pos, length1, dist1);
 				++n_tok;
 				pos += length1;
+				at_bit = br.position();
 			}
 		}
 		if (ST_OK == st && br.consumed_bits() > uint64_t(8) * blk.in_len) st = ST_INPUT_OVERRUN;
@@ -612,22 +648,24 @@ struct pvc3_bgzf_inflater
 {
 	int device{};
 	size_t max_in{}, max_out{};
-	uint32_t max_blocks{}, n_slots{}, grid_max{}, grid_full{};
-	hipStream_t stream{};
-	uint8_t *d_in{}, *d_out{};
-	pvc3_bgzf_block *d_blocks{};
-	uint32_t *d_status{};
-	// the matches of every block between the two kernels
-	token_t *d_tokens{};
-	size_t tokens_cap{};				// in tokens
-	uint32_t *d_ntok{};
-	uint32_t grid_resolve{};
-	// the device-resident form (pvc3_bgzf_inflater_submit_device): where the blocks' bytes went and their checksums
-	uint64_t *d_off{};
-	uint32_t *d_lens{}, *d_crc{};
+	uint32_t max_blocks{}, n_slots{}, grid_max{}, grid_full{}, grid_resolve{};
 	pvc3_crc::tables *d_crc_tables{};
+	// Everything else is a slot's own, the stream included: the groups of two slots are on the GPU at the same time.  A launch of a
+	// thousand blocks takes as long as a launch of one (a block is one wave's work from its first bit to its last), so two launches
+	// one after the other on one stream, as it was, left most of the chip idle twice.
 	struct slot
 	{
+		hipStream_t stream{};
+		uint8_t *d_in{}, *d_out{};
+		pvc3_bgzf_block *d_blocks{};
+		uint32_t *d_status{};
+		// the matches of every block between the two kernels
+		token_t *d_tokens{};
+		size_t tokens_cap{};				// in tokens
+		uint32_t *d_ntok{};
+		// the device-resident form (pvc3_bgzf_inflater_submit_device): where the blocks' bytes went and their checksums
+		uint64_t *d_off{};
+		uint32_t *d_lens{}, *d_crc{};
 		uint8_t *h_in{}, *h_out{};
 		pvc3_bgzf_block *h_blocks{};
 		uint32_t *h_status{};
@@ -641,23 +679,23 @@ struct pvc3_bgzf_inflater
 
 namespace {
 
-// The two kernels of one group of blocks on the handle's stream (with room for the tokens of out_bytes of output).
-int launch_inflate(pvc3_bgzf_inflater *h, uint8_t *d_out, size_t out_bytes, uint32_t n_blocks, hipEvent_t start, hipEvent_t stop)
+// The two kernels of one group of blocks on the slot's stream (with room for the tokens of out_bytes of output).
+int launch_inflate(pvc3_bgzf_inflater *h, pvc3_bgzf_inflater::slot &s, uint8_t *d_out, size_t out_bytes, uint32_t n_blocks)
 {
 	size_t const need = out_bytes / 3 + n_blocks + 64;
-	if (need > h->tokens_cap)
+	if (need > s.tokens_cap)
 	{
-		HIP_TRY(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
-		if (h->d_tokens) { (void) hipFree(h->d_tokens); h->d_tokens = nullptr; h->tokens_cap = 0; }
-		HIP_TRY(hipMalloc((void **) &h->d_tokens, (need + need / 8) * sizeof(token_t)), "hipMalloc");
-		h->tokens_cap = need + need / 8;
+		HIP_TRY(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
+		if (s.d_tokens) { (void) hipFree(s.d_tokens); s.d_tokens = nullptr; s.tokens_cap = 0; }
+		HIP_TRY(hipMalloc((void **) &s.d_tokens, (need + need / 8) * sizeof(token_t)), "hipMalloc");
+		s.tokens_cap = need + need / 8;
 	}
 	uint32_t const grid = (n_blocks < h->grid_max) ? n_blocks : h->grid_max, grid_resolve = (n_blocks < h->grid_resolve) ? n_blocks : h->grid_resolve;
-	HIP_TRY(hipEventRecord(start, h->stream), "hipEventRecord");
-	hipLaunchKernelGGL(k_inflate_decode, dim3(grid), dim3(WAVE), 0, h->stream, h->d_in, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
-	hipLaunchKernelGGL(k_inflate_resolve_lanes, dim3(grid_resolve), dim3(WAVE), 0, h->stream, h->d_blocks, d_out, h->d_status, n_blocks, h->d_tokens, h->d_ntok);
+	HIP_TRY(hipEventRecord(s.start, s.stream), "hipEventRecord");
+	hipLaunchKernelGGL(k_inflate_decode, dim3(grid), dim3(WAVE), 0, s.stream, s.d_in, s.d_blocks, d_out, s.d_status, n_blocks, s.d_tokens, s.d_ntok);
+	hipLaunchKernelGGL(k_inflate_resolve_lanes, dim3(grid_resolve), dim3(WAVE), 0, s.stream, s.d_blocks, d_out, s.d_status, n_blocks, s.d_tokens, s.d_ntok);
 	HIP_TRY(hipGetLastError(), "k_inflate_decode");
-	HIP_TRY(hipEventRecord(stop, h->stream), "hipEventRecord");
+	HIP_TRY(hipEventRecord(s.stop, s.stream), "hipEventRecord");
 	return 0;
 }
 
@@ -669,26 +707,17 @@ void pvc3_bgzf_inflater_destroy(pvc3_bgzf_inflater *h)
 {
 	if (!h) return;
 	(void) hipSetDevice(h->device);
-	if (h->stream) (void) hipStreamSynchronize(h->stream);
 	for (auto &s : h->slots)
 	{
-		if (s.h_in) (void) hipHostFree(s.h_in);
-		if (s.h_out) (void) hipHostFree(s.h_out);
-		if (s.h_blocks) (void) hipHostFree(s.h_blocks);
-		if (s.h_status) (void) hipHostFree(s.h_status);
-		if (s.h_off) (void) hipHostFree(s.h_off);
-		if (s.h_lens) (void) hipHostFree(s.h_lens);
-		if (s.h_crc) (void) hipHostFree(s.h_crc);
+		if (s.stream) (void) hipStreamSynchronize(s.stream);
+		for (void *p : {(void *) s.h_in, (void *) s.h_out, (void *) s.h_blocks, (void *) s.h_status, (void *) s.h_off, (void *) s.h_lens, (void *) s.h_crc}) if (p) (void) hipHostFree(p);
+		for (void *p : {(void *) s.d_in, (void *) s.d_out, (void *) s.d_blocks, (void *) s.d_status, (void *) s.d_tokens, (void *) s.d_ntok, (void *) s.d_off, (void *) s.d_lens, (void *) s.d_crc}) if (p) (void) hipFree(p);
 		if (s.start) (void) hipEventDestroy(s.start);
 		if (s.stop) (void) hipEventDestroy(s.stop);
 		if (s.done) (void) hipEventDestroy(s.done);
+		if (s.stream) (void) hipStreamDestroy(s.stream);
 	}
-	if (h->d_in) (void) hipFree(h->d_in);
-	if (h->d_out) (void) hipFree(h->d_out);
-	if (h->d_blocks) (void) hipFree(h->d_blocks);
-	if (h->d_status) (void) hipFree(h->d_status);
-	for (void *p : {(void *) h->d_off, (void *) h->d_lens, (void *) h->d_crc, (void *) h->d_crc_tables, (void *) h->d_tokens, (void *) h->d_ntok}) if (p) (void) hipFree(p);
-	if (h->stream) (void) hipStreamDestroy(h->stream);
+	if (h->d_crc_tables) (void) hipFree(h->d_crc_tables);
 	delete h;
 }
 
@@ -718,16 +747,16 @@ int pvc3_bgzf_inflater_create(int device, size_t max_in_bytes, size_t max_out_by
 		check(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, k_inflate_resolve_lanes, WAVE, 0), "hipOccupancyMaxActiveBlocksPerMultiprocessor");
 		h->grid_resolve = (uint32_t) prop.multiProcessorCount * (uint32_t) ((per_cu_b < 1) ? 1 : per_cu_b);
 	}
-	check(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
-	if (0 == rc) check(hipMalloc((void **) &h->d_in, max_in_bytes + IN_SLACK), "hipMalloc");
-	if (0 == rc) check(hipMalloc((void **) &h->d_out, max_out_bytes), "hipMalloc");
-	if (0 == rc) check(hipMalloc((void **) &h->d_blocks, max_blocks * sizeof(pvc3_bgzf_block)), "hipMalloc");
-	if (0 == rc) check(hipMalloc((void **) &h->d_status, max_blocks * sizeof(uint32_t)), "hipMalloc");
-	if (0 == rc) check(hipMalloc((void **) &h->d_ntok, max_blocks * sizeof(uint32_t)), "hipMalloc");
 	for (uint32_t i = 0; i < n_slots && 0 == rc; ++i)
 	{
 		auto &s = h->slots[i];
-		check(hipHostMalloc((void **) &s.h_in, max_in_bytes + IN_SLACK, hipHostMallocDefault), "hipHostMalloc");
+		check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+		if (0 == rc) check(hipMalloc((void **) &s.d_in, max_in_bytes + IN_SLACK), "hipMalloc");
+		if (0 == rc) check(hipMalloc((void **) &s.d_out, max_out_bytes), "hipMalloc");
+		if (0 == rc) check(hipMalloc((void **) &s.d_blocks, max_blocks * sizeof(pvc3_bgzf_block)), "hipMalloc");
+		if (0 == rc) check(hipMalloc((void **) &s.d_status, max_blocks * sizeof(uint32_t)), "hipMalloc");
+		if (0 == rc) check(hipMalloc((void **) &s.d_ntok, max_blocks * sizeof(uint32_t)), "hipMalloc");
+		if (0 == rc) check(hipHostMalloc((void **) &s.h_in, max_in_bytes + IN_SLACK, hipHostMallocDefault), "hipHostMalloc");
 		if (0 == rc) check(hipHostMalloc((void **) &s.h_out, max_out_bytes, hipHostMallocDefault), "hipHostMalloc");
 		if (0 == rc) check(hipHostMalloc((void **) &s.h_blocks, max_blocks * sizeof(pvc3_bgzf_block), hipHostMallocDefault), "hipHostMalloc");
 		if (0 == rc) check(hipHostMalloc((void **) &s.h_status, max_blocks * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
@@ -742,8 +771,8 @@ int pvc3_bgzf_inflater_create(int device, size_t max_in_bytes, size_t max_out_by
 
 uint32_t pvc3_bgzf_inflater_blocks_in_flight(pvc3_bgzf_inflater const *h) { return h ? h->grid_max : 0; }
 
-// Fewer blocks at a time than the chip's LDS holds (0: as many as it holds again): a caller whose other kernels run next to the
-// inflater's leaves them room — a block being inflated keeps 39 KB of its CU's LDS for milliseconds.
+// Fewer blocks of a launch at a time than the chip's LDS holds (0: as many as it holds again), for a caller whose other kernels run
+// next to the inflater's.
 int pvc3_bgzf_inflater_limit_in_flight(pvc3_bgzf_inflater *h, uint32_t blocks)
 {
 	if (!h) return fail(E_INVALID, "pvc3_bgzf_inflater_limit_in_flight: null argument");
@@ -768,12 +797,12 @@ int pvc3_bgzf_inflater_submit(pvc3_bgzf_inflater *h, uint32_t slot, uint32_t n_b
 			return fail(E_INVALID, "pvc3_bgzf_inflater_submit: a block outside the slot's input or output");
 	}
 	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
-	HIP_TRY(hipMemcpyAsync(h->d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
-	HIP_TRY(hipMemcpyAsync(h->d_blocks, s.h_blocks, n_blocks * sizeof(pvc3_bgzf_block), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
-	if (int const rc = launch_inflate(h, h->d_out, h->max_out, n_blocks, s.start, s.stop)) return rc;
-	HIP_TRY(hipMemcpyAsync(s.h_status, h->d_status, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
-	if (out_bytes) HIP_TRY(hipMemcpyAsync(s.h_out, h->d_out, out_bytes, hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
-	HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
+	HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(s.d_blocks, s.h_blocks, n_blocks * sizeof(pvc3_bgzf_block), hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+	if (int const rc = launch_inflate(h, s, s.d_out, h->max_out, n_blocks)) return rc;
+	HIP_TRY(hipMemcpyAsync(s.h_status, s.d_status, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+	if (out_bytes) HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, out_bytes, hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+	HIP_TRY(hipEventRecord(s.done, s.stream), "hipEventRecord");
 	s.n = n_blocks; s.busy = true;
 	return 0;
 }
@@ -789,17 +818,17 @@ int pvc3_bgzf_inflater_submit_device(pvc3_bgzf_inflater *h, uint32_t slot, uint3
 	auto &s = h->slots[slot];
 	if (s.busy) return fail(E_STATE, "pvc3_bgzf_inflater_submit_device: the slot has not been waited for");
 	HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
-	if (!h->d_off)
+	if (!h->d_crc_tables)
 	{
-		HIP_TRY(hipMalloc((void **) &h->d_off, h->max_blocks * sizeof(uint64_t)), "hipMalloc");
-		HIP_TRY(hipMalloc((void **) &h->d_lens, h->max_blocks * sizeof(uint32_t)), "hipMalloc");
-		HIP_TRY(hipMalloc((void **) &h->d_crc, h->max_blocks * sizeof(uint32_t)), "hipMalloc");
 		HIP_TRY(hipMalloc((void **) &h->d_crc_tables, sizeof(pvc3_crc::tables)), "hipMalloc");
 		pvc3_crc::tables const t = pvc3_crc::make_tables();
 		HIP_TRY(hipMemcpy(h->d_crc_tables, &t, sizeof(t), hipMemcpyHostToDevice), "hipMemcpy");
 	}
-	if (!s.h_off)
+	if (!s.d_off)
 	{
+		HIP_TRY(hipMalloc((void **) &s.d_off, h->max_blocks * sizeof(uint64_t)), "hipMalloc");
+		HIP_TRY(hipMalloc((void **) &s.d_lens, h->max_blocks * sizeof(uint32_t)), "hipMalloc");
+		HIP_TRY(hipMalloc((void **) &s.d_crc, h->max_blocks * sizeof(uint32_t)), "hipMalloc");
 		HIP_TRY(hipHostMalloc((void **) &s.h_off, h->max_blocks * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc");
 		HIP_TRY(hipHostMalloc((void **) &s.h_lens, h->max_blocks * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
 		HIP_TRY(hipHostMalloc((void **) &s.h_crc, h->max_blocks * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
@@ -811,16 +840,16 @@ int pvc3_bgzf_inflater_submit_device(pvc3_bgzf_inflater *h, uint32_t slot, uint3
 			return fail(E_INVALID, "pvc3_bgzf_inflater_submit_device: a block outside the slot's input or the output");
 		s.h_off[i] = b.out_off; s.h_lens[i] = b.out_len;
 	}
-	HIP_TRY(hipMemcpyAsync(h->d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
-	HIP_TRY(hipMemcpyAsync(h->d_blocks, s.h_blocks, n_blocks * sizeof(pvc3_bgzf_block), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
-	HIP_TRY(hipMemcpyAsync(h->d_off, s.h_off, n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
-	HIP_TRY(hipMemcpyAsync(h->d_lens, s.h_lens, n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream), "hipMemcpyAsync");
-	if (int const rc = launch_inflate(h, (uint8_t *) d_out, d_out_bytes, n_blocks, s.start, s.stop)) return rc;
-	hipLaunchKernelGGL(pvc3_crc::k_crc32_ranges, dim3((n_blocks < 4096) ? n_blocks : 4096), dim3(64), 0, h->stream, (uint8_t const *) d_out, h->d_off, h->d_lens, 0u, 0u, n_blocks, h->d_crc_tables, h->d_crc);
+	HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(s.d_blocks, s.h_blocks, n_blocks * sizeof(pvc3_bgzf_block), hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(s.d_off, s.h_off, n_blocks * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(s.d_lens, s.h_lens, n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream), "hipMemcpyAsync");
+	if (int const rc = launch_inflate(h, s, (uint8_t *) d_out, d_out_bytes, n_blocks)) return rc;
+	hipLaunchKernelGGL(pvc3_crc::k_crc32_ranges, dim3((n_blocks < 4096) ? n_blocks : 4096), dim3(64), 0, s.stream, (uint8_t const *) d_out, s.d_off, s.d_lens, 0u, 0u, n_blocks, h->d_crc_tables, s.d_crc);
 	HIP_TRY(hipGetLastError(), "k_crc32_ranges");
-	HIP_TRY(hipMemcpyAsync(s.h_status, h->d_status, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
-	HIP_TRY(hipMemcpyAsync(s.h_crc, h->d_crc, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream), "hipMemcpyAsync");
-	HIP_TRY(hipEventRecord(s.done, h->stream), "hipEventRecord");
+	HIP_TRY(hipMemcpyAsync(s.h_status, s.d_status, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+	HIP_TRY(hipMemcpyAsync(s.h_crc, s.d_crc, n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream), "hipMemcpyAsync");
+	HIP_TRY(hipEventRecord(s.done, s.stream), "hipEventRecord");
 	s.n = n_blocks; s.busy = true;
 	return 0;
 }

@@ -39,6 +39,7 @@ struct device_records_result
 	uint64_t blocks_host{};
 	std::vector <std::pair <uint32_t, uint32_t>> ranges;
 	double rss_setup_mb{};
+	double t_writer_wait{}, t_writer_fetch{}, t_writer_file{};		// of t_writer: waiting for the compressor, its bytes fetched, written to the file
 	double t_drain{}, t_total{};				// the writer's last pieces after the main thread's last; the whole call but for the objects' destruction
 	std::vector <uint64_t> removed_tags;		// [65536]
 	// per piece, seconds since the path began: handed to the inflater, taken up by the main thread, inflated, records found, projected, rewritten (and handed to the compressor)
@@ -91,6 +92,9 @@ inline void zlib_inflate_block(uint8_t const *src, std::size_t in_len, uint8_t *
 
 }
 
+// Slots of the compressor: one being filled and compressed, one whose bytes are coming back, one whose bytes are going to the file.
+constexpr unsigned device_records_out_slots = 3;
+
 // What the two codecs are made for, from the sizes of a piece (so that a caller can make them ahead of time).
 struct device_records_sizes
 {
@@ -115,7 +119,7 @@ inline device_records_result run_device_records(device_records_options const &op
 	auto bgzf_check = [](int rc, char const *what) { if (rc) throw io_error(std::string(what) + ": " + pvc3_bgzf_last_error()); };
 	auto rec_check = [](int rc, char const *what) { if (rc) throw io_error(std::string(what) + ": " + pvc3_last_error()); };
 
-	constexpr unsigned IN_SLOTS = PVC3_RECORDS_SLOTS, OUT_SLOTS = 2;
+	constexpr unsigned IN_SLOTS = PVC3_RECORDS_SLOTS, OUT_SLOTS = device_records_out_slots;
 	auto const t_begin = now();
 	device_records_sizes const sz = device_records_sizes::of(opt.piece_compressed, opt.piece_stream);
 	std::size_t const max_in = sz.max_in;
@@ -268,6 +272,24 @@ inline device_records_result run_device_records(device_records_options const &op
 	bool writer_done = false;
 	std::exception_ptr writer_error;
 	std::thread writer([&]() {
+		// The bytes of one piece go to the file (on a thread of their own) while the next piece's come back from the GPU.
+		std::future <void> writing;
+		unsigned writing_slot = 0;
+		bool writing_last = false;		// the write in flight is the last of its slot
+		auto finish_write = [&]() {
+			if (!writing.valid()) return;
+			auto const t = now();
+			writing.get();
+			res.t_writer_file += since(t);
+			if (writing_last)
+			{
+				{
+					std::lock_guard <std::mutex> lock(m);
+					out_free[writing_slot] = true;
+				}
+				cv.notify_all();
+			}
+		};
 		try
 		{
 			for (;;)
@@ -276,29 +298,44 @@ inline device_records_result run_device_records(device_records_options const &op
 				{
 					std::unique_lock <std::mutex> lock(m);
 					cv.wait(lock, [&]() { return writer_done || !to_write.empty(); });
-					if (to_write.empty()) return;
+					if (to_write.empty()) break;
 					slot = to_write.front(); to_write.pop_front();
 				}
 				auto const t0 = now();
 				uint64_t total = 0; float ms = 0;
 				bgzf_check(pvc3_bgzf_dev_wait(deflater, slot, &total, &ms), "pvc3_bgzf_dev_wait");
+				res.t_writer_wait += since(t0);
 				for (uint64_t off = 0; off < total; )
 				{
+					if (writing.valid() && writing_slot == slot) finish_write();		// (a piece that comes back in several parts: they share the slot's page-locked memory)
 					uint8_t const *bytes{}; uint64_t n = 0;
+					auto const t1 = now();
 					bgzf_check(pvc3_bgzf_dev_fetch(deflater, slot, off, &bytes, &n), "pvc3_bgzf_dev_fetch");
-					opt.write_blocks(bytes, n);
+					res.t_writer_fetch += since(t1);
+					finish_write();
 					off += n;
+					writing_slot = slot; writing_last = off >= total;
+					writing = std::async(std::launch::async, [&opt, bytes, n]() { opt.write_blocks(bytes, n); });
+				}
+				if (0 == total)
+				{
+					finish_write();
+					{
+						std::lock_guard <std::mutex> lock(m);
+						out_free[slot] = true;
+					}
+					cv.notify_all();
 				}
 				res.deflate_kernel_s += 1e-3 * ms; res.bytes_out += total;
 				res.t_writer += since(t0);
-				{
-					std::lock_guard <std::mutex> lock(m);
-					out_free[slot] = true;
-				}
-				cv.notify_all();
 			}
+			finish_write();
 		}
-		catch (...) { std::lock_guard <std::mutex> lock(m); writer_error = std::current_exception(); writer_done = true; cv.notify_all(); }
+		catch (...)
+		{
+			if (writing.valid()) { try { writing.get(); } catch (...) {} }
+			std::lock_guard <std::mutex> lock(m); writer_error = std::current_exception(); writer_done = true; cv.notify_all();
+		}
 	});
 	struct join_threads
 	{

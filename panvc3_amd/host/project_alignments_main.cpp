@@ -332,6 +332,11 @@ struct write_job
 
 int main(int argc, char **argv)
 {
+	// The record path on the GPU keeps seven streams busy (the context's, three of the inflater, the compressor's ...); the HIP runtime
+	// spreads a process's streams over four hardware queues unless told otherwise, and two streams that land on one queue take
+	// turns: the compressed bytes then came back at 10 GB/s behind an inflate kernel instead of 40 (every other run, as the threads
+	// that make the streams happened to be scheduled).  Read by the runtime when it starts; a value in the environment wins.
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	options opt;
 	static option const long_opts[] = {
 		{"alignments", required_argument, nullptr, 'a'}, {"bam-input", no_argument, nullptr, 'B'}, {"msa-index", required_argument, nullptr, 'm'},
@@ -620,7 +625,7 @@ int main(int argc, char **argv)
 			int const first_device = opt.devices.front();
 			after_contexts = [&]() {
 				records_inflater = std::async(std::launch::async, [&]() { pvc3_bgzf_inflater *h{}; if (pvc3_bgzf_inflater_create(first_device, sizes.max_in, 1, sizes.max_blocks_in, PVC3_RECORDS_SLOTS, &h)) inflater_message = pvc3_bgzf_last_error(); return h; });
-				records_deflater = std::async(std::launch::async, [&]() { pvc3_bgzf_dev *h{}; if (pvc3_bgzf_dev_create(first_device, sizes.max_blocks_out, 2, &h)) deflater_message = pvc3_bgzf_last_error(); return h; });
+				records_deflater = std::async(std::launch::async, [&]() { pvc3_bgzf_dev *h{}; if (pvc3_bgzf_dev_create(first_device, sizes.max_blocks_out, device_records_out_slots, &h)) deflater_message = pvc3_bgzf_last_error(); return h; });
 			};
 			// the longest read decides between 128- and 256-byte position windows: the first records of the file are looked at on the host
 			// (while the HIP runtime is still starting)
@@ -708,7 +713,8 @@ int main(int argc, char **argv)
 				std::cerr << "\tRecord path on the GPU: " << dr.records << " records in " << dr.batches << " pieces; " << dr.blocks_in << " blocks in (" << dr.blocks_host << " of them the host's share, " << dr.blocks_refused << " inflated on the host instead), "
 						  << dr.bytes_in << " bytes of records in, " << dr.bytes_out << " bytes of file out; kernels: inflate " << dr.inflate_kernel_s << " s, deflate " << dr.deflate_kernel_s << " s\n";
 				std::cerr << "\tStages (s): start-up " << t_startup << ", reader thread " << dr.t_reader << ", codecs and buffers " << dr.t_setup << ", main: waiting for the reader " << dr.t_wait_read << ", waiting for the inflaters " << dr.t_inflate_wait << " (host threads at work " << dr.t_host_inflate << ")"
-						  << ", records found and scattered " << dr.t_frame << ", projected " << dr.t_project << ", rewritten " << dr.t_rewrite << ", waiting for the writer " << dr.t_wait_writer << ", writer thread " << dr.t_writer << '\n';
+						  << ", records found and scattered " << dr.t_frame << ", projected " << dr.t_project << ", rewritten " << dr.t_rewrite << ", waiting for the writer " << dr.t_wait_writer << ", writer thread " << dr.t_writer
+						  << " (waiting for the compressor " << dr.t_writer_wait << ", fetching " << dr.t_writer_fetch << ", writing " << dr.t_writer_file << ")\n";
 				std::cerr << "\tTimeline (s): GPU contexts " << t_contexts_up << ", index file and FASTA " << t_files_read << ", both " << t_prepared << ", first reads looked at " << t_peeked << ", index on the GPUs (start-up done) " << t_startup
 						  << ", record path begun " << t_records_begin << " (its last pieces written in " << dr.t_drain << ", all of it " << dr.t_total << "), last batch rewritten " << t_batches_done << ", output closed " << t_closed << "; wall clock at the start " << std::fixed << epoch_start << ", now "
 						  << std::chrono::duration <double>(std::chrono::system_clock::now().time_since_epoch()).count() << std::defaultfloat

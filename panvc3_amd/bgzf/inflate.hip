@@ -281,9 +281,8 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
 	return v;
 }
 
-// A symbol takes 10 + 5 + 9 + 13 = 37 bits at most through the tables, and every lane looks at 64 of its own: the walk goes on
-// while a symbol begins in the lanes.
-constexpr unsigned WALK_LAST = 63;
+// (A symbol takes 10 + 5 + 9 + 13 = 37 bits at most through the tables, and every lane looks at 64 of its own: the walk goes on
+// while a symbol begins in the lanes.)
 
 __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 	uint8_t const *__restrict__ in, pvc3_bgzf_block const *__restrict__ blocks, uint8_t *__restrict__ out, uint32_t *__restrict__ status, uint32_t n_blocks,
@@ -434,13 +433,21 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 				uint32_t o = 0;
 				uint64_t chain = 0;
 				uint32_t t = (uint32_t) __builtin_amdgcn_readlane((int) bits, 0);
-				while (t)
-				{
-					chain |= uint64_t(1) << o;
-					o += t;
-					if (o > WALK_LAST) break;
-					t = (uint32_t) __builtin_amdgcn_readlane((int) bits, (int) o);
-				}
+				// while (t) { chain |= 1 << o; o += t; if (o > 63) break; t = readlane(bits, o); } — written out, because the compiler makes
+				// fifteen instructions and two taken branches per symbol of it, and this loop is where a block's time goes.  (s_nop 1: four
+				// wait states between the scalar write of o and its use as v_readlane's lane select.)
+				if (t)
+					asm volatile("1:\n\t"
+						"s_bitset1_b64 %[chain], %[o]\n\t"
+						"s_add_u32 %[o], %[o], %[t]\n\t"
+						"s_cmp_gt_u32 %[o], 63\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_nop 1\n\t"
+						"v_readlane_b32 %[t], %[bits], %[o]\n\t"
+						"s_cmp_lg_u32 %[t], 0\n\t"
+						"s_cbranch_scc1 1b\n\t"
+						"2:"
+						: [chain] "+s"(chain), [o] "+s"(o), [t] "+s"(t) : [bits] "v"(bits) : "scc");
 				bool const stopped = 0 == t;
 				bool const on_chain = 0 != ((chain >> lane) & 1);
 				uint32_t const makes = !on_chain ? 0u : (K_LITERAL == kind) ? 1u : length;

@@ -521,12 +521,13 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 // kernel: 0.70 ms a block).  Most matches of a stretch do not depend on each other (they copy from a record or two back), so: the
 // matches come 64 at a time, one per lane; a lane finds the earlier matches of the 64 whose output it reads (their places ascend:
 // two binary searches through ds_bpermute, and none at all when every source lies before the first place of the 64 — the usual
-// case); then, in rounds, every match whose sources are all written copies at once — each lane its own, five aligned dwords in and
-// up to 16 bytes out — and the few that are long, or repeat a pattern of their own output, go one at a time across the lanes.
-// 0.33 ms a block.
+// case); then, in rounds, every match whose sources are all written copies at once — each lane its own, up to 32 bytes in four
+// unaligned 8-byte accesses each way — and the few that are longer, or repeat a pattern of their own output, go one at a time across
+// the lanes.  (zlib level 6 on BAM records, tools/calib/token_stats.py: 5 900 matches a block, 99 % of them at most 32 bytes, 18 % read
+// another of their 64, 3.8 rounds per 64.)
 constexpr unsigned RESOLVE_BYTES = 65536;		// a block's output: ISIZE at most
-constexpr unsigned RESOLVE_SLACK = 48;		// the block may begin 15 bytes in, and a lane reads 19 bytes past its match's first
-constexpr unsigned LANE_COPY_MAX = 16;
+constexpr unsigned RESOLVE_SLACK = 48;		// the block may begin 15 bytes in, and a lane reads 24 bytes from its match's first whatever its length
+constexpr unsigned LANE_COPY_MAX = 32;
 __global__ __launch_bounds__(WAVE) void k_inflate_resolve_lanes(pvc3_bgzf_block const *__restrict__ blocks, uint8_t *__restrict__ out, uint32_t const *__restrict__ status, uint32_t n_blocks,
 	token_t const *__restrict__ tokens, uint32_t const *__restrict__ n_tokens)
 {
@@ -558,7 +559,6 @@ __global__ __launch_bounds__(WAVE) void k_inflate_resolve_lanes(pvc3_bgzf_block 
 		uint32_t const tail = h + 16 * n_q;
 		if (tail + lane < want) B[tail + lane] = dst[tail + lane];
 		__syncthreads();
-		uint32_t const *const words = reinterpret_cast <uint32_t const *>(buf);
 		for (uint32_t t0 = 0; t0 < n; t0 += WAVE)
 		{
 			bool const valid = t0 + lane < n;
@@ -593,14 +593,35 @@ __global__ __launch_bounds__(WAVE) void k_inflate_resolve_lanes(pvc3_bgzf_block 
 				{
 					if (ready && by_lane)
 					{
-						uint32_t const a = b_off + from;
-						uint32_t const *w = words + (a >> 2);
-						uint32_t const w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
-						uint32_t d[4] = {__builtin_amdgcn_alignbyte(w1, w0, a & 3), __builtin_amdgcn_alignbyte(w2, w1, a & 3), __builtin_amdgcn_alignbyte(w3, w2, a & 3), __builtin_amdgcn_alignbyte(w4, w3, a & 3)};
-						if (1 == dist) d[0] = d[1] = d[2] = d[3] = (d[0] & 0xff) * 0x01010101u;
-#pragma unroll
-						for (uint32_t j = 0; j < LANE_COPY_MAX; ++j)
-							if (j < length) B[pos + j] = (uint8_t) (d[j / 4] >> (8 * (j % 4)));
+						// eight bytes at a time at any address (LDS takes unaligned accesses on this target), the last eight — or four — of a
+						// match once more where they end; every read before the first write
+						uint8_t const *src = B + from;
+						uint8_t *to = B + pos;
+						bool const small = length < 8;
+						uint64_t r0, r1, r2, rt;
+						__builtin_memcpy(&r0, src, 8);
+						__builtin_memcpy(&r1, src + 8, 8);
+						__builtin_memcpy(&r2, src + 16, 8);
+						__builtin_memcpy(&rt, src + (small ? 0 : length - 8), 8);
+						if (1 == dist) r0 = r1 = r2 = rt = (r0 & 0xff) * UINT64_C(0x0101010101010101);
+						if (small)
+						{
+							uint32_t const lo = (uint32_t) r0;
+							if (3 == length) { uint16_t const h = (uint16_t) lo; __builtin_memcpy(to, &h, 2); to[2] = (uint8_t) (lo >> 16); }
+							else
+							{
+								uint32_t const hi = (uint32_t) (r0 >> (8 * (length - 4)));
+								__builtin_memcpy(to, &lo, 4);
+								__builtin_memcpy(to + length - 4, &hi, 4);
+							}
+						}
+						else
+						{
+							__builtin_memcpy(to, &r0, 8);
+							if (length >= 16) __builtin_memcpy(to + 8, &r1, 8);
+							if (length >= 24) __builtin_memcpy(to + 16, &r2, 8);
+							__builtin_memcpy(to + length - 8, &rt, 8);
+						}
 					}
 				}
 				for (uint64_t rest = round & ~__ballot(ready && by_lane); rest; rest &= rest - 1)

@@ -245,12 +245,10 @@ def test_inflate_zlib_streams(gpu_inflater):
 
 
 @pytest.mark.gpu
-def test_inflate_matches_that_reach_behind_the_ring(gpu_inflater):
-	"""The inflater keeps the output's last 8 KB in LDS; a match whose source begins further back reads the output in global memory,
-	and one that begins behind the ring and reaches into it reads both.  zlib's level 9 finds a copy of a block of random bytes at
-	every distance up to 32 KB: distances around the ring's size and its half, a few bytes and whole blocks past it, the longest
-	match at the largest distance, copies that overlap their own output, several far copies in a row, in the pinned-output form and
-	in the device-resident one."""
+def test_inflate_matches_at_every_distance(gpu_inflater):
+	"""zlib's level 9 finds a copy of a block of random bytes at every distance up to 32 KB: distances around powers of two, the
+	longest match at the largest distance, copies that overlap their own output, several far copies in a row, in the pinned-output
+	form and in the device-resident one.  (Written for an inflater that kept only the output's last 8 KB in LDS.)"""
 	rng = np.random.default_rng(41)
 	cases = []
 	for dist in (4000, 4095, 4096, 4097, 7800, 8000, 8191, 8192, 8193, 8450, 12000, 16384, 20000, 32000, 32768):
@@ -272,6 +270,40 @@ def test_inflate_matches_that_reach_behind_the_ring(gpu_inflater):
 	dev, st2, crcs = gpu_inflater.inflate_to_device(streams, sizes, slot=1)
 	assert not st2.any() and dev == b"".join(c[:65536] for c in cases)
 	assert [int(x) for x in crcs] == [zlib.crc32(c[:65536]) & 0xffffffff for c in cases]
+
+
+@pytest.mark.gpu
+def test_inflate_matches_that_copy_matches(gpu_inflater):
+	"""What the second kernel (k_inflate_resolve_lanes) has to order: matches whose sources are other matches' output a few bytes
+	back.  Periods of 1 .. 24 bytes (every match overlaps its own output and copies the one before it), texts made of copies of
+	their own last few hundred bytes (64 matches in a row that read each other), lengths around the 16 bytes a lane copies by itself,
+	and symbol frequencies that give codes longer than the decoder's tables index (the one-symbol path)."""
+	rng = np.random.default_rng(43)
+	cases = []
+	for period in range(1, 25):
+		unit = bytes(rng.integers(0, 256, size=period, dtype=np.uint8))
+		cases.append((unit * (3000 // period + 1))[:3000] + bytes(rng.integers(0, 256, size=20, dtype=np.uint8)) + unit * 40)
+	for reach, longest in ((40, 12), (300, 40), (300, 17), (2000, 300), (64, 16)):
+		out = bytearray(rng.integers(0, 256, size=64, dtype=np.uint8))
+		while len(out) < 60000:
+			back = int(rng.integers(1, min(reach, len(out)) + 1)); n = int(rng.integers(3, longest + 1))
+			for _ in range(n): out.append(out[-back])		# (a copy that may overlap itself)
+			if rng.random() < 0.3: out.extend(rng.integers(0, 256, size=int(rng.integers(1, 4)), dtype=np.uint8).tobytes())
+		cases.append(bytes(out[:65536]))
+	ranks = np.arange(1, 257, dtype=np.float64)
+	skewed = rng.choice(256, size=65536, p=(1 / ranks ** 1.6) / (1 / ranks ** 1.6).sum()).astype(np.uint8)
+	cases.append(bytes(skewed))
+	cases.append(bytes(skewed[:30000]) + bytes(skewed[100:30100]))
+	streams, sizes, want = [], [], []
+	for c in cases:
+		for level in (1, 6, 9):
+			streams.append(_raw_deflate(c, level)); sizes.append(len(c)); want.append(c)
+	got, status, _ = gpu_inflater.inflate(streams, sizes, gap=3)
+	bad = [i for i in range(len(want)) if status[i] != 0 or got[i] != want[i]]
+	assert not bad, (bad[:5], [int(status[i]) for i in bad[:5]])
+	dev, st2, crcs = gpu_inflater.inflate_to_device(streams, sizes, slot=1)
+	assert not st2.any() and dev == b"".join(want)
+	assert [int(x) for x in crcs] == [zlib.crc32(c) & 0xffffffff for c in want]
 
 
 @pytest.mark.gpu

@@ -232,6 +232,14 @@ __device__ __forceinline__ token_t make_token(uint32_t pos, uint32_t length, uin
 // ranges of bytes that do not overlap get ranges of tokens that do not overlap.
 __device__ __forceinline__ size_t token_base(uint64_t out_off) { return (size_t) ((out_off + 2) / 3); }
 
+// -DPVC3_INF_CYCLES (tools/calib/inf_variants/cycles.py): the shader clock at the seams of a pass, summed per block and left in the
+// block's first 72 bytes of output instead of its bytes.
+#ifdef PVC3_INF_CYCLES
+#define TICK(k) do { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); cyc[k] += now_ - last_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_) :: "memory"); } while (0)
+#else
+#define TICK(k) do {} while (0)
+#endif
+
 // ---- decoding ---------------------------------------------------------------------------------------------------------------------------
 // Table entries that hold everything a lane needs to decode its symbol without a branch.
 //   literal / length: value (the literal's byte | the length's base) | code length << 9 | extra bits << 13 | kind << 16
@@ -302,6 +310,9 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 		uint8_t *const dst = out + blk.out_off;
 		token_t *const tok = tokens + token_base(blk.out_off);
 		uint32_t n_tok = 0;
+#ifdef PVC3_INF_CYCLES
+		uint64_t cyc[9] = {}, last_ = 0;
+#endif
 
 		for (bool last = false; !last && ST_OK == st; )
 		{
@@ -405,12 +416,17 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 			// how many bits it takes and how many bytes it makes.  A scalar walk then only follows the chain (o, o + bits of the
 			// symbol at o, ...: one v_readlane and seven scalar instructions per symbol); the lanes on the chain get the places of
 			// their output from a prefix sum across the wave and store — a literal its byte, a match its token.
-			// The bits come straight from the staged dwords here (five of them, out of the lanes, hold every lane's 64 bits): the
-			// scalar window is only set up again for what the lanes do not decode — codes longer than the tables' index (rare)
-			// and the end of the block go through the one-symbol path behind the walk.
+			// The bits come straight from the staged dwords here (five of them, out of the lanes, hold every lane's 64 bits); the
+			// scalar window is set up again behind the block.  What the lanes do not decode — codes longer than the tables' index
+			// (3.7 % of the symbols of zlib's level 6 on BAM records) and the end of the block — goes through the one-symbol path
+			// behind the walk.
 			uint32_t at_bit = br.position();
+#ifdef PVC3_INF_CYCLES
+			asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_) :: "memory");
+#endif
 			for (bool end_of_block = false; !end_of_block && ST_OK == st; )
 			{
+				TICK(7);
 				uint32_t const w0 = at_bit >> 5;
 				if (w0 < br.batch_first || w0 + 5 > br.batch_first + WAVE) br.load_batch(w0);		// (before: the one-symbol path has read ahead)
 				uint32_t const i0 = w0 - br.batch_first;
@@ -421,21 +437,28 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 				bool const z0 = q < 32, z1 = q < 64;
 				uint32_t const d0 = z0 ? s0 : z1 ? s1 : s2, d1 = z0 ? s1 : z1 ? s2 : s3, d2 = z0 ? s2 : z1 ? s3 : s4;
 				uint64_t const mine = (uint64_t) __builtin_amdgcn_alignbit(d1, d0, q & 31) | ((uint64_t) __builtin_amdgcn_alignbit(d2, d1, q & 31) << 32);
+				asm volatile("" :: "v"(mine));
+				TICK(0);
 				uint32_t const e = L.t_ll[(uint32_t) mine & ((1u << LL_BITS) - 1)];
 				uint32_t const l = (e >> 9) & 15, x = (e >> 13) & 7, kind = e >> 16;
 				uint32_t const length = (e & 0x1ff) + __builtin_amdgcn_ubfe((uint32_t) (mine >> l), 0, x);		// (a literal's byte, for a literal)
 				uint32_t const behind = (uint32_t) (mine >> (l + x));
+				asm volatile("" :: "v"(behind), "v"(length));
+				TICK(1);
 				uint32_t const ed = L.t_d[behind & ((1u << D_BITS) - 1)];
 				uint32_t const ld = (ed >> 15) & 15, xd = (ed >> 19) & 15;
 				uint32_t const dist = (ed & 0x7fff) + __builtin_amdgcn_ubfe(behind >> ld, 0, xd);
 				bool const is_match = K_MATCH == kind && 0 != (ed >> 23);
 				uint32_t const bits = (K_LITERAL == kind) ? l : is_match ? (l + x + ld + xd) : 0u;		// none: the walk stops here
+				asm volatile("" :: "v"(bits), "v"(dist));
+				TICK(2);
 				uint32_t o = 0;
 				uint64_t chain = 0;
 				uint32_t t = (uint32_t) __builtin_amdgcn_readlane((int) bits, 0);
 				// while (t) { chain |= 1 << o; o += t; if (o > 63) break; t = readlane(bits, o); } — written out, because the compiler makes
-				// fifteen instructions and two taken branches per symbol of it, and this loop is where a block's time goes.  (s_nop 1: four
-				// wait states between the scalar write of o and its use as v_readlane's lane select.)
+				// fifteen instructions and two taken branches per symbol of it, and this loop is where a block's time goes: eight symbols in
+				// a straight line (a pass has six on average), so that the only branch taken is the one that leaves.  (s_nop 1: four wait
+				// states between the scalar write of o and its use as v_readlane's lane select.)
 				if (t)
 					asm volatile("1:\n\t"
 						"s_bitset1_b64 %[chain], %[o]\n\t"
@@ -444,15 +467,74 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 						"s_cbranch_scc1 2f\n\t"
 						"s_nop 1\n\t"
 						"v_readlane_b32 %[t], %[bits], %[o]\n\t"
-						"s_cmp_lg_u32 %[t], 0\n\t"
-						"s_cbranch_scc1 1b\n\t"
+						"s_cmp_eq_u32 %[t], 0\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_bitset1_b64 %[chain], %[o]\n\t"
+						"s_add_u32 %[o], %[o], %[t]\n\t"
+						"s_cmp_gt_u32 %[o], 63\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_nop 1\n\t"
+						"v_readlane_b32 %[t], %[bits], %[o]\n\t"
+						"s_cmp_eq_u32 %[t], 0\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_bitset1_b64 %[chain], %[o]\n\t"
+						"s_add_u32 %[o], %[o], %[t]\n\t"
+						"s_cmp_gt_u32 %[o], 63\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_nop 1\n\t"
+						"v_readlane_b32 %[t], %[bits], %[o]\n\t"
+						"s_cmp_eq_u32 %[t], 0\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_bitset1_b64 %[chain], %[o]\n\t"
+						"s_add_u32 %[o], %[o], %[t]\n\t"
+						"s_cmp_gt_u32 %[o], 63\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_nop 1\n\t"
+						"v_readlane_b32 %[t], %[bits], %[o]\n\t"
+						"s_cmp_eq_u32 %[t], 0\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_bitset1_b64 %[chain], %[o]\n\t"
+						"s_add_u32 %[o], %[o], %[t]\n\t"
+						"s_cmp_gt_u32 %[o], 63\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_nop 1\n\t"
+						"v_readlane_b32 %[t], %[bits], %[o]\n\t"
+						"s_cmp_eq_u32 %[t], 0\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_bitset1_b64 %[chain], %[o]\n\t"
+						"s_add_u32 %[o], %[o], %[t]\n\t"
+						"s_cmp_gt_u32 %[o], 63\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_nop 1\n\t"
+						"v_readlane_b32 %[t], %[bits], %[o]\n\t"
+						"s_cmp_eq_u32 %[t], 0\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_bitset1_b64 %[chain], %[o]\n\t"
+						"s_add_u32 %[o], %[o], %[t]\n\t"
+						"s_cmp_gt_u32 %[o], 63\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_nop 1\n\t"
+						"v_readlane_b32 %[t], %[bits], %[o]\n\t"
+						"s_cmp_eq_u32 %[t], 0\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_bitset1_b64 %[chain], %[o]\n\t"
+						"s_add_u32 %[o], %[o], %[t]\n\t"
+						"s_cmp_gt_u32 %[o], 63\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_nop 1\n\t"
+						"v_readlane_b32 %[t], %[bits], %[o]\n\t"
+						"s_cmp_eq_u32 %[t], 0\n\t"
+						"s_cbranch_scc1 2f\n\t"
+						"s_branch 1b\n\t"
 						"2:"
 						: [chain] "+s"(chain), [o] "+s"(o), [t] "+s"(t) : [bits] "v"(bits) : "scc");
+				TICK(3);
 				bool const stopped = 0 == t;
 				bool const on_chain = 0 != ((chain >> lane) & 1);
 				uint32_t const makes = !on_chain ? 0u : (K_LITERAL == kind) ? 1u : length;
 				uint32_t const upto = wave_inclusive_sum(makes);
 				uint32_t const made = (uint32_t) __builtin_amdgcn_readlane((int) upto, 63);
+				TICK(4);
 				if (pos + made > want) { st = ST_OUTPUT_OVERFLOW; break; }
 				uint32_t const at = pos + upto - makes;
 				if (on_chain && K_LITERAL == kind) dst[at] = (uint8_t) e;
@@ -466,51 +548,66 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 				}
 				pos += made;
 				at_bit += o;
+				TICK(5);
+#ifdef PVC3_INF_CYCLES
+				++cyc[8];
+#endif
 				if (!stopped) continue;
 
-				// one symbol the long way: a code longer than the table's index, the end of the block, or a code that does not exist
-				br.seek(at_bit);
-				uint32_t e1 = uni(L.t_ll[br.peek(LL_BITS)]);
+				// one symbol the long way — a code longer than the table's index, the end of the block, or a code that does not exist — out
+				// of the 64 bits the lane it begins in has looked at (48 at most: 15 + 5 + 15 + 13)
+				uint64_t w = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) mine, (int) o) | ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (mine >> 32), (int) o) << 32);
+				uint32_t e1 = uni(L.t_ll[(uint32_t) w & ((1u << LL_BITS) - 1)]);
 				if (0 == e1)
 				{
 					uint32_t sym = 0, l1 = 0;
-					if (!long_code(br.low32(), LL_BITS + 1, L.sorted_ll, L.ll, sym, l1)) { st = ST_BAD_SYMBOL; break; }
+					if (!long_code((uint32_t) w, LL_BITS + 1, L.sorted_ll, L.ll, sym, l1)) { st = ST_BAD_SYMBOL; break; }
 					e1 = litlen_entry32(sym, l1);
 					if (0 == e1) { st = ST_BAD_SYMBOL; break; }
 				}
-				br.drop((e1 >> 9) & 15);
+				uint32_t used = (e1 >> 9) & 15;
+				w >>= used;
 				uint32_t const kind1 = e1 >> 16;
 				if (K_LITERAL == kind1)
 				{
 					if (pos >= want) { st = ST_OUTPUT_OVERFLOW; break; }
 					if (0 == lane) dst[pos] = (uint8_t) e1;
 					++pos;
-					at_bit = br.position();
+					at_bit += used;
 					continue;
 				}
-				if (K_END == kind1) { end_of_block = true; break; }
-				uint32_t const length1 = (e1 & 0x1ff) + br.take((e1 >> 13) & 7);
-				br.refill();
-				uint32_t ed1 = uni(L.t_d[br.peek(D_BITS)]);
+				if (K_END == kind1) { at_bit += used; end_of_block = true; break; }
+				uint32_t const x1 = (e1 >> 13) & 7;
+				uint32_t const length1 = (e1 & 0x1ff) + ((uint32_t) w & ((1u << x1) - 1));
+				w >>= x1; used += x1;
+				uint32_t ed1 = uni(L.t_d[(uint32_t) w & ((1u << D_BITS) - 1)]);
 				if (0 == ed1)
 				{
 					uint32_t ds = 0, l1 = 0;
-					if (!long_code(br.low32(), D_BITS + 1, L.sorted_d, L.d, ds, l1)) { st = ST_BAD_SYMBOL; break; }
+					if (!long_code((uint32_t) w, D_BITS + 1, L.sorted_d, L.d, ds, l1)) { st = ST_BAD_SYMBOL; break; }
 					ed1 = dist_entry32(ds, l1);
 					if (0 == ed1) { st = ST_BAD_SYMBOL; break; }
 				}
-				br.drop((ed1 >> 15) & 15);
-				uint32_t const dist1 = (ed1 & 0x7fff) + br.take((ed1 >> 19) & 15);
+				uint32_t const ld1 = (ed1 >> 15) & 15, xd1 = (ed1 >> 19) & 15;
+				w >>= ld1;
+				uint32_t const dist1 = (ed1 & 0x7fff) + ((uint32_t) w & ((1u << xd1) - 1));
+				used += ld1 + xd1;
 				if (dist1 > pos) { st = ST_BAD_DISTANCE; break; }
 				if (pos + length1 > want) { st = ST_OUTPUT_OVERFLOW; break; }
 				if (0 == lane) tok[n_tok] = make_token(pos, length1, dist1);
 				++n_tok;
 				pos += length1;
-				at_bit = br.position();
+				at_bit += used;
+				TICK(6);
 			}
+			br.seek(at_bit);		// the scalar window again, for what follows the block
 		}
 		if (ST_OK == st && br.consumed_bits() > uint64_t(8) * blk.in_len) st = ST_INPUT_OVERRUN;
 		if (ST_OK == st && pos != want) st = ST_LENGTH_MISMATCH;
+#ifdef PVC3_INF_CYCLES
+		__threadfence();
+		if (0 == lane && want >= 72) { for (int k = 0; k < 72; ++k) dst[k] = (uint8_t) (cyc[k / 8] >> (8 * (k & 7))); n_tok = 0; }
+#endif
 		if (0 == lane) { status[b] = st; n_tokens[b] = (ST_OK == st) ? n_tok : 0; }
 		__syncthreads();		// the tables are the next block's from here
 	}
@@ -520,8 +617,8 @@ __global__ __launch_bounds__(WAVE) void k_inflate_decode(
 // A match at a time across the lanes costs the latency of LDS — read, wait, write — for a dozen bytes (the first form of this
 // kernel: 0.70 ms a block).  Most matches of a stretch do not depend on each other (they copy from a record or two back), so: the
 // matches come 64 at a time, one per lane; a lane finds the earlier matches of the 64 whose output it reads (their places ascend:
-// two binary searches through ds_bpermute, and none at all when every source lies before the first place of the 64 — the usual
-// case); then, in rounds, every match whose sources are all written copies at once — each lane its own, up to 32 bytes in four
+// two binary searches through ds_bpermute, and none at all when every source lies before the first place of the 64); then, in
+// rounds, every match whose sources are all written copies at once — each lane its own, up to 32 bytes in four
 // unaligned 8-byte accesses each way — and the few that are longer, or repeat a pattern of their own output, go one at a time across
 // the lanes.  (zlib level 6 on BAM records, tools/calib/token_stats.py: 5 900 matches a block, 99 % of them at most 32 bytes, 18 % read
 // another of their 64, 3.8 rounds per 64.)

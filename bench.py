@@ -149,7 +149,7 @@ def cli_end_to_end(n_records):
 			"record_path_host": {"seconds": dt_host, "value": P["n"] / dt_host, "stages": stages_host, "large": {"seconds": dt_host_large, "value": n_large / dt_host_large},
 								 "marginal": (n_large - P["n"]) / max(1e-9, dt_host_large - dt_host)},
 			"what": "bin/panvc3_project_alignments, BAM file in, BAM file out, wall clock of the whole process, best of 3 (large: best of 2, huge: one run): the records are "
-					"inflated, found, projected, written anew and compressed on the GPU (--record-path=gpu, the default; the host's threads inflate a share of the blocks); "
+					"inflated, found, projected, written anew and compressed on the GPU (--record-path=gpu, the default); "
 					"record_path_host: the same with the records on the host's threads; seconds_without_records: the same command on an input without records (index file, FASTA, GPU start-up)",
 		}
 	finally:

@@ -8,7 +8,7 @@
 // waves and a launch of a few thousand blocks fills the chip with independent streams of dependent loads:
 //
 //   parse     64 positions at a time, lane = position.  The candidate of a position is the latest earlier position with the
-//             same hash of its four bytes, from a 4096-entry table in LDS that holds positions of *earlier windows* only
+//             same hash of its four bytes, from a 2048-entry table in LDS that holds positions of *earlier windows* only
 //             (read by all lanes, then updated with ds_max: the largest position wins, whatever the order of the lanes), or
 //             the position one byte back if that matches (runs of one quality value or base: the matches the table cannot
 //             see because they begin inside the window).  Every lane extends its candidate eight bytes per step.  The greedy
@@ -37,7 +37,13 @@ thread_local char g_bgzf_error[256];		// the message of the calling thread's las
 
 namespace {
 
-constexpr unsigned HASH_BITS = 12;
+// 2 048 entries: on BAM records the output is as small as with 4 096 (0.3329 against 0.3334 of the input) and as fast, and a block
+// being compressed holds 11.4 KB of its CU's LDS instead of 19.6 (tools/calib/deflate_hash_bits.py; the code construction's scratch
+// needs 2 048 dwords of it).
+#ifndef PVC3_DEFLATE_HASH_BITS
+#define PVC3_DEFLATE_HASH_BITS 11
+#endif
+constexpr unsigned HASH_BITS = PVC3_DEFLATE_HASH_BITS;
 constexpr unsigned WAVE = 64;
 constexpr unsigned N_LL = 286, N_D = 30, N_CL = 19;
 constexpr unsigned MAX_MATCH = 258, MAX_DIST = 32768;

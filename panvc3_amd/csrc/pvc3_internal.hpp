@@ -148,7 +148,8 @@ struct run_work
 static_assert(80 == sizeof(run_work), "run_work layout");
 constexpr uint64_t TRACE_NONE = ~UINT64_C(0);
 
-// Alignment classes: lanes per run W in {16, 32, 64} x orientation (0: lane = query row, 1: lane = reference column), plus the
+// Alignment classes: shorter side of the run <= 16, 32, 64 (4, 8, 16 lanes per run with four lines of the matrix each) x orientation
+// (0: lines = query rows, 1: lines = reference columns), plus the
 // runs that need the striped one-wave-per-run kernel (short side > 64 or more anti-diagonals than the LDS trace holds).
 constexpr uint32_t DP_CLASSES = 7;
 constexpr uint32_t DP_CLASS_BIG = 6;

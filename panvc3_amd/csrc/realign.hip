@@ -63,16 +63,6 @@ __device__ __forceinline__ double shfl_up_f64(double v)
 	return r.d;
 }
 
-// The same, but lane 0 receives 0.0 (no dependency on the previous contents of the destination: one instruction per half).
-__device__ __forceinline__ double shfl_up_f64_zero(double v)
-{
-	union { double d; int i[2]; } a, r;
-	a.d = v;
-	r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x138, 0xf, 0xf, true);
-	r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x138, 0xf, 0xf, true);
-	return r.d;
-}
-
 // Lane i of every row of 16 receives lane i - 1's value, the first lane of a row receives `first`: DPP row_shr:1.
 __device__ __forceinline__ double row_shr1_f64(double v, double first)
 {
@@ -434,26 +424,34 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 }
 
 
-// ---- packed alignment: t_width lanes per run, 64 / t_width runs per wavefront ----------------------------------------------
+// ---- packed alignment: t_lanes lanes per run with four lines of the matrix each, 64 / t_lanes runs per wavefront ---------------
 // Matrix M(i, j), i = 0..n over the query (vertical), j = 0..m over the reference (horizontal); V = best score ending in a
-// vertical gap (query base against nothing: 'I'), H = horizontal gap ('D').  A lane owns one line of the matrix along the
-// shorter side of the run (t_ref_lanes: a column j, otherwise a row i) and walks along the longer side, one cell per step,
-// lane l one step behind lane l - 1: every step computes one anti-diagonal.  What a cell needs from the neighbouring line
-// (its M and its gap score towards this line) arrives by DPP from lane l - 1; the line's own M and gap score stay in registers.
+// vertical gap (query base against nothing: 'I'), H = horizontal gap ('D').  The lines of the matrix along the shorter side of
+// the run (t_ref_lanes: columns j, otherwise rows i) are dealt out four to a lane, lines 4l + 1 .. 4l + 4 to lane l of the run;
+// a lane walks along the longer side, one position — four cells, from its first line down to its fourth — per step, lane l one
+// step behind lane l - 1.  What the first of a lane's lines needs from the line before it (its M and its gap score towards
+// this line, at the same position) is what lane l - 1 computed for its fourth line one step earlier and arrives by DPP; the
+// other three lines take it from the cell computed just before in the same lane; a line's own M and gap score stay in registers.
+//
+// Until round 4 a lane owned ONE line, so a step computed one anti-diagonal: a run of s x L cells took s + L - 1 steps of
+// max(16, 32, 64) lanes, of which 35 - 50 % were cells (C5: s up to 58, L around 45) at 36 vector instructions a step.  With
+// four lines per lane the fill and drain of the wavefront is a quarter as long (L + s / 4 - 1 steps) and what a step costs
+// beside its cells (the exchange, the stream, the trace) is paid once for four of them.
+constexpr uint32_t DP_LINES = 4;
 struct dp_shared
 {
 	double score[SCORE_ROWS][2];					// [phred or NO_QUAL][0 match, 1 mismatch]
-	uint16_t stream[4][64 + DP_MAX_STEPS + 8];		// per run: the items along the longer side, dna5 rank | phred << 8, behind 64 unused entries
+	uint16_t stream[16][64 + DP_MAX_STEPS + 8];		// per run: the items along the longer side, dna5 rank | phred << 8, behind 64 unused entries
 };
-constexpr uint32_t TRACE_CHUNK = 16384;				// trace words a wave takes from the trace buffer at a time (16 - 64 tasks)
+constexpr uint32_t TRACE_CHUNK = 16384;				// trace words a wave takes from the trace buffer at a time (4 - 64 tasks)
 
-template <uint32_t t_width, bool t_ref_lanes>
+template <uint32_t t_lanes, bool t_ref_lanes>
 __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_params const *__restrict__ prm, uint32_t cls, dp_shared &S)
 {
-	constexpr uint32_t G = 64 / t_width;
-	constexpr uint32_t FILL = DP_MAX_STEPS / t_width;		// stream items a lane fetches at most
+	constexpr uint32_t G = 64 / t_lanes;
+	constexpr uint32_t TASK_WORDS = ((DP_MAX_STEPS + t_lanes + 3) / 4) * 128;		// trace words of a task at most
 	uint32_t const lane = lane_id();
-	uint32_t const g = lane / t_width, l = lane % t_width;
+	uint32_t const g = lane / t_lanes, l = lane % t_lanes;
 	for (uint32_t i = lane; i < SCORE_ROWS; i += 64)
 	{
 		S.score[i][0] = (i <= MAX_PHRED) ? prm->s_match[i] : 0.0;		// NO_QUAL: nucleotide_scoring_scheme<> default 0 / -1
@@ -470,7 +468,7 @@ __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_pa
 	// A wave takes trace space for several tasks at a time (one atomic per chunk), but never much more than its own tasks can
 	// use: with few runs every wave has one or two tasks, and 8192 waves x 64 KB would be half a gigabyte of reservations.
 	uint32_t const my_tasks = (blockIdx.x < n_tasks) ? ((n_tasks - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
-	uint32_t const trace_chunk = (my_tasks * (DP_MAX_STEPS / 8) * 64 < TRACE_CHUNK) ? (my_tasks * (DP_MAX_STEPS / 8) * 64) : TRACE_CHUNK;
+	uint32_t const trace_chunk = (my_tasks * TASK_WORDS < TRACE_CHUNK) ? (my_tasks * TASK_WORDS) : TRACE_CHUNK;
 #ifdef PVC3_DP_STAMPS
 	unsigned long long stamp_acc[4] = {0, 0, 0, 0};		// set-up, alignment, -, tasks
 #define PVC3_STAMP(k) do { unsigned long long const now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - stamp_t; stamp_t = now_; } while (0)
@@ -497,138 +495,134 @@ __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_pa
 			text = it->text; seq4 = it->seq4; qual = it->qual;
 		}
 		uint32_t const n_short = t_ref_lanes ? it_m : it_n, n_long = t_ref_lanes ? it_n : it_m;
-
-		// The lane's own item (shorter side) and the run's stream (longer side): rank | phred << 8.  All loads are issued before
-		// any of them is used (one round trip instead of one per item).
-		uint32_t raw_a[FILL + 1], raw_b[FILL + 1];		// text byte, or SEQ byte and QUAL byte, of the items l, l + t_width, ... (last: the own item)
-#pragma unroll
-		for (uint32_t k = 0; k <= FILL; ++k)
-		{
-			bool const own = (FILL == k);
-			uint32_t const x = own ? l : (l + k * t_width);
-			bool const query_side = own ? !t_ref_lanes : t_ref_lanes;
-			bool const ok = x < (own ? n_short : n_long);
-			raw_a[k] = 0; raw_b[k] = 0x100;		// 0x100: no base quality
-			if (ok)
-			{
-				if (query_side)
-				{
-					raw_a[k] = seq4[(it_q0 + x) >> 1];
-					if (qual) raw_b[k] = qual[it_q0 + x];
-				}
-				else raw_a[k] = text[x];
-			}
-		}
-		auto item_of = [&](uint32_t k, bool query_side, uint32_t x) -> uint32_t {
-			if (!query_side) return dna5_rank_of_char(raw_a[k]) | (NO_QUAL << 8);
-			uint32_t const code = ((it_q0 + x) & 1) ? (raw_a[k] & 0xf) : (raw_a[k] >> 4);
-			uint32_t const ph = (0x100 == raw_b[k]) ? NO_QUAL : ((raw_b[k] > MAX_PHRED) ? MAX_PHRED : raw_b[k]);		// phred42 saturates
-			return dna5_rank_of_seq4(code) | (ph << 8);
-		};
-#pragma unroll
-		for (uint32_t k = 0; k < FILL; ++k)
-		{
-			uint32_t const x = l + k * t_width;
-			if (x < n_long) S.stream[g][64 + x] = (uint16_t) item_of(k, t_ref_lanes, x);
-		}
-		uint32_t own = 3 | (NO_QUAL << 8);
-		if (l < n_short) own = item_of(FILL, !t_ref_lanes, l);
-		uint32_t const own_rank = own & 7, own_q = own >> 8;
-
-		uint32_t steps = have ? (n_long + n_short - 1) : 0;
+		// the last lane of the run with a line is lane (n_short - 1) / 4: it reaches the last position in step n_long - 1 + that
+		uint32_t steps = (have && n_short) ? (n_long + (n_short - 1) / DP_LINES) : 0, longest = have ? n_long : 0;
 #pragma unroll
 		for (int off = 32; off; off >>= 1)
 		{
-			uint32_t const o = (uint32_t) __shfl_xor((int) steps, off);
+			uint32_t const o = (uint32_t) __shfl_xor((int) steps, off), o2 = (uint32_t) __shfl_xor((int) longest, off);
 			steps = (o > steps) ? o : steps;
+			longest = (o2 > longest) ? o2 : longest;
 		}
-		steps = rfl(steps);
-		// Trace words of this task: one row of 64 per 8 steps, in the context's trace buffer.
+		steps = rfl(steps); longest = rfl(longest);
+
+		// The run's stream (longer side) and the lane's own items (its four lines of the shorter side): rank | phred << 8.  The
+		// loads of eight items are issued before any of them is used.
+		auto load_raw = [&](bool query_side, uint32_t x, uint32_t &a, uint32_t &b) {
+			a = 0; b = 0x100;		// 0x100: no base quality
+			if (query_side) { a = seq4[(it_q0 + x) >> 1]; if (qual) b = qual[it_q0 + x]; }
+			else a = text[x];
+		};
+		auto item_of = [&](bool query_side, uint32_t x, uint32_t a, uint32_t b) -> uint32_t {
+			if (!query_side) return dna5_rank_of_char(a) | (NO_QUAL << 8);
+			uint32_t const code = ((it_q0 + x) & 1) ? (a & 0xf) : (a >> 4);
+			uint32_t const ph = (0x100 == b) ? NO_QUAL : ((b > MAX_PHRED) ? MAX_PHRED : b);		// phred42 saturates
+			return dna5_rank_of_seq4(code) | (ph << 8);
+		};
+		for (uint32_t x0 = 0; x0 < longest; x0 += 8 * t_lanes)
+		{
+			uint32_t ra[8], rb[8];
+#pragma unroll
+			for (uint32_t u = 0; u < 8; ++u)
+			{
+				uint32_t const x = x0 + l + u * t_lanes;
+				ra[u] = 0; rb[u] = 0x100;
+				if (x < n_long) load_raw(t_ref_lanes, x, ra[u], rb[u]);
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < 8; ++u)
+			{
+				uint32_t const x = x0 + l + u * t_lanes;
+				if (x < n_long) S.stream[g][64 + x] = (uint16_t) item_of(t_ref_lanes, x, ra[u], rb[u]);
+			}
+		}
+		uint32_t own[DP_LINES];
+		{
+			uint32_t ra[DP_LINES], rb[DP_LINES];
+#pragma unroll
+			for (uint32_t k = 0; k < DP_LINES; ++k)
+			{
+				ra[k] = 0; rb[k] = 0x100;
+				if (DP_LINES * l + k < n_short) load_raw(!t_ref_lanes, DP_LINES * l + k, ra[k], rb[k]);
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < DP_LINES; ++k)
+				own[k] = (DP_LINES * l + k < n_short) ? item_of(!t_ref_lanes, DP_LINES * l + k, ra[k], rb[k]) : (3u | (NO_QUAL << 8));
+		}
+
+		// Trace of this task: a 64-bit word per lane and four steps (a nibble per cell, 16 bits per step), 64 of them a row.
 		uint64_t trace_loc = 0;
-		bool const traced = arena_take_from(trace_alloc, ((steps + 7) / 8) * 64, trace_chunk, &W.counters->trace_head, W.trace_cap, &W.counters->trace_overflow, lane, trace_loc);
+		bool const traced = arena_take_from(trace_alloc, ((steps + 3) / 4) * 128, trace_chunk, &W.counters->trace_head, W.trace_cap, &W.counters->trace_overflow, lane, trace_loc);
 		if (have && 0 == l) W.run_items[item_idx].trace_loc = traced ? trace_loc : TRACE_NONE;
 		if (!traced)
 			continue;		// the host grows the trace buffer and repeats the batch
-		uint32_t *trace = W.trace + trace_loc + lane;
+		uint64_t *trace = reinterpret_cast <uint64_t *>(W.trace + trace_loc) + lane;
 		wave_lds_fence();
 		PVC3_STAMP(0);
 
 		// Line 0 of the matrix (the first row, or the first column) feeds lane 0 of the run: M = the boundary gap, gap score -inf.
 		// gap(k) = k * (open + ext) when the opening score is positive, open + k * ext otherwise (small integers: exact).
 		auto gap = [&](uint32_t k) -> double { return (0 == k) ? 0.0 : ((open > 0.0) ? (double) k * go : open + (double) k * ge); };
-		bool const line_ok = l < n_short;
-		double own_m = gap(l + 1), own_b = neg_inf;		// M and the along-the-line gap score of the cell before the first one
-		double diag = gap(l);
-		double cur_m = 0.0, cur_a = neg_inf;			// what the next lane receives: this line's M and its across-the-lines gap score
-		// Lane 0 of a run receives the boundary from "above": M = gap(t + 1), gap score -inf.  Both arrive as ADDENDS that are
-		// 0.0 in every other lane (what a lane receives from its neighbour plus 0.0 is the same number, up to the sign of a
-		// zero, which no comparison and no later sum can tell): two adds per step instead of four selects.
-		double const bnd_step_l = (0 == l) ? bnd_step : 0.0, ninf_l = (0 == l) ? neg_inf : 0.0;
-		double bnd = go - bnd_step;						// (width 16: the value DPP feeds lane 0 of each row with) gap(t + 1) = go + t * bnd_step, small integers: exact
-		double bnd_l = (0 == l) ? (go - bnd_step) : 0.0;
-		// Lanes along the query compare every item with the same base at the same quality: their two scores stay in registers.
-		double const own_s_match = S.score[own_q][0], own_s_mismatch = S.score[own_q][1];
-		uint32_t acc = 0;
-		// Lane l uses item t - l in step t; the 64 entries in front of the stream make the index non-negative (whatever they
-		// hold is read by lanes that are not active yet).
+		double own_m[DP_LINES], own_b[DP_LINES];		// per line: M and the along-the-line gap score of the cell before the next one
+#pragma unroll
+		for (uint32_t k = 0; k < DP_LINES; ++k) { own_m[k] = gap(DP_LINES * l + k + 1); own_b[k] = neg_inf; }
+		double diag0 = gap(DP_LINES * l);				// M of the line before the lane's first, one position back
+		double out_m = 0.0, out_a = neg_inf;			// what the next lane receives: the fourth line's M and its across-the-lines gap score
+		double bnd = go - bnd_step;						// the boundary line's M at the position of the step: gap(t + 1) = go + t * bnd_step (small integers: exact)
+		uint64_t acc = 0;
+		// Lane l is at position t - l + 1 in step t; the 64 entries in front of the stream make the index non-negative (whatever
+		// they hold is read by lanes that are not active yet).
 		uint16_t const *my_stream = &S.stream[g][64 - l];
 		uint32_t item_next = my_stream[0];
 		for (uint32_t t = 0; t < steps; ++t)
 		{
-			double nb_m, nb_a;
-			if constexpr (16 == t_width)
-			{
-				bnd += bnd_step;
-				nb_m = row_shr1_f64(cur_m, bnd);
-				nb_a = row_shr1_f64(cur_a, neg_inf);
-			}
-			else if constexpr (64 == t_width)
-			{
-				bnd_l += bnd_step_l;
-				nb_m = shfl_up_f64_zero(cur_m) + bnd_l;		// (lane 0 of the wave receives 0.0 from the shift)
-				nb_a = shfl_up_f64_zero(cur_a) + ninf_l;
-			}
-			else
-			{
-				// (two runs per wave: lane 32 receives lane 31's values from the shift and has to replace them)
-				bnd += bnd_step;
-				nb_m = shfl_up_f64_zero(cur_m);
-				nb_a = shfl_up_f64_zero(cur_a);
-				if (0 == l) { nb_m = bnd; nb_a = neg_inf; }
-			}
+			bnd += bnd_step;
+			double nb_m = row_shr1_f64(out_m, bnd), nb_a = row_shr1_f64(out_a, neg_inf);
+			if constexpr (t_lanes < 16)
+				if (0 == l) { nb_m = bnd; nb_a = neg_inf; }		// (the first lane of a run that is not the first of its row of 16)
 			uint32_t const pos = t - l + 1;				// 1-based position along the longer side handled in this step
-			bool const active = line_ok && (t >= l) && (pos <= n_long);
+			bool const stepping = (t >= l) && (pos <= n_long);
 			uint32_t const item = item_next;
-			item_next = my_stream[t + 1];				// t + 1 <= DP_MAX_STEPS: inside the array for every lane
-			uint32_t nib = 0;
-			if (active)
+			item_next = my_stream[t + 1];				// t + 1 <= steps <= DP_MAX_STEPS: inside the array for every lane
+			uint32_t nibs = 0;
+			if (stepping)
 			{
-				bool const is_match = (item & 7) == own_rank;
-				double s;
-				if constexpr (t_ref_lanes) s = S.score[item >> 8][is_match ? 0 : 1];
-				else s = is_match ? own_s_match : own_s_mismatch;
-				// The larger value wins and ties keep the extension: max() gives the value (equal operands are the same number, no
-				// NaN can arise from finite scores and -inf), the comparison only feeds the trace bit.
-				double const a_open = nb_m + go, a_ext = nb_a + ge;
-				double const a = __builtin_fmax(a_ext, a_open); bool const a_opened = a_ext < a_open;
-				double const b_open = own_m + go, b_ext = own_b + ge;
-				double const b = __builtin_fmax(b_ext, b_open); bool const b_opened = b_ext < b_open;
-				// lanes along the query: a = V (from the row above), b = H; lanes along the reference: a = H (from the column to the left), b = V
-				double const v = t_ref_lanes ? b : a, h = t_ref_lanes ? a : b;
-				bool const v_opened = t_ref_lanes ? b_opened : a_opened, h_opened = t_ref_lanes ? a_opened : b_opened;
-				double const d = diag + s;
-				uint32_t state = is_match ? 0u : 1u;		// 0 diagonal match, 1 diagonal mismatch, 2 up, 3 left
-				double const dv = __builtin_fmax(d, v);
-				if (d < v) state = 2;
-				double const best = __builtin_fmax(dv, h);
-				if (dv < h) state = 3;
-				nib = state | (v_opened ? 4u : 0u) | (h_opened ? 8u : 0u);
-				own_m = best; own_b = b; cur_m = best; cur_a = a; diag = nb_m;
+				double in_m = nb_m, in_a = nb_a, dg = diag0;
+#pragma unroll
+				for (uint32_t k = 0; k < DP_LINES; ++k)
+				{
+					if (DP_LINES * l + k < n_short)
+					{
+						bool const is_match = (item & 7) == (own[k] & 7);
+						double const s = S.score[t_ref_lanes ? (item >> 8) : (own[k] >> 8)][is_match ? 0 : 1];
+						// The larger value wins and ties keep the extension: max() gives the value (equal operands are the same number,
+						// no NaN can arise from finite scores and -inf), the comparison only feeds the trace bit.
+						double const a_open = in_m + go, a_ext = in_a + ge;
+						double const a = __builtin_fmax(a_ext, a_open); bool const a_opened = a_ext < a_open;
+						double const b_open = own_m[k] + go, b_ext = own_b[k] + ge;
+						double const b = __builtin_fmax(b_ext, b_open); bool const b_opened = b_ext < b_open;
+						// lanes along the query: a = V (from the row above), b = H; lanes along the reference: a = H (from the column to the left), b = V
+						double const v = t_ref_lanes ? b : a, h = t_ref_lanes ? a : b;
+						bool const v_opened = t_ref_lanes ? b_opened : a_opened, h_opened = t_ref_lanes ? a_opened : b_opened;
+						double const d = dg + s;
+						uint32_t state = is_match ? 0u : 1u;		// 0 diagonal match, 1 diagonal mismatch, 2 up, 3 left
+						double const dv = __builtin_fmax(d, v);
+						if (d < v) state = 2;
+						double const best = __builtin_fmax(dv, h);
+						if (dv < h) state = 3;
+						nibs |= (state | (v_opened ? 4u : 0u) | (h_opened ? 8u : 0u)) << (4 * k);
+						dg = own_m[k];			// this line's M one position back: the next line's diagonal
+						own_m[k] = best; own_b[k] = b;
+						in_m = best; in_a = a;
+					}
+				}
+				diag0 = nb_m;
+				out_m = in_m; out_a = in_a;
 			}
-			acc |= nib << (4 * (t & 7));
-			if (7 == (t & 7) || t + 1 == steps)
+			acc |= (uint64_t) nibs << (16 * (t & 3));
+			if (3 == (t & 3) || t + 1 == steps)
 			{
-				trace[(t >> 3) * 64] = acc;			// 256 contiguous bytes per wave
+				trace[(t >> 2) * 64] = acc;			// 512 contiguous bytes per wave
 				acc = 0;
 			}
 		}
@@ -643,28 +637,30 @@ __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_pa
 }
 
 // One launch for the six classes (blockIdx.y): their grids run side by side instead of one short kernel after the other.
-__global__ __launch_bounds__(64, 8) void k_realign_dp(dev_batch_work const W, dev_params const *__restrict__ prm)
+__global__ __launch_bounds__(64, 4) void k_realign_dp(dev_batch_work const W, dev_params const *__restrict__ prm)
 {
 	__shared__ dp_shared S;
 	switch (blockIdx.y)
 	{
-		case 0: realign_dp_class <16, false>(W, prm, 0, S); break;
-		case 1: realign_dp_class <16, true>(W, prm, 1, S); break;
-		case 2: realign_dp_class <32, false>(W, prm, 2, S); break;
-		case 3: realign_dp_class <32, true>(W, prm, 3, S); break;
-		case 4: realign_dp_class <64, false>(W, prm, 4, S); break;
-		default: realign_dp_class <64, true>(W, prm, 5, S); break;
+		case 0: realign_dp_class <4, false>(W, prm, 0, S); break;		// shorter side <= 16: four lanes a run, sixteen runs a wave
+		case 1: realign_dp_class <4, true>(W, prm, 1, S); break;
+		case 2: realign_dp_class <8, false>(W, prm, 2, S); break;		// <= 32
+		case 3: realign_dp_class <8, true>(W, prm, 3, S); break;
+		case 4: realign_dp_class <16, false>(W, prm, 4, S); break;		// <= 64
+		default: realign_dp_class <16, true>(W, prm, 5, S); break;
 	}
 }
 
 // Traceback (trace_iterator_base) of the packed alignments, lane = run: diagonal > up > left where the direction is decided;
-// a gap continues until the cell whose gap score was formed by opening.  Cell (i, j) was computed in step i + j - 2 by the
-// lane of its line.  The operations come out last to first and are written run-length from the end of the run's slot.
-// One cell per iteration, written as data flow: the nibble of the cell, the direction taken, the operation, the next state.
+// a gap continues until the cell whose gap score was formed by opening.  Cell (i, j) lies on line x (j for lanes along the
+// reference, i otherwise) at position p (the other one): it was computed by lane (x - 1) / 4 of the run in step p - 1 + that
+// lane, as the ((x - 1) mod 4)-th nibble of the step's sixteen bits.  The operations come out last to first and are written
+// run-length from the end of the run's slot.  One cell per iteration, written as data flow: the nibble of the cell, the
+// direction taken, the operation, the next state.
 __global__ __launch_bounds__(256) void k_realign_traceback(dev_batch_work const W)
 {
 	uint32_t const cls = blockIdx.y;
-	uint32_t const width = 16u << (cls >> 1), per_task = 64 / width;
+	uint32_t const lanes = 4u << (cls >> 1), per_task = 64 / lanes;
 	bool const ref_lanes = cls & 1;
 	uint32_t const count = W.counters->dp_count[cls];
 	uint32_t const *list = W.dp_list + (uint64_t) cls * W.runs_cap;
@@ -677,33 +673,32 @@ __global__ __launch_bounds__(256) void k_realign_traceback(dev_batch_work const 
 			continue;		// the trace buffer overflowed: the batch is repeated
 		uint32_t const m = it->m, n = it->n;
 		uint64_t const ops_loc = it->ops_loc;
-		uint32_t const *trace = W.trace + trace_loc + (at % per_task) * width - 1;		// + line (1-based) of the run
+		uint64_t const *trace = reinterpret_cast <uint64_t const *>(W.trace + trace_loc) + (at % per_task) * lanes;		// + lane of the run
 		uint32_t *slot_end = W.arena + ops_loc + (m + n);
 		uint32_t n_out = 0, cur_op = 0xf, cur_cnt = 0;
 		uint32_t i = n, j = m, st = 0;		// st: 0 = M, 1 = V (up), 2 = H (left)
 		// A load per cell would make the walk a chain of some hundred dependent memory round trips.  The path moves to the same
-		// or the previous line and one or two steps back per cell, so a window of 4 lines x 16 steps (two 16-byte loads) serves
-		// the next half dozen cells from registers.
-		typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
-		u32x4 win_a{0, 0, 0, 0}, win_b{0, 0, 0, 0};		// lines win_line - 3 .. win_line of row win_row and of row win_row - 1
-		uint32_t win_row = 0xFFFFFFF0u, win_line = 0;
+		// or the previous line and one or two steps back per cell, so a window of 2 lanes (8 lines) x 8 steps (two 16-byte loads)
+		// serves the next few cells from registers.
+		typedef unsigned long long __attribute__((ext_vector_type(2))) u64x2;
+		u64x2 win_a{0, 0}, win_b{0, 0};		// lanes win_lane - 1, win_lane of row win_row and of row win_row - 1
+		uint32_t win_row = 0xFFFFFFF0u, win_lane = 0;
 		while (i | j)
 		{
-			uint32_t const t = i + j - 2;
 			bool const inner = (0 != i) && (0 != j);
-			uint32_t const line = ref_lanes ? j : i, row = t >> 3;
-			if (inner && !((row == win_row || row + 1 == win_row) && line <= win_line && line + 3 >= win_line))
+			uint32_t const line = (ref_lanes ? j : i) - 1, p = (ref_lanes ? i : j) - 1;		// (meaningless on the matrix' edge, where they are not used)
+			uint32_t const ln = line >> 2, t = p + ln, row = t >> 2;
+			if (inner && !((row == win_row || row + 1 == win_row) && (ln == win_lane || ln + 1 == win_lane)))
 			{
-				win_row = row; win_line = line;
-				uint32_t const *p = trace + (uint64_t) row * 64 + line - 3;		// the trace buffer has room in front of its first word
-				__builtin_memcpy(&win_a, p, 16);
-				if (row) __builtin_memcpy(&win_b, p - 64, 16);
+				win_row = row; win_lane = ln;
+				uint64_t const *q = trace + (uint64_t) row * 64 + ln;		// the trace buffer has room in front of its first word
+				__builtin_memcpy(&win_a, q - 1, 16);
+				if (row) __builtin_memcpy(&win_b, q - 65, 16);
 			}
-			u32x4 const wv = (row == win_row) ? win_a : win_b;
-			uint32_t const k = line + 3 - win_line;		// 0 .. 3 inside the window
-			uint32_t const word = (0 == k) ? wv.x : (1 == k) ? wv.y : (2 == k) ? wv.z : wv.w;
+			u64x2 const wv = (row == win_row) ? win_a : win_b;
+			uint64_t const word = (ln == win_lane) ? wv.y : wv.x;
 			uint32_t const edge = (0 == i) ? (3u | ((1 == j) ? 8u : 0u)) : (2u | ((1 == i) ? 4u : 0u));	// first row: left, opened at column 1; first column: up
-			uint32_t const nibble = inner ? ((word >> (4 * (t & 7))) & 0xfu) : edge;
+			uint32_t const nibble = inner ? ((uint32_t) (word >> (16 * (t & 3) + 4 * (line & 3))) & 0xfu) : edge;
 			uint32_t const state = nibble & 3;
 			uint32_t const dir = (0 == st) ? ((state < 2) ? 0u : (state - 1)) : st;		// 0 diagonal, 1 up, 2 left
 			uint32_t const op = (0 == dir) ? ((state & 1) ? OP_X : OP_EQ) : ((1 == dir) ? OP_I : OP_D);		// align.hh:99-106

@@ -148,11 +148,14 @@ struct run_work
 static_assert(80 == sizeof(run_work), "run_work layout");
 constexpr uint64_t TRACE_NONE = ~UINT64_C(0);
 
-// Alignment classes: shorter side of the run <= 16, 32, 64 (4, 8, 16 lanes per run with four lines of the matrix each) x orientation
-// (0: lines = query rows, 1: lines = reference columns), plus the
-// runs that need the striped one-wave-per-run kernel (short side > 64 or more anti-diagonals than the LDS trace holds).
-constexpr uint32_t DP_CLASSES = 7;
-constexpr uint32_t DP_CLASS_BIG = 6;
+// Alignment classes: the lines of the matrix along the run's shorter side go four to a lane, so a run takes (shorter + 3) / 4 lanes;
+// the classes are lane groups of 3, 4, 6, 8, 12 and 16 lanes (a shorter side of up to 12, 16, 24, 32, 48, 64) x orientation (0:
+// lines = query rows, 1: lines = reference columns), plus the runs that need the striped one-wave-per-run kernel (shorter side >
+// 64 or longer + shorter - 1 > DP_MAX_STEPS).
+constexpr uint32_t DP_WIDTHS = 6;
+constexpr uint32_t DP_CLASSES = 2 * DP_WIDTHS + 1;
+constexpr uint32_t DP_CLASS_BIG = 2 * DP_WIDTHS;
+__host__ __device__ constexpr uint32_t dp_lanes_of_class(uint32_t cls) { uint32_t const w = cls >> 1; return (0 == w) ? 3u : (1 == w) ? 4u : (2 == w) ? 6u : (3 == w) ? 8u : (4 == w) ? 12u : 16u; }
 constexpr uint32_t DP_MAX_STEPS = 128;		// anti-diagonal steps of a packed alignment (long + short - 1)
 
 // Global counters of one projection attempt (zeroed before every launch sequence).

@@ -33,7 +33,7 @@ constexpr uint32_t TR_DIAG = 0, TR_UP = 1, TR_LEFT = 2, TR_DIR_MASK = 3, TR_V_OP
 constexpr uint32_t MAX_PHRED = 41;
 constexpr uint32_t NO_QUAL = MAX_PHRED + 1;			// row of the score table for records without base qualities: 0 / -1
 constexpr uint32_t SCORE_ROWS = NO_QUAL + 1;
-constexpr uint32_t SCAN_STAGE = 256;				// work items per class a wave of k_realign_scan collects before it appends them
+constexpr uint32_t SCAN_STAGE = 128;				// work items per class a wave of k_realign_scan collects before it appends them
 
 // seqan3::dna5 ranks (A C G N T); assign_char is case-insensitive, U -> T, anything else -> N.
 __device__ __forceinline__ uint32_t dna5_rank_of_char(uint32_t c)
@@ -248,8 +248,9 @@ __device__ __forceinline__ uint32_t dp_class_of(uint32_t m, uint32_t n, uint32_t
 	uint32_t const shorter = (m < n) ? m : n, longer = (m < n) ? n : m;
 	if (!packed || shorter > 64 || longer + shorter - 1 > DP_MAX_STEPS)
 		return DP_CLASS_BIG;
-	uint32_t const w = (shorter <= 16) ? 0 : (shorter <= 32) ? 1 : 2;
-	return 2 * w + ((m < n) ? 1 : 0);		// orientation 1: lanes along the reference (the shorter side)
+	uint32_t const lanes = (shorter + 3) / 4;
+	uint32_t const w = (lanes <= 3) ? 0 : (lanes <= 4) ? 1 : (lanes <= 6) ? 2 : (lanes <= 8) ? 3 : (lanes <= 12) ? 4 : 5;
+	return 2 * w + ((m < n) ? 1 : 0);		// orientation 1: lines along the reference (the shorter side)
 }
 
 __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restrict__ entries, dev_batch_in const in, dev_batch_work const W, uint32_t n_regions, uint32_t packed)
@@ -441,50 +442,33 @@ constexpr uint32_t DP_LINES = 4;
 struct dp_shared
 {
 	double score[SCORE_ROWS][2];					// [phred or NO_QUAL][0 match, 1 mismatch]
-	uint16_t stream[16][64 + DP_MAX_STEPS + 8];		// per run: the items along the longer side, dna5 rank | phred << 8, behind 64 unused entries
+	uint16_t stream[21][64 + DP_MAX_STEPS + 8];		// per run: the items along the longer side, dna5 rank | phred << 8, behind 64 unused entries
 };
 constexpr uint32_t TRACE_CHUNK = 16384;				// trace words a wave takes from the trace buffer at a time (4 - 64 tasks)
 
+struct dp_constants { double open, ge, go, bnd_step, neg_inf; };
+
+// One task: 64 / t_lanes runs of class `cls`, from the task-th group of its list.
 template <uint32_t t_lanes, bool t_ref_lanes>
-__device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_params const *__restrict__ prm, uint32_t cls, dp_shared &S)
+__device__ __forceinline__ void realign_dp_task(dev_batch_work const &W, uint32_t cls, uint32_t task, uint32_t count, dp_constants const &K, dp_shared &S, arena_alloc &trace_alloc, uint32_t trace_chunk)
 {
-	constexpr uint32_t G = 64 / t_lanes;
-	constexpr uint32_t TASK_WORDS = ((DP_MAX_STEPS + t_lanes + 3) / 4) * 128;		// trace words of a task at most
+	constexpr uint32_t G = 64 / t_lanes;		// (3, 6, 12 lanes: 63, 60, 60 lanes of the wave at work)
 	uint32_t const lane = lane_id();
-	uint32_t const g = lane / t_lanes, l = lane % t_lanes;
-	for (uint32_t i = lane; i < SCORE_ROWS; i += 64)
-	{
-		S.score[i][0] = (i <= MAX_PHRED) ? prm->s_match[i] : 0.0;		// NO_QUAL: nucleotide_scoring_scheme<> default 0 / -1
-		S.score[i][1] = (i <= MAX_PHRED) ? prm->s_mismatch[i] : -1.0;
-	}
-	double const open = (double) prm->gap_open, ge = (double) prm->gap_ext;
-	double const go = open + ge;						// seqan3's internal gap-open score = open + extension
-	double const bnd_step = (open > 0.0) ? go : ge;		// first row / column: x_1 = go, x_k = x_{k-1} + max(go, ge), ties keep the extension
-	double const neg_inf = -__builtin_inf();
-	uint32_t const count = W.counters->dp_count[cls];
+	bool const idle = lane >= G * t_lanes;
+	uint32_t const g = idle ? 0 : (lane / t_lanes), l = lane % t_lanes;
+	double const open = K.open, ge = K.ge, go = K.go, bnd_step = K.bnd_step, neg_inf = K.neg_inf;
 	uint32_t const *list = W.dp_list + (uint64_t) cls * W.runs_cap;
-	uint32_t const n_tasks = (count + G - 1) / G;
-	arena_alloc trace_alloc{0, 0};
-	// A wave takes trace space for several tasks at a time (one atomic per chunk), but never much more than its own tasks can
-	// use: with few runs every wave has one or two tasks, and 8192 waves x 64 KB would be half a gigabyte of reservations.
-	uint32_t const my_tasks = (blockIdx.x < n_tasks) ? ((n_tasks - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
-	uint32_t const trace_chunk = (my_tasks * TASK_WORDS < TRACE_CHUNK) ? (my_tasks * TASK_WORDS) : TRACE_CHUNK;
 #ifdef PVC3_DP_STAMPS
-	unsigned long long stamp_acc[4] = {0, 0, 0, 0};		// set-up, alignment, -, tasks
+	unsigned long long stamp_acc[4] = {0, 0, 0, 1};		// set-up, alignment, -, tasks
+	unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #define PVC3_STAMP(k) do { unsigned long long const now_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += now_ - stamp_t; stamp_t = now_; } while (0)
 #else
 #define PVC3_STAMP(k) do {} while (0)
 #endif
-
-	for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x)
 	{
-#ifdef PVC3_DP_STAMPS
-		unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
-		stamp_acc[3] += 1;
-#endif
 		wave_lds_fence();		// the previous task's LDS reads are done
 		uint32_t const slot_idx = task * G + g;
-		bool const have = slot_idx < count;
+		bool const have = !idle && slot_idx < count;
 		uint32_t const item_idx = have ? list[slot_idx] : 0;
 		uint32_t it_m = 0, it_n = 0, it_q0 = 0;
 		uint8_t const *text = nullptr, *seq4 = nullptr, *qual = nullptr;
@@ -555,7 +539,7 @@ __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_pa
 		bool const traced = arena_take_from(trace_alloc, ((steps + 3) / 4) * 128, trace_chunk, &W.counters->trace_head, W.trace_cap, &W.counters->trace_overflow, lane, trace_loc);
 		if (have && 0 == l) W.run_items[item_idx].trace_loc = traced ? trace_loc : TRACE_NONE;
 		if (!traced)
-			continue;		// the host grows the trace buffer and repeats the batch
+			return;			// the host grows the trace buffer and repeats the batch
 		uint64_t *trace = reinterpret_cast <uint64_t *>(W.trace + trace_loc) + lane;
 		wave_lds_fence();
 		PVC3_STAMP(0);
@@ -577,9 +561,13 @@ __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_pa
 		for (uint32_t t = 0; t < steps; ++t)
 		{
 			bnd += bnd_step;
-			double nb_m = row_shr1_f64(out_m, bnd), nb_a = row_shr1_f64(out_a, neg_inf);
-			if constexpr (t_lanes < 16)
-				if (0 == l) { nb_m = bnd; nb_a = neg_inf; }		// (the first lane of a run that is not the first of its row of 16)
+			double nb_m, nb_a;
+			if constexpr (16 == t_lanes) { nb_m = row_shr1_f64(out_m, bnd); nb_a = row_shr1_f64(out_a, neg_inf); }		// (a run = a row of the DPP)
+			else
+			{
+				nb_m = shfl_up_f64(out_m); nb_a = shfl_up_f64(out_a);
+				if (0 == l) { nb_m = bnd; nb_a = neg_inf; }
+			}
 			uint32_t const pos = t - l + 1;				// 1-based position along the longer side handled in this step
 			bool const stepping = (t >= l) && (pos <= n_long);
 			uint32_t const item = item_next;
@@ -636,19 +624,65 @@ __device__ __forceinline__ void realign_dp_class(dev_batch_work const &W, dev_pa
 #endif
 }
 
-// One launch for the six classes (blockIdx.y): their grids run side by side instead of one short kernel after the other.
+// One launch for the twelve classes: their tasks one range behind the other, dealt out to the waves round robin, so that a class
+// with many runs gets as many waves as it has work for (a grid per class, as it was, gave every class the same number of waves:
+// the classes with most of the cells were still at it when the others' waves had long gone).
 __global__ __launch_bounds__(64, 4) void k_realign_dp(dev_batch_work const W, dev_params const *__restrict__ prm)
 {
 	__shared__ dp_shared S;
-	switch (blockIdx.y)
+	__shared__ uint32_t first_task[DP_CLASS_BIG + 1], class_count[DP_CLASS_BIG];
+	uint32_t const lane = lane_id();
 	{
-		case 0: realign_dp_class <4, false>(W, prm, 0, S); break;		// shorter side <= 16: four lanes a run, sixteen runs a wave
-		case 1: realign_dp_class <4, true>(W, prm, 1, S); break;
-		case 2: realign_dp_class <8, false>(W, prm, 2, S); break;		// <= 32
-		case 3: realign_dp_class <8, true>(W, prm, 3, S); break;
-		case 4: realign_dp_class <16, false>(W, prm, 4, S); break;		// <= 64
-		default: realign_dp_class <16, true>(W, prm, 5, S); break;
+		uint32_t const c = (lane < DP_CLASS_BIG) ? lane : 0;
+		uint32_t const cnt = W.counters->dp_count[c], per_task = 64 / dp_lanes_of_class(c);
+		uint32_t tasks = (lane < DP_CLASS_BIG) ? ((cnt + per_task - 1) / per_task) : 0, before = tasks;
+		for (uint32_t d = 1; d < 16; d <<= 1)
+		{
+			uint32_t const y = (uint32_t) __shfl_up((int) before, (int) d);
+			if (lane >= d) before += y;
+		}
+		if (lane < DP_CLASS_BIG) { first_task[lane + 1] = before; class_count[lane] = cnt; }
+		if (0 == lane) first_task[0] = 0;
 	}
+	wave_lds_fence();
+	uint32_t const total = first_task[DP_CLASS_BIG];
+	if (blockIdx.x >= total) return;
+	for (uint32_t i = lane; i < SCORE_ROWS; i += 64)
+	{
+		S.score[i][0] = (i <= MAX_PHRED) ? prm->s_match[i] : 0.0;		// NO_QUAL: nucleotide_scoring_scheme<> default 0 / -1
+		S.score[i][1] = (i <= MAX_PHRED) ? prm->s_mismatch[i] : -1.0;
+	}
+	dp_constants K;
+	K.open = (double) prm->gap_open; K.ge = (double) prm->gap_ext;
+	K.go = K.open + K.ge;									// seqan3's internal gap-open score = open + extension
+	K.bnd_step = (K.open > 0.0) ? K.go : K.ge;				// first row / column: x_1 = go, x_k = x_{k-1} + max(go, ge), ties keep the extension
+	K.neg_inf = -__builtin_inf();
+	arena_alloc trace_alloc{0, 0};
+	// A wave takes trace space for several tasks at a time (one atomic per chunk), but never much more than its own tasks can
+	// use: with few runs every wave has one or two tasks, and 8192 waves x 64 KB would be half a gigabyte of reservations.
+	constexpr uint32_t TASK_WORDS = ((DP_MAX_STEPS + 16 + 3) / 4) * 128;		// trace words of a task at most
+	uint32_t const my_tasks = (total - blockIdx.x + gridDim.x - 1) / gridDim.x;
+	uint32_t const trace_chunk = (my_tasks * TASK_WORDS < TRACE_CHUNK) ? (my_tasks * TASK_WORDS) : TRACE_CHUNK;
+	// This wave's tasks are blockIdx.x, blockIdx.x + gridDim.x, ...: class by class, so that each class's code is a loop of its own
+	// (all twelve bodies inside one loop share one register allocation, and spill).
+	auto tasks_of = [&](uint32_t cls, auto &&one_task) {
+		uint32_t const lo = first_task[cls], hi = first_task[cls + 1], n = gridDim.x;
+		uint32_t const behind = (blockIdx.x + n - lo % n) % n;		// the first of this wave's tasks at or behind lo
+		for (uint32_t at = lo + behind; at < hi; at += n)
+			one_task(at - lo, class_count[cls]);
+	};
+	tasks_of(0, [&](uint32_t task, uint32_t count) { realign_dp_task <3, false>(W, 0, task, count, K, S, trace_alloc, trace_chunk); });		// (dp_lanes_of_class)
+	tasks_of(1, [&](uint32_t task, uint32_t count) { realign_dp_task <3, true>(W, 1, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(2, [&](uint32_t task, uint32_t count) { realign_dp_task <4, false>(W, 2, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(3, [&](uint32_t task, uint32_t count) { realign_dp_task <4, true>(W, 3, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(4, [&](uint32_t task, uint32_t count) { realign_dp_task <6, false>(W, 4, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(5, [&](uint32_t task, uint32_t count) { realign_dp_task <6, true>(W, 5, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(6, [&](uint32_t task, uint32_t count) { realign_dp_task <8, false>(W, 6, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(7, [&](uint32_t task, uint32_t count) { realign_dp_task <8, true>(W, 7, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(8, [&](uint32_t task, uint32_t count) { realign_dp_task <12, false>(W, 8, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(9, [&](uint32_t task, uint32_t count) { realign_dp_task <12, true>(W, 9, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(10, [&](uint32_t task, uint32_t count) { realign_dp_task <16, false>(W, 10, task, count, K, S, trace_alloc, trace_chunk); });
+	tasks_of(11, [&](uint32_t task, uint32_t count) { realign_dp_task <16, true>(W, 11, task, count, K, S, trace_alloc, trace_chunk); });
 }
 
 // Traceback (trace_iterator_base) of the packed alignments, lane = run: diagonal > up > left where the direction is decided;
@@ -660,7 +694,7 @@ __global__ __launch_bounds__(64, 4) void k_realign_dp(dev_batch_work const W, de
 __global__ __launch_bounds__(256) void k_realign_traceback(dev_batch_work const W)
 {
 	uint32_t const cls = blockIdx.y;
-	uint32_t const lanes = 4u << (cls >> 1), per_task = 64 / lanes;
+	uint32_t const lanes = dp_lanes_of_class(cls), per_task = 64 / lanes;
 	bool const ref_lanes = cls & 1;
 	uint32_t const count = W.counters->dp_count[cls];
 	uint32_t const *list = W.dp_list + (uint64_t) cls * W.runs_cap;
@@ -1027,7 +1061,7 @@ int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in co
 		hipLaunchKernelGGL(k_gather_qual, dim3(list_blocks), dim3(256), 0, s, in, work, n_regions);
 	hipLaunchKernelGGL(k_realign_scan, dim3(list_blocks), dim3(256), 0, s, entries, in, work, n_regions, packed);
 	if (n_waves < 1) n_waves = 1;
-	hipLaunchKernelGGL(k_realign_dp, dim3(n_waves, DP_CLASS_BIG), dim3(64), 0, s, work, params);
+	hipLaunchKernelGGL(k_realign_dp, dim3(n_waves), dim3(64), 0, s, work, params);
 	hipLaunchKernelGGL(k_realign_traceback, dim3(1024, DP_CLASS_BIG), dim3(256), 0, s, work);
 	if (big_waves < 1) big_waves = 1;
 	hipLaunchKernelGGL(k_realign_big, dim3(big_waves), dim3(64), 0, s, work, params, lds_budget);

@@ -45,16 +45,16 @@ def run(scale):
 		db.project()
 		st = db.finish()
 	L = _lib.lib()
-	out = (C.c_ulonglong * 56)()
+	out = (C.c_ulonglong * 104)()
 	L.pvc3_debug_wave_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
-	assert 0 == L.pvc3_debug_wave_stats(db._h, out, 56)
-	v = np.array(out[:]).reshape(7, 8)
-	names = ["16 query", "16 ref", "32 query", "32 ref", "64 query", "64 ref"]
+	assert 0 == L.pvc3_debug_wave_stats(db._h, out, 104)
+	v = np.array(out[:]).reshape(13, 8)
+	names = ["%d lanes, %s" % (w, o) for w in (3, 4, 6, 8, 12, 16) for o in ("query", "ref")]
 	print("%s, scale %g: %d runs" % (desc, scale, st["n_runs"]))
-	print("%-10s %10s %12s %12s %12s   cycles per task" % ("class", "tasks", "set-up", "alignment", "traceback"))
+	print("%-16s %10s %12s %12s %12s   cycles per task" % ("class", "tasks", "set-up", "alignment", "traceback"))
 	for c, name in enumerate(names):
 		t = max(1, int(v[c][3]))
-		print("%-10s %10d %12.0f %12.0f %12.0f" % (name, v[c][3], v[c][0] / t, v[c][1] / t, v[c][2] / t))
+		print("%-16s %10d %12.0f %12.0f %12.0f" % (name, v[c][3], v[c][0] / t, v[c][1] / t, v[c][2] / t))
 
 
 if __name__ == "__main__":

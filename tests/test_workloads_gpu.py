@@ -685,15 +685,19 @@ def test_full_size_properties(pvc3, oracle_mod, synth, name):
 
 
 def test_indel_run_shapes_and_gap_scores(pvc3, oracle_mod):
-	"""One indel run of m reference bases against n query bases for every packing shape of the alignment kernels (16 / 32 / 64
-	lanes per run, lanes along the query or along the reference, the striped kernel beyond 64 x ... or 128 anti-diagonals),
+	"""One indel run of m reference bases against n query bases for every packing shape of the alignment kernels (four lines of
+	the matrix per lane, lane groups of 3 / 4 / 6 / 8 / 12 / 16 lanes — a shorter side of up to 12 / 16 / 24 / 32 / 48 / 64, on
+	either side of every limit, with and without a partly used last lane — lines along the query or along the reference, runs of
+	different lengths side by side in a wavefront, the striped kernel beyond 64 x ... or 128 steps),
 	with related and unrelated slices (co-optimal paths), mixed base qualities, N bases, lower-case reference text, records
 	without qualities, and gap scores with a positive, zero and negative opening score (open + extension > 0, == 0, < 0)."""
 	rng = np.random.default_rng(77)
 	seg = lambda k: "".join("ACGT"[x] for x in rng.integers(0, 4, size=k))
 	shapes = [(1, 1), (1, 16), (16, 1), (16, 16), (17, 5), (5, 17), (15, 40), (40, 15), (16, 113), (113, 16), (17, 17), (32, 32), (32, 60),
 			  (60, 32), (33, 32), (32, 33), (33, 33), (64, 64), (64, 65), (65, 64), (40, 64), (64, 40), (65, 10), (10, 65), (100, 20), (20, 100),
-			  (100, 29), (100, 30), (30, 100), (120, 9), (9, 120), (3, 126), (126, 3), (127, 2), (2, 128), (70, 70), (150, 7), (1, 200)]
+			  (100, 29), (100, 30), (30, 100), (120, 9), (9, 120), (3, 126), (126, 3), (127, 2), (2, 128), (70, 70), (150, 7), (1, 200),
+			  (2, 7), (3, 3), (5, 5), (6, 9), (7, 7), (9, 9), (11, 40), (12, 30), (30, 12), (13, 30), (30, 13), (23, 23), (24, 50), (50, 24), (25, 50),
+			  (50, 25), (47, 47), (48, 60), (60, 48), (49, 60), (60, 49), (63, 63), (64, 61), (61, 64), (12, 12), (13, 13), (24, 24), (25, 25), (48, 48), (49, 49)]
 	pairs, recs = [], []
 	for m, n in shapes:
 		for variant in range(3):

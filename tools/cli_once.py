@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One run of the command line (record path on the GPU) on the 16 M-record file with everything it reports, and the wall clock around it.
+"""One run of the command line (record path on the GPU unless --arg says otherwise) on the 16 M-record file with everything it reports, and the wall clock around it.
 usage: tools/cli_once.py [--workdir DIR] [--repeat N] [KEY=VALUE ...]"""
 import argparse, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,12 +12,13 @@ def main():
 	ap.add_argument("--repeat", type=int, default=3)
 	ap.add_argument("--copies", type=int, default=64)
 	ap.add_argument("--keep-output", action="store_true", help="overwrite the previous run's output instead of writing a new file")
+	ap.add_argument("--arg", action="append", default=[], help="an argument more for the command line, e.g. --arg=--record-path=host")
 	ap.add_argument("env", nargs="*")
 	args = ap.parse_args()
 	import cli_e2e
 	P = cli_e2e.prepare(args.workdir, scale=0.25, repeat=1)
 	n = cli_e2e.write_repeated(P, os.path.join(args.workdir, "in_large.bam"), args.copies)
-	cmd = cli_e2e.project_command(P, alignments="in_large.bam", output="out_large.bam")
+	cmd = cli_e2e.project_command(P, alignments="in_large.bam", output="out_large.bam") + args.arg
 	env = dict(os.environ, **dict(kv.split("=", 1) for kv in args.env))
 	subprocess.run(cmd, cwd=args.workdir, capture_output=True, env=env)
 	for _ in range(args.repeat):

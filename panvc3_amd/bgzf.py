@@ -171,6 +171,34 @@ class BlockInflater:
 			o += n
 		return got, status, best
 
+	def inflate_slots(self, groups):
+		"""groups[k] = (streams, sizes) for slot k: every slot is submitted before any is waited for (each has a stream of its own, so
+		their kernels are on the GPU together).  Returns a list of (list of bytes or None, statuses) per slot."""
+		laid = []
+		for slot, (streams, sizes) in enumerate(groups):
+			inp, out, blocks = self._views(slot)
+			pos, opos = 2, 0
+			for i, (s, n) in enumerate(zip(streams, sizes)):
+				inp[pos:pos + len(s)] = np.frombuffer(s, dtype=np.uint8)
+				blocks[i] = (pos, len(s), n, opos)
+				pos += len(s) + 1
+				opos += n
+			out[:opos] = 0xCD
+			laid.append((out, pos, opos))
+		for slot, (streams, _) in enumerate(groups):
+			_check(self._L.pvc3_bgzf_inflater_submit(self._h, slot, len(streams), laid[slot][1], laid[slot][2]))
+		results = []
+		for slot, (streams, sizes) in enumerate(groups):
+			st, ms = C.c_void_p(), C.c_float()
+			_check(self._L.pvc3_bgzf_inflater_wait(self._h, slot, C.byref(st), C.byref(ms)))
+			status = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint32)), shape=(len(streams),)).copy()
+			got, o = [], 0
+			for i, n in enumerate(sizes):
+				got.append(laid[slot][0][o:o + n].tobytes() if 0 == status[i] else None)
+				o += n
+			results.append((got, status))
+		return results
+
 	def inflate_to_device(self, streams, sizes, slot=0):
 		"""pvc3_bgzf_inflater_submit_device: the streams inflated into device memory (allocated here), one behind the other; returns
 		(the bytes copied back, statuses, the CRC-32 of every block as the device computed them)."""

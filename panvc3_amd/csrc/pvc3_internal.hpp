@@ -152,6 +152,7 @@ constexpr uint64_t TRACE_NONE = ~UINT64_C(0);
 // the classes are lane groups of 3, 4, 6, 8, 12 and 16 lanes (a shorter side of up to 12, 16, 24, 32, 48, 64) x orientation (0:
 // lines = query rows, 1: lines = reference columns), plus the runs that need the striped one-wave-per-run kernel (shorter side >
 // 64 or longer + shorter - 1 > DP_MAX_STEPS).
+constexpr uint32_t DP_LINES_PER_LANE = 4;
 constexpr uint32_t DP_WIDTHS = 6;
 constexpr uint32_t DP_CLASSES = 2 * DP_WIDTHS + 1;
 constexpr uint32_t DP_CLASS_BIG = 2 * DP_WIDTHS;

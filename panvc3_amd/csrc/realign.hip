@@ -425,6 +425,52 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 }
 
 
+// ---- the class lists in pieces of equal length --------------------------------------------------------------------------------------
+// A task of k_realign_dp takes as long as the longest of its 4 - 21 runs, and the runs come in the order of the records: on C5, where the
+// longer side is anything from 13 to 60, 54 % of the lane-steps of a task were cells as the lists stood and 67 % are with every 1 024
+// consecutive entries of a list sorted by the steps their runs take (a sort of the whole list would give 68 %).  One block per piece:
+// key | index as one 64-bit word, a bitonic network in LDS.
+constexpr uint32_t SORT_PIECE = 1024, SORT_THREADS = 256;
+__global__ __launch_bounds__(SORT_THREADS) void k_realign_sort(dev_batch_work const W)
+{
+	__shared__ unsigned long long keyed[SORT_PIECE];
+	uint32_t const cls = blockIdx.y;
+	uint32_t const count = W.counters->dp_count[cls];
+	uint32_t *list = W.dp_list + (uint64_t) cls * W.runs_cap;
+	bool const ref_lanes = cls & 1;
+	for (uint32_t base = blockIdx.x * SORT_PIECE; base < count; base += gridDim.x * SORT_PIECE)
+	{
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < SORT_PIECE; i += SORT_THREADS)
+		{
+			unsigned long long v = ~0ull;		// (behind the list's end: sorts last, is not written back)
+			if (base + i < count)
+			{
+				uint32_t const idx = list[base + i];
+				uint32_t const m = W.run_items[idx].m, n = W.run_items[idx].n;
+				uint32_t const n_short = ref_lanes ? m : n, n_long = ref_lanes ? n : m;
+				v = ((unsigned long long) (n_long + (n_short + DP_LINES_PER_LANE - 1) / DP_LINES_PER_LANE) << 32) | idx;
+			}
+			keyed[i] = v;
+		}
+		__syncthreads();
+		for (uint32_t k = 2; k <= SORT_PIECE; k <<= 1)
+			for (uint32_t j = k >> 1; j; j >>= 1)
+			{
+				for (uint32_t t = threadIdx.x; t < SORT_PIECE / 2; t += SORT_THREADS)
+				{
+					uint32_t const lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;		// the t-th pair j apart
+					unsigned long long const a = keyed[lo], b = keyed[hi];
+					bool const up = 0 == (lo & k);
+					if ((a > b) == up) { keyed[lo] = b; keyed[hi] = a; }
+				}
+				__syncthreads();
+			}
+		for (uint32_t i = threadIdx.x; i < SORT_PIECE; i += SORT_THREADS)
+			if (base + i < count) list[base + i] = (uint32_t) keyed[i];
+	}
+}
+
 // ---- packed alignment: t_lanes lanes per run with four lines of the matrix each, 64 / t_lanes runs per wavefront ---------------
 // Matrix M(i, j), i = 0..n over the query (vertical), j = 0..m over the reference (horizontal); V = best score ending in a
 // vertical gap (query base against nothing: 'I'), H = horizontal gap ('D').  The lines of the matrix along the shorter side of
@@ -438,7 +484,7 @@ __global__ __launch_bounds__(256) void k_realign_scan(dev_entry const *__restric
 // max(16, 32, 64) lanes, of which 35 - 50 % were cells (C5: s up to 58, L around 45) at 36 vector instructions a step.  With
 // four lines per lane the fill and drain of the wavefront is a quarter as long (L + s / 4 - 1 steps) and what a step costs
 // beside its cells (the exchange, the stream, the trace) is paid once for four of them.
-constexpr uint32_t DP_LINES = 4;
+constexpr uint32_t DP_LINES = DP_LINES_PER_LANE;
 struct dp_shared
 {
 	double score[SCORE_ROWS][2];					// [phred or NO_QUAL][0 match, 1 mismatch]
@@ -1061,6 +1107,7 @@ int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in co
 		hipLaunchKernelGGL(k_gather_qual, dim3(list_blocks), dim3(256), 0, s, in, work, n_regions);
 	hipLaunchKernelGGL(k_realign_scan, dim3(list_blocks), dim3(256), 0, s, entries, in, work, n_regions, packed);
 	if (n_waves < 1) n_waves = 1;
+	hipLaunchKernelGGL(k_realign_sort, dim3(512, DP_CLASS_BIG), dim3(SORT_THREADS), 0, s, work);
 	hipLaunchKernelGGL(k_realign_dp, dim3(n_waves), dim3(64), 0, s, work, params);
 	hipLaunchKernelGGL(k_realign_traceback, dim3(1024, DP_CLASS_BIG), dim3(256), 0, s, work);
 	if (big_waves < 1) big_waves = 1;

@@ -307,6 +307,26 @@ def test_inflate_matches_that_copy_matches(gpu_inflater):
 
 
 @pytest.mark.gpu
+def test_inflater_slots_at_once(gpu_inflater):
+	"""Both slots submitted before either is waited for: each slot has a stream, device input, token space and status of its own, so
+	two groups of blocks are decoded at the same time — different data, different numbers of blocks, several rounds."""
+	rng = np.random.default_rng(47)
+	for round_ in range(3):
+		groups, want = [], []
+		for slot in range(2):
+			pieces = []
+			for _ in range(int(rng.integers(40, 300))):
+				kind = int(rng.integers(0, 3))
+				size = int(rng.integers(1, 65281))
+				pieces.append(_bam_like(rng, 260)[:size] if 0 == kind else bytes(rng.integers(0, 4 if 1 == kind else 256, size=size, dtype=np.uint8)))
+			groups.append(([_raw_deflate(p, int(rng.choice([1, 6, 9]))) for p in pieces], [len(p) for p in pieces]))
+			want.append(pieces)
+		for slot, (got, status) in enumerate(gpu_inflater.inflate_slots(groups)):
+			bad = [i for i in range(len(want[slot])) if status[i] != 0 or got[i] != want[slot][i]]
+			assert not bad, (round_, slot, bad[:5], [int(status[i]) for i in bad[:5]])
+
+
+@pytest.mark.gpu
 def test_inflate_what_the_gpu_deflated(gpu, gpu_inflater):
 	rng = np.random.default_rng(31)
 	data = _bam_like(rng, 6000)

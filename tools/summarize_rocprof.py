@@ -33,7 +33,7 @@ def main():
 			fetch_factor = float(a.split("=", 1)[1])
 	out_dir, trace_dir = args[0], args[1]
 	os.makedirs(out_dir, exist_ok=True)
-	stats = glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True)
+	stats = sorted(glob.glob(os.path.join(trace_dir, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)		# the newest run of a directory that has seen several
 	if stats:
 		shutil.copy(stats[0], os.path.join(out_dir, "kernel_stats.csv"))
 	summary = {}
@@ -42,7 +42,7 @@ def main():
 			summary.setdefault(short(r["Name"]), {}).update(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), pct=float(r["Percentage"]))
 	if len(args) >= 4:
 		for d, ctr in ((args[2], "FETCH_SIZE"), (args[3], "WRITE_SIZE")):
-			f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+			f = max(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
 			acc = collections.defaultdict(list)
 			meta = {}
 			for r in csv.DictReader(open(f)):

@@ -14,6 +14,7 @@
  *                                        project_alignments.cc:575-594, :726
  *   pvc3_project_positions               msa_index::sequence_entry::project_position include/panvc3/msa_index.hh:253-258
  *                                        (call sites project_alignments.cc:900, convert-bed-positions/main.cc:60-73)
+ *   pvc3_split_match_ops                 rewrite_cigar_sequence_match + fill_ref_n_positions rewrite-cigar/main.cc:191-284, :126-148
  *   pvc3_rescore_alignments              cigar_alignment_scorer::calculate_score recalculate-mapq/main.cc:189-289
  *   pvc3_recalculate_mapq                mapq_scorer::process_alignment_group recalculate-mapq/main.cc:962-1180 and
  *                                        bowtie2_v2_score_calculator::calculate_mapq :441-566
@@ -322,6 +323,45 @@ PVC3_API int pvc3_recalculate_mapq(pvc3_context *ctx, pvc3_mapq_batch const *in,
 
 /* project_position for n independent positions: out[i] = rank0_dst(select0_src(1 + pos[i])); PVC3_NO_MATE if out of range. */
 PVC3_API int pvc3_project_positions(pvc3_context *ctx, uint64_t n, uint32_t const *src_entry, uint32_t const *dst_entry, uint32_t const *pos, uint32_t *out);
+
+/* ---- the rewrite_cigar tool's sequence-match mode (rewrite-cigar/main.cc:191-284): every M of a record's CIGAR is split into = / X
+ * by comparing seqan3::dna5::to_char of the read's bases with the raw bytes of the record's reference sequence (runs inside one M
+ * are not merged with the operations around it), every other operation is kept; and the positions of 'N' in the reference from the
+ * alignment's start on, over the bases the CIGAR consumes, as a bit map (:126-148: bit p % 8 of byte p / 8; (consumed + 7) / 8
+ * bytes, none if the CIGAR consumes no reference base).  The reference sequences live in HBM (pvc3_reference). ---- */
+typedef struct pvc3_reference pvc3_reference;
+PVC3_API int pvc3_reference_create(pvc3_context *ctx, uint32_t n_sequences, uint8_t const *const *bytes, uint64_t const *lengths, pvc3_reference **out);
+PVC3_API void pvc3_reference_destroy(pvc3_reference *ref);
+enum
+{
+	PVC3_SPLIT_OK = 0,
+	PVC3_SPLIT_BAD_OP = 1,			/* operation code > 8 (main.cc:279-281 libbio_fail) */
+	PVC3_SPLIT_QUERY_RANGE = 2,		/* an M reaches past the end of SEQ (main.cc:249 libbio_assert_lte) */
+	PVC3_SPLIT_EMPTY_M = 3,			/* an M of no bases (the reference reads query_seq[query_pos] regardless: undefined there, refused here) */
+	PVC3_SPLIT_REF_RANGE = 4		/* the alignment reaches past the end of its reference sequence, or the sequence does not exist */
+};
+typedef struct pvc3_split_in
+{
+	uint64_t n;
+	uint32_t const *sequence;		/* [n] which of the reference's sequences */
+	uint32_t const *pos;			/* [n] 0-based start of the alignment in it */
+	uint64_t const *cigar_off;		/* [n + 1] */
+	uint32_t const *cigar;			/* BAM encoding: count << 4 | op */
+	uint64_t const *seq_off;		/* [n] BYTE offset of the record's packed bases in seq4 (a record's bases begin a byte, as in BAM) */
+	uint8_t const *seq4;			/* 4-bit codes, high nibble first; seq4_bytes bytes */
+	uint64_t seq4_bytes;
+	uint32_t const *l_seq;			/* [n] */
+} pvc3_split_in;
+typedef struct pvc3_split_out
+{
+	uint64_t *cigar_off;			/* [n + 1] */
+	uint32_t *cigar; uint64_t cigar_cap;
+	uint64_t *n_map_off;			/* [n + 1] */
+	uint8_t *n_map; uint64_t n_map_cap;
+	int32_t *status;				/* [n] PVC3_SPLIT_*; a record with a status has no operations and no map */
+} pvc3_split_out;
+/* PVC3_E_CAPACITY: *n_cigar operations / *n_map_bytes bytes are needed (both are always set); nothing else was written. */
+PVC3_API int pvc3_split_match_ops(pvc3_context *ctx, pvc3_reference const *ref, pvc3_split_in const *in, pvc3_split_out *out, uint64_t *n_cigar, uint64_t *n_map_bytes);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,16 @@ class Params(C.Structure):
 	_fields_ = [("gap_open", C.c_int32), ("gap_ext", C.c_int32), ("score_mode", C.c_int32), ("tiebreak_mode", C.c_int32)]
 
 
+class SplitIn(C.Structure):
+	_fields_ = [("n", C.c_uint64), ("sequence", C.c_void_p), ("pos", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("seq_off", C.c_void_p),
+				("seq4", C.c_void_p), ("seq4_bytes", C.c_uint64), ("l_seq", C.c_void_p)]
+
+
+class SplitOut(C.Structure):
+	_fields_ = [("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("cigar_cap", C.c_uint64), ("n_map_off", C.c_void_p), ("n_map", C.c_void_p), ("n_map_cap", C.c_uint64),
+				("status", C.c_void_p)]
+
+
 class BatchIn(C.Structure):
 	_fields_ = [
 		("n", C.c_uint64),
@@ -113,6 +123,9 @@ def lib():
 		"pvc3_dbatch_download": ([vp, vp, P(BatchOut)], i32),
 		"pvc3_dbatch_checksum": ([vp, vp, u64, P(u64)], i32),
 		"pvc3_project_positions": ([vp, u64, vp, vp, vp, vp], i32),
+		"pvc3_reference_create": ([vp, u32, vp, vp, P(vp)], i32),
+		"pvc3_reference_destroy": ([vp], None),
+		"pvc3_split_match_ops": ([vp, vp, P(SplitIn), P(SplitOut), P(u64), P(u64)], i32),
 		"pvc3_rescore_alignments": ([vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, P(RescoreParams), vp, vp], i32),
 		"pvc3_recalculate_mapq": ([vp, P(MapqBatch), vp, vp, P(MapqStats)], i32),
 		"pvc3_pipeline_create": ([vp, P(PipelineCaps), P(vp)], i32),

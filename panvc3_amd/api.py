@@ -199,6 +199,58 @@ class Context:
 		return out
 
 
+class Reference:
+	"""Reference sequences in HBM (pvc3_reference_*) for Context.split_match_ops."""
+
+	def __init__(self, ctx, sequences):
+		self._L = _lib.lib()
+		self._ctx = ctx
+		self._keep = [np.frombuffer(s if isinstance(s, (bytes, bytearray)) else s.encode(), dtype=np.uint8) for s in sequences]
+		ptrs = (C.c_void_p * max(1, len(self._keep)))(*[a.ctypes.data if a.size else None for a in self._keep])
+		lens = np.array([a.size for a in self._keep], dtype=np.uint64)
+		h = C.c_void_p()
+		check(self._L.pvc3_reference_create(ctx._h, len(self._keep), ptrs, lens.ctypes.data, C.byref(h)))
+		self._h = h
+
+	def close(self):
+		if self._h:
+			self._L.pvc3_reference_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		self.close()
+
+
+def split_match_ops(ctx, reference, sequence, pos, cigars, seqs4, l_seq):
+	"""pvc3_split_match_ops (rewrite-cigar/main.cc:191-284): cigars[i] = array of BAM operations, seqs4[i] = the record's packed bases.
+	Returns (list of operation arrays, list of N-position maps as bytes, statuses)."""
+	L = _lib.lib()
+	n = len(cigars)
+	cigar_off = np.zeros(n + 1, dtype=np.uint64); cigar_off[1:] = np.cumsum([len(c) for c in cigars])
+	cigar = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint32) for c in cigars]) if n and cigar_off[n] else np.zeros(0, dtype=np.uint32))
+	seq_off = np.zeros(n, dtype=np.uint64)
+	if n: seq_off[1:] = np.cumsum([len(b) for b in seqs4])[:-1]
+	seq4 = np.frombuffer(b"".join(bytes(b) for b in seqs4), dtype=np.uint8)
+	sequence = np.ascontiguousarray(sequence, dtype=np.uint32); pos = np.ascontiguousarray(pos, dtype=np.uint32); l_seq = np.ascontiguousarray(l_seq, dtype=np.uint32)
+	si = _lib.SplitIn(n, sequence.ctypes.data, pos.ctypes.data, cigar_off.ctypes.data, cigar.ctypes.data if cigar.size else None, seq_off.ctypes.data,
+					  seq4.ctypes.data if seq4.size else None, seq4.size, l_seq.ctypes.data)
+	out_off = np.zeros(n + 1, dtype=np.uint64); map_off = np.zeros(n + 1, dtype=np.uint64); status = np.zeros(max(1, n), dtype=np.int32)
+	cap_c, cap_m = 0, 0		# the first call asks
+	for _ in range(2):
+		out_c = np.zeros(max(1, cap_c), dtype=np.uint32); out_m = np.zeros(max(1, cap_m), dtype=np.uint8)
+		so = _lib.SplitOut(out_off.ctypes.data, out_c.ctypes.data, cap_c, map_off.ctypes.data, out_m.ctypes.data, cap_m, status.ctypes.data)
+		nc, nm = C.c_uint64(), C.c_uint64()
+		rc = L.pvc3_split_match_ops(ctx._h, reference._h, C.byref(si), C.byref(so), C.byref(nc), C.byref(nm))
+		if -5 == rc:		# PVC3_E_CAPACITY: the sizes needed are in nc, nm
+			cap_c, cap_m = nc.value, nm.value
+			continue
+		check(rc)
+		break
+	else:
+		raise RuntimeError("pvc3_split_match_ops asked for capacity twice")
+	return ([out_c[int(out_off[i]):int(out_off[i + 1])].copy() for i in range(n)], [out_m[int(map_off[i]):int(map_off[i + 1])].tobytes() for i in range(n)], status[:n].copy())
+
+
 class DeviceBatch:
 	"""A batch resident in HBM (pvc3_dbatch_*)."""
 

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpvc3_hip.so")
-SOURCES = ["api.cpp", "records_api.cpp", "index.cpp", "kernels.hip", "project_fast.hip", "project_probes.hip", "project_mid.hip", "project_general.hip", "realign.hip", "mapq.hip", "records.hip"]
+SOURCES = ["api.cpp", "records_api.cpp", "split_api.cpp", "index.cpp", "kernels.hip", "project_fast.hip", "project_probes.hip", "project_mid.hip", "project_general.hip", "realign.hip", "mapq.hip", "records.hip", "split_ops.hip"]
 ARCH = "gfx950"
 
 
@@ -137,7 +137,7 @@ def build_host(force=False, verbose=False):
 	for name, extra in (
 		("panvc3_index_msa", ["-lz"]),
 		("panvc3_project_alignments", ["-L" + HERE, "-lpvc3_hip", "-lpvc3_bgzf", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
-		("panvc3_rewrite_cigar", ["-lz"]),
+		("panvc3_rewrite_cigar", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
 		("panvc3_convert_bed_positions", ["-L" + HERE, "-lpvc3_hip", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
 		("panvc3_recalculate_mapq", ["-L" + HERE, "-lpvc3_hip", "-lpvc3_bgzf", "-lz", "-Wl,-rpath,$ORIGIN/../panvc3_amd", "-Wl,-rpath-link,/opt/rocm/lib"]),
 	):

@@ -231,8 +231,8 @@ def test_io_round_trip_sam_bam(tools, tmp_path):
 	assert [l for l in open(tmp_path / "py.sam").read().split("\n") if l and not l.startswith("@")] == [r.sam_line() for r in recs]
 
 
-def test_rewrite_cigar_tool(tools, built_index):
-	"""bin/panvc3_rewrite_cigar against oracle/rewrite_cigar_tool.py: M -> = / X with the N bit map, and back to M."""
+def _rewrite_cigar_case(built_index):
+	"""rc_in.bam and ref.fa in the index fixture's directory; the records, the lines -S has to print and their CIGARs (oracle/rewrite_cigar_tool.py)."""
 	from oracle import rewrite_cigar_tool as rc
 	from tests.synth import synth
 	tmp_path, fasta = built_index
@@ -269,6 +269,13 @@ def test_rewrite_cigar_tool(tools, built_index):
 		cig, nb = rc.sequence_match(r.cigar, r.seq, seqs[r.rname], r.pos - 1)
 		cig_s.append(cig)
 		want_s.append(expected_line(r, cig, ("XN", "B", ("C", list(nb))) if nb else None))
+	return tmp_path, recs, want_s, cig_s
+
+
+def test_rewrite_cigar_tool(tools, built_index):
+	"""bin/panvc3_rewrite_cigar against oracle/rewrite_cigar_tool.py: M -> = / X with the N bit map, and back to M."""
+	from oracle import rewrite_cigar_tool as rc
+	tmp_path, recs, want_s, cig_s = _rewrite_cigar_case(built_index)
 	p = _run([tools["panvc3_rewrite_cigar"], "-a", "rc_in.bam", "--output-sequence-match-ops", "--reference=ref.fa"], cwd=tmp_path)
 	out = p.stdout.decode().split("\n")
 	assert [l for l in out if l and not l.startswith("@")] == want_s
@@ -282,6 +289,32 @@ def test_rewrite_cigar_tool(tools, built_index):
 	assert [l.split("\t")[5] for l in body] == [rc.alignment_match(r.cigar) if r.cigar != "*" else "*" for r in recs]
 	bad = _run([tools["panvc3_rewrite_cigar"], "-a", "rc_in.bam", "-S"], cwd=tmp_path, check=False)
 	assert bad.returncode != 0 and b"--reference is required" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_rewrite_cigar_tool_on_the_gpu(tools, built_index):
+	"""--device=0: the M operations split and the N positions found by pvc3_split_match_ops; the same lines as the restatement's, and
+	the same bytes as the host's run but for the command line in @PG; the records the tool refuses are refused with the same words."""
+	tmp_path, recs, want_s, cig_s = _rewrite_cigar_case(built_index)
+	host = _run([tools["panvc3_rewrite_cigar"], "-a", "rc_in.bam", "-S", "--reference=ref.fa"], cwd=tmp_path).stdout.decode().split("\n")
+	gpu = _run([tools["panvc3_rewrite_cigar"], "-a", "rc_in.bam", "-S", "--reference=ref.fa", "--device=0"], cwd=tmp_path).stdout.decode().split("\n")
+	assert [l for l in gpu if l and not l.startswith("@")] == want_s
+	assert [l for l in gpu if not l.startswith("@PG\tID:panvc3.rewrite-cigar")] == [l for l in host if not l.startswith("@PG\tID:panvc3.rewrite-cigar")]
+	_run([tools["panvc3_rewrite_cigar"], "-a", "rc_in.bam", "-S", "-r", "ref.fa", "-b", "-o", "rc_gpu.bam", "--device=0"], cwd=tmp_path)
+	_run([tools["panvc3_rewrite_cigar"], "-a", "rc_in.bam", "-S", "-r", "ref.fa", "-b", "-o", "rc_host.bam"], cwd=tmp_path)
+	assert bamio.read_bam(tmp_path / "rc_gpu.bam")[1:] == bamio.read_bam(tmp_path / "rc_host.bam")[1:]
+	# an alignment past the end of its sequence: both refuse it
+	short = tmp_path / "short.fa"
+	text = open(tmp_path / "ref.fa").read().split(">")
+	with open(short, "w") as f:
+		for part in text[1:]:
+			lines = part.split("\n")
+			f.write(">" + lines[0] + "\n" + "".join(lines[1:])[:40] + "\n")
+	for extra in ([], ["--device=0"]):
+		bad = _run([tools["panvc3_rewrite_cigar"], "-a", "rc_in.bam", "-S", "-r", "short.fa"] + extra, cwd=tmp_path, check=False)
+		assert bad.returncode != 0 and b"extends past the end of its reference sequence" in bad.stderr, extra
+	bad = _run([tools["panvc3_rewrite_cigar"], "-a", "rc_in.bam", "-M", "--device=0"], cwd=tmp_path, check=False)
+	assert bad.returncode != 0 and b"--device has an effect" in bad.stderr
 
 
 @pytest.mark.gpu

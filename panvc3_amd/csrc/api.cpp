@@ -191,7 +191,7 @@ int enqueue_projection(pvc3_context *ctx, pvc3_dbatch *b)
 	HIP_TRY(hipMemsetAsync(b->work.wave_stats, 0, 3 * (uint64_t) project_wave_count(b->n) * WAVE_STATS * sizeof(unsigned long long), s));
 	b->timed = ctx->timing;
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
-	if (int const e = ctx->have_windows ? launch_project_fast(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, ctx->wide_windows, s)
+	if (int const e = ctx->have_windows ? launch_project_fast(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, ctx->wide_windows, ctx->gap_dense, s)
 			: launch_project_probes(ctx->d_entries, ctx->n_entries, b->in, b->work, ctx->fast_path, s))
 		return set_error(PVC3_E_HIP, "k_project_fast launch: %s", hipGetErrorString((hipError_t) e));
 	if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
@@ -451,6 +451,9 @@ int pvc3_context_upload_index(pvc3_context *ctx, pvc3_index const *idx)
 	mark_("sizes");
 	ctx->have_windows = false;
 	ctx->wide_windows = pwin_shift > 6;
+	// rows with more than one gap column in sixteen (k_project_mid's own measure): hardly a window of theirs is clean (k_project_fast <.., wary>)
+	ctx->gap_dense = false;
+	for (auto const &e : idx->entries) ctx->gap_dense = ctx->gap_dense || (e.n_zeros && 16 * (e.n_cols - e.n_zeros) > e.n_cols);
 	for (size_t i = 0; i < idx->entries.size(); ++i)
 	{
 		host_entry const &e = idx->entries[i];

@@ -29,6 +29,7 @@ struct pvc3_context
 	pvc3_params params{0, 0, -1, 0};
 
 	// Options.
+	bool gap_dense{};					// the index has rows with a gap column in sixteen or more (pvc3_context_upload_index)
 	uint32_t realign_waves{8192};		// packed alignment kernels: one 64-thread block each
 	uint32_t big_waves{1024};			// striped alignment kernel (runs that do not fit the packed kernels): waves = scratch slots
 	uint32_t realign_lds_bytes{};

@@ -121,7 +121,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 
 // t_wide: 256-byte windows, for reads of up to 255 bases.  Only there can a record need a ninth piece of text, and the code
 // that fetches it costs the narrow kernel registers it does not have.
-template <bool t_wide>
+template <bool t_wide, bool t_wary = false>
 __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_entry const *__restrict__ entries, uint32_t n_entries, dev_batch_in const in, dev_batch_work const W, uint32_t use_fast_path)
 {
 	uint32_t const lane = lane_id();
@@ -207,6 +207,17 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 	uint64_t next_chunk_base = (g_begin < g_end && !batch_bad) ? rfl64(in.cigar_off[64 * g_begin]) : 0;
 	u32x4 next_chunk = load_chunk(next_chunk_base);
 
+	// The compare is requested before the window's header says whether it will be needed (one memory round trip instead of two).
+	// Where hardly any window is clean — rows with a gap every few dozen columns — nearly all of that is thrown away.  The wary
+	// form of the kernel (t_wary: launched for an index with such rows, pvc3_context_upload_index decides) keeps a credit per wave,
+	// 0 .. 3: up for a group of which one candidate in sixteen was finished here, down otherwise; a wave without credit asks for the
+	// compare only in every eighth group (whose outcome can earn the credit back) and leaves the other groups' candidates to
+	// k_project_mid, which takes any record.  C3G: 2.5 -> 1.8 ms.  The choice depends on the wave's own history alone, so a run
+	// repeats itself.  (A form of its own, because the plain kernel has no register to spare: with the credit in it — even in LDS —
+	// it spills, and C3 is 3 % slower.)
+	__shared__ uint32_t lds_credit[t_wary ? 4 : 1];
+	uint32_t *const credit = &lds_credit[t_wary ? rfl(threadIdx.x >> 6) : 0];
+	if (t_wary && 0 == lane) *credit = 3;
 	for (uint64_t g = g_begin; g < g_end; ++g)
 	{
 		uint64_t const rec = g * 64 + lane;
@@ -389,7 +400,9 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 			// lane of the eighth piece loads it itself.)
 			uint32_t const bytes = (pieces <= FAST_WORDS) ? 16 * pieces : 16 * FAST_WORDS + 4;
 			bool const fits = (pieces <= FAST_WORDS + (t_wide ? 1 : 0)) && (PWIN_HEADER + 4 * (nib >> 3) + bytes <= (2u << sh));
-			cand = use_fast_path && has_win && simple && (U < FAST_MAX_BASES) && fits;
+			bool speculate = true;
+			if constexpr (t_wary) speculate = (0 != *credit) || (0 == ((g - g_begin) & 7));
+			cand = speculate && use_fast_path && has_win && simple && (U < FAST_MAX_BASES) && fits;
 			bits |= cand ? B_CAND : 0u;
 		}
 		bool fast = false;
@@ -552,6 +565,12 @@ __global__ __launch_bounds__(256, PVC3_FAST_MIN_WAVES) void k_project_fast(dev_e
 #ifdef PVC3_ABL_NO_COMPARE
 		fast = false;
 #endif
+		if constexpr (t_wary)
+		{
+			uint32_t const tried = (uint32_t) popc64(ballot(0 != (bits & B_CAND))), won = (uint32_t) popc64(ballot(fast));
+			uint32_t const have = *credit;
+			if (tried && 0 == lane) *credit = (16 * won >= tried) ? ((have < 3) ? (have + 1) : 3u) : ((have > 0) ? (have - 1) : 0u);
+		}
 		if (ballot(fast))
 		{
 			uint32_t const R = fast ? ref_consumed : 0;
@@ -726,15 +745,17 @@ uint32_t grid_blocks(uint64_t n)
 
 uint32_t project_wave_count(uint64_t n) { return 4 * grid_blocks(n); }
 
-int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, bool wide_windows, void *stream)
+int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, bool wide_windows, bool wary, void *stream)
 {
 	if (0 == in.n) return 0;
 	// PVC3_FAST_DYN_LDS: bytes of unused dynamic LDS per block — an occupancy experiment (fewer blocks per CU), not an option.
 	static uint32_t const dyn_lds = [] { char const *e = getenv("PVC3_FAST_DYN_LDS"); return e ? (uint32_t) atoi(e) : 0u; }();
-	if (wide_windows)
-		hipLaunchKernelGGL(k_project_fast <true>, dim3(grid_blocks(in.n)), dim3(256), dyn_lds, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
-	else
-		hipLaunchKernelGGL(k_project_fast <false>, dim3(grid_blocks(in.n)), dim3(256), dyn_lds, (hipStream_t) stream, entries, n_entries, in, work, use_fast_path);
+	dim3 const grid(grid_blocks(in.n)), block(256);
+	hipStream_t const s = (hipStream_t) stream;
+	if (wide_windows && wary) hipLaunchKernelGGL((k_project_fast <true, true>), grid, block, dyn_lds, s, entries, n_entries, in, work, use_fast_path);
+	else if (wide_windows) hipLaunchKernelGGL((k_project_fast <true, false>), grid, block, dyn_lds, s, entries, n_entries, in, work, use_fast_path);
+	else if (wary) hipLaunchKernelGGL((k_project_fast <false, true>), grid, block, dyn_lds, s, entries, n_entries, in, work, use_fast_path);
+	else hipLaunchKernelGGL((k_project_fast <false, false>), grid, block, dyn_lds, s, entries, n_entries, in, work, use_fast_path);
 	return (int) hipGetLastError();
 }
 

@@ -272,7 +272,7 @@ struct dev_params
 };
 
 // Launch wrappers (kernels.hip).  All enqueue on `stream` and return a hipError_t as int.
-int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, bool wide_windows, void *stream);
+int launch_project_fast(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, uint32_t use_fast_path, bool wide_windows, bool wary, void *stream);
 int launch_project_mid(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
 int launch_project_general(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, void *stream);
 int launch_realign(dev_entry const *entries, uint32_t n_entries, dev_batch_in const &in, dev_batch_work const &work, dev_params const *params, uint32_t n_waves, uint32_t big_waves, uint32_t lds_budget, uint32_t packed, void *stream);	// consumes run_list / run_count
